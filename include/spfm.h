@@ -1,0 +1,177 @@
+/*
+ * spfm.h -- C ABI of the MI355X (gfx950) sparse factorization-machine
+ * proximal coordinate-descent core (libspfm_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of neonnnnn/sparsepoly:
+ * every entry point replaces one interpreter->Numba call (or one NumPy block)
+ * of the reference's epoch drivers.  Citations are into the reference tree
+ * (sparsepoly/...).  Plain pointers and sizes only; no C++/torch types; no
+ * exception crosses the boundary.  All host buffers stay owned by the caller
+ * and are copied during the call.
+ *
+ * Conventions
+ *   return 0 = ok; <0 = error (spfm_last_error() gives the text)
+ *     SPFM_ERR_INVALID      -> the reference raises ValueError for this input
+ *     SPFM_ERR_RUNTIME      -> HIP/RCCL failure
+ *     SPFM_ERR_UNSUPPORTED  -> valid for the reference, outside this library
+ *   A handle is not thread-safe; distinct handles are independent.  Each handle
+ *   owns one HIP stream; calls return after the stream has drained unless noted.
+ *   Host arrays are float64 / int32 / int64 as in the reference
+ *   (dataset.py:60-66, base.py:41-49); device storage precision is the handle's
+ *   dtype (values, A caches, y_pred in f32 or f64; reductions, prox and
+ *   parameters always f64).
+ */
+#ifndef SPFM_H
+#define SPFM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spfm_engine* spfm_handle;
+
+#define SPFM_OK 0
+#define SPFM_ERR_INVALID (-1)
+#define SPFM_ERR_RUNTIME (-2)
+#define SPFM_ERR_UNSUPPORTED (-3)
+
+/* storage precision of X values, A caches, y_pred, y on the device */
+#define SPFM_F32 0
+#define SPFM_F64 1
+
+/* loss.py:74-80 registries */
+#define SPFM_LOSS_SQUARED 0
+#define SPFM_LOSS_SQUARED_HINGE 1
+#define SPFM_LOSS_LOGISTIC 2
+
+/* regularizer/__init__.py:8-15 */
+#define SPFM_REG_L1 0
+#define SPFM_REG_L21 1
+#define SPFM_REG_SQUAREDL12 2
+#define SPFM_REG_SQUAREDL21 3
+#define SPFM_REG_OMEGATI 4
+#define SPFM_REG_OMEGACS 5
+
+#define SPFM_SOLVER_PCD 0
+#define SPFM_SOLVER_PBCD 1
+
+/* coordinate schedules (spfm_set_schedule) */
+#define SPFM_SCHED_EXACT 0   /* keep the given order; batch = maximal run of row-disjoint columns */
+#define SPFM_SCHED_COLORED 1 /* first-fit colouring of the column conflict graph; order is permuted */
+
+#define SPFM_MAX_DEGREE 6
+
+/* -- lifetime ------------------------------------------------------------ */
+int spfm_create(spfm_handle* out, int device_id, int dtype);
+void spfm_destroy(spfm_handle h);
+/* h may be NULL: returns the calling thread's last creation error */
+const char* spfm_last_error(spfm_handle h);
+/* library / device identification, e.g. "gfx950:sramecc+:xnack-" */
+int spfm_device_name(spfm_handle h, char* out, int cap);
+
+/* -- data ------------------------------------------------------------------
+ * Replaces get_dataset(X, order="fortran") (dataset.py:119-123, CSCDataset
+ * :94-116) plus col_norm_sq = row_norms(X.T, squared=True)
+ * (sparse_factorization_machines.py:406-409).  CSC of the LOCAL row shard:
+ * indptr[d+1] (int64), indices[nnz] (int32 row ids in [0,n)), data[nnz], y[n].
+ * The library also builds the CSR image it needs for the row-oriented passes. */
+int spfm_set_data_csc(spfm_handle h, int64_t n, int32_t d, const int64_t* indptr,
+                      const int32_t* indices, const double* data, const double* y);
+
+/* -- parameters -------------------------------------------------------------
+ * P is (n_orders, k, d) row-major as self.P_ (sparse_factorization_machines.py
+ * :383-389), w (d), lams (k, each +-1: :403-404).  d must equal the data's
+ * n_features when data is present; a handle without data (predict only) takes d
+ * from here.  get copies the live device state back (pcd callbacks see live P_,
+ * :227-228). */
+int spfm_set_params(spfm_handle h, int n_orders, int k, int32_t d, const double* P,
+                    const double* w, const double* lams);
+int spfm_get_params(spfm_handle h, double* P, double* w);
+
+/* -- configuration ----------------------------------------------------------
+ * loss (base.py:18-25), regularizer (base.py:27-34) and the solver whose cache
+ * protocol is initialised: regularizer.init_cache_pcd / init_cache_pbcd(degree,
+ * d, k) (sparse_factorization_machines.py:194,282).  Errors as the reference:
+ * SquaredL12 degree>2 / SquaredL21 degree!=2 -> SPFM_ERR_INVALID
+ * (squaredl12.py:25-26, squaredl21.py:28-29); solver/regularizer pairs the
+ * reference cannot run (README.md:28-32) -> SPFM_ERR_INVALID. */
+int spfm_configure(spfm_handle h, int solver, int loss, int regularizer, int top_degree);
+
+/* -- initial prediction ----------------------------------------------------
+ * y_pred = _get_output(X) (sparse_factorization_machines.py:437-451, kernels.py
+ * :71-115,140-153): ANOVA kernel of order `degree` on P[0], + X.w if fit_linear,
+ * + the order-2 term on P[1] if add_lower_deg2 (fit_lower='explicit', degree 3). */
+int spfm_init_pred(spfm_handle h, int degree, int fit_linear, int add_lower_deg2);
+int spfm_get_y_pred(spfm_handle h, double* out);
+/* sum_i loss(y_pred_i, y_i) (loss.py:20-21,34-42,61-65) of the local shard */
+int spfm_loss_sum(spfm_handle h, double* out);
+
+/* Same computation on a caller-supplied CSR matrix (predict(),
+ * sparse_factorization_machines.py:453-458).  indptr[n+1] int64, indices int32
+ * column ids in [0,d). */
+int spfm_predict_csr(spfm_handle h, int64_t n, const int64_t* indptr, const int32_t* indices,
+                     const double* data, int degree, int fit_linear, int add_lower_deg2,
+                     double* out);
+
+/* -- coordinate schedule ----------------------------------------------------
+ * The reference's epoch functions take the visiting order as an argument
+ * (indices_feature: pcd.py:86-87,97; pbcd.py:99,110; cd_linear.py:8,10).
+ * This call fixes the order for the following epochs and partitions it into
+ * batches of columns that share no row, which the device processes as one
+ * dependent step (results equal the sequential sweep in `order_out`).
+ *   conflict_indptr/indices: CSC structure used for the disjointness test; pass
+ *     NULL to use the local data (single process).  Multi-GPU: pass the GLOBAL
+ *     structure so that all ranks derive the identical schedule.
+ *   order_out[d]: the order actually used (== indices_feature for EXACT).
+ *   n_batches_out: number of dependent steps per sweep. */
+int spfm_set_schedule(spfm_handle h, int mode, const int32_t* indices_feature,
+                      const int64_t* conflict_indptr, const int32_t* conflict_indices,
+                      int64_t conflict_n_rows, int32_t* order_out, int32_t* n_batches_out);
+
+/* Host-only form of the batch construction (no handle, no device): fills
+ * order_out[d] and batch_ptr_out[<= d+1] (batch b = order_out[batch_ptr[b] ..
+ * batch_ptr[b+1])) and returns the number of batches in n_batches_out.
+ * max_batch <= 0 selects the library default (4096 columns per step). */
+int spfm_schedule_build(int mode, int64_t n_rows, int32_t d, const int64_t* indptr,
+                        const int32_t* indices, const int32_t* indices_feature, int max_batch,
+                        int32_t* order_out, int32_t* batch_ptr_out, int32_t* n_batches_out);
+
+/* -- epochs ------------------------------------------------------------------
+ * One call = one reference epoch function call.  viol receives sum_viol. */
+
+/* cd_linear._cd_linear_epoch (optimizer/cd_linear.py:8-33) */
+int spfm_cd_linear_epoch(spfm_handle h, double alpha, double* viol);
+
+/* pcd.pcd_epoch (optimizer/pcd.py:71-137) on P[order_idx] with `degree`;
+ * indices_component[n_comp] as pcd.py:86,92. */
+int spfm_pcd_epoch(spfm_handle h, int order_idx, int degree, double beta, double gamma,
+                   double eta, const int32_t* indices_component, int n_comp, double* viol);
+
+/* pbcd.pbcd_epoch (optimizer/pbcd.py:82-148) on P[order_idx] */
+int spfm_pbcd_epoch(spfm_handle h, int order_idx, int degree, double beta, double gamma,
+                    double eta, double* viol);
+
+/* -- multi-GPU (one process per GPU, RCCL over xGMI) ---------------------------
+ * Rows are sharded; the column partial sums of every step are all-reduced
+ * (sum, f64) so that every rank applies the identical prox.  id is an opaque
+ * 128-byte RCCL unique id created on rank 0 and shipped by the caller. */
+int spfm_comm_unique_id(char* id128);
+int spfm_comm_init(spfm_handle h, const char* id128, int n_ranks, int rank);
+
+/* -- instrumentation ----------------------------------------------------------
+ * Device time (ms, HIP events on the handle's stream) and launch count of the
+ * dominant kernel family since the last reset: which = 0 pcd gradient gather,
+ * 1 pcd sync scatter, 2 pbcd gradient, 3 pbcd sync, 4 cd_linear step.
+ * Timing is only collected when enabled (it serialises the stream). */
+int spfm_profile_enable(spfm_handle h, int on);
+int spfm_profile_get(spfm_handle h, int which, double* ms, int64_t* launches, int64_t* nnz);
+int spfm_profile_reset(spfm_handle h);
+/* use hipGraph replay for the per-pass launch sequences (default on) */
+int spfm_set_use_graph(spfm_handle h, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPFM_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of the C ABI in ``include/spfm.h`` (``lib/libspfm_hip.so``).
+
+This is the only way the package reaches the device: there is no CPU fallback.
+If the shared library is missing or no HIP device is present, the calls below
+raise ``RuntimeError`` -- the estimators never silently compute elsewhere.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspfm_hip.so")
+
+SPFM_OK, SPFM_ERR_INVALID, SPFM_ERR_RUNTIME, SPFM_ERR_UNSUPPORTED = 0, -1, -2, -3
+DTYPES = {"f32": 0, "f64": 1}
+LOSSES = {"squared": 0, "squared_hinge": 1, "logistic": 2}
+REGULARIZERS = {"l1": 0, "l21": 1, "squaredl12": 2, "squaredl21": 3, "omegati": 4, "omegacs": 5}
+SOLVERS = {"pcd": 0, "pbcd": 1}
+SCHEDULES = {"exact": 0, "colored": 1}
+
+# every symbol include/spfm.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "spfm_create", "spfm_destroy", "spfm_last_error", "spfm_device_name", "spfm_set_data_csc",
+    "spfm_set_params", "spfm_get_params", "spfm_configure", "spfm_init_pred", "spfm_get_y_pred",
+    "spfm_loss_sum", "spfm_predict_csr", "spfm_set_schedule", "spfm_schedule_build",
+    "spfm_cd_linear_epoch",
+    "spfm_pcd_epoch", "spfm_pbcd_epoch", "spfm_comm_unique_id", "spfm_comm_init",
+    "spfm_profile_enable", "spfm_profile_get", "spfm_profile_reset", "spfm_set_use_graph",
+]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_h = C.c_void_p
+
+_lib = None
+
+
+def load():
+    """dlopen libspfm_hip.so and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "sparsepoly_amd: HIP extension %s is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`bash sparsepoly_amd/csrc/build.sh`; there is no CPU fallback." % LIB_PATH
+        )
+    L = C.CDLL(LIB_PATH)
+    L.spfm_create.argtypes = [C.POINTER(_h), C.c_int, C.c_int]
+    L.spfm_destroy.argtypes = [_h]
+    L.spfm_destroy.restype = None
+    L.spfm_last_error.argtypes = [_h]
+    L.spfm_last_error.restype = C.c_char_p
+    L.spfm_device_name.argtypes = [_h, C.c_char_p, C.c_int]
+    L.spfm_set_data_csc.argtypes = [_h, C.c_int64, C.c_int32, _lp, _ip, _dp, _dp]
+    L.spfm_set_params.argtypes = [_h, C.c_int, C.c_int, C.c_int32, _dp, _dp, _dp]
+    L.spfm_get_params.argtypes = [_h, _dp, _dp]
+    L.spfm_configure.argtypes = [_h, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.spfm_init_pred.argtypes = [_h, C.c_int, C.c_int, C.c_int]
+    L.spfm_get_y_pred.argtypes = [_h, _dp]
+    L.spfm_loss_sum.argtypes = [_h, _dp]
+    L.spfm_predict_csr.argtypes = [_h, C.c_int64, _lp, _ip, _dp, C.c_int, C.c_int, C.c_int, _dp]
+    L.spfm_set_schedule.argtypes = [_h, C.c_int, _ip, _lp, _ip, C.c_int64, _ip, _ip]
+    L.spfm_schedule_build.argtypes = [C.c_int, C.c_int64, C.c_int32, _lp, _ip, _ip, C.c_int, _ip,
+                                      _ip, _ip]
+    L.spfm_cd_linear_epoch.argtypes = [_h, C.c_double, _dp]
+    L.spfm_pcd_epoch.argtypes = [_h, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _ip,
+                                 C.c_int, _dp]
+    L.spfm_pbcd_epoch.argtypes = [_h, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _dp]
+    L.spfm_comm_unique_id.argtypes = [C.c_char_p]
+    L.spfm_comm_init.argtypes = [_h, C.c_char_p, C.c_int, C.c_int]
+    L.spfm_profile_enable.argtypes = [_h, C.c_int]
+    L.spfm_profile_get.argtypes = [_h, C.c_int, _dp, _lp, _lp]
+    L.spfm_profile_reset.argtypes = [_h]
+    L.spfm_set_use_graph.argtypes = [_h, C.c_int]
+    for name in SYMBOLS:
+        f = getattr(L, name)
+        if name not in ("spfm_destroy", "spfm_last_error"):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+def i64(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(_lp)

@@ -1,0 +1,1186 @@
+// spfm_engine.hip -- host engine + C ABI (include/spfm.h) of the gfx950 sparse-FM
+// proximal coordinate-descent core.  See DESIGN.md for the execution model.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/spfm.h"
+#include "spfm_kernels.hip.h"
+
+namespace spfm {
+void schedule_exact(int64_t, int32_t, const int64_t*, const int32_t*, const int32_t*, int,
+                    std::vector<int32_t>&);
+void schedule_colored(int64_t, int32_t, const int64_t*, const int32_t*, const int32_t*, int,
+                      std::vector<int32_t>&, std::vector<int32_t>&);
+void csc_to_csr(int64_t, int32_t, const int64_t*, const int32_t*, std::vector<int64_t>&,
+                std::vector<int32_t>&, std::vector<int64_t>&);
+}  // namespace spfm
+
+using namespace spfm;
+
+static thread_local std::string g_create_error;
+
+// ------------------------------------------------------------------ RCCL (lazy)
+// RCCL is loaded with dlopen so that the single-GPU path has no link dependency
+// and shares whichever librccl the process already holds (PyTorch ships one).
+namespace {
+typedef struct ncclComm* ncclComm_t;
+struct ncclUniqueId_ {
+    char internal[128];
+};
+enum { ncclSum_ = 0 };
+enum { ncclFloat64_ = 8 };
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId_*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId_, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load(std::string& err) {
+        if (lib) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* nm : names) {
+            lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) {
+            err = std::string("cannot load librccl: ") + dlerror();
+            return false;
+        }
+        GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+        AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) {
+            err = "librccl lacks a required symbol";
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+}  // namespace
+
+// --------------------------------------------------------------------- buffers
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t b) {
+        if (b <= bytes && p) return hipSuccess;
+        release();
+        if (b == 0) b = 16;
+        hipError_t e = hipMalloc(&p, b);
+        if (e == hipSuccess) bytes = b;
+        return e;
+    }
+    template <typename U>
+    U* as() const {
+        return reinterpret_cast<U*>(p);
+    }
+};
+
+#define HIPC(expr)                                                                       \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            err = std::string(#expr) + ": " + hipGetErrorString(_e);                     \
+            return SPFM_ERR_RUNTIME;                                                     \
+        }                                                                                \
+    } while (0)
+
+#define FAIL(code, msg) \
+    do {                \
+        err = (msg);    \
+        return (code);  \
+    } while (0)
+
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+struct ProfSlot {
+    std::vector<hipEvent_t> ev;  // pairs
+    size_t used = 0;
+    double ms = 0.0;
+    int64_t launches = 0, nnz = 0;
+};
+
+struct spfm_engine {
+    int device = 0, dtype = SPFM_F32;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string devname;
+
+    // data
+    int64_t n = 0, nnz = 0;
+    int d = 0;
+    bool have_data = false;
+    DevBuf cptr, cidx, cval, rptr, ridx, rval, yy, A, col_norm;
+    std::vector<int64_t> h_cptr;
+    std::vector<int32_t> h_cidx;
+    bool col_norm_reduced = false;
+
+    // params
+    int n_orders = 0, k = 0;
+    bool have_params = false;
+    DevBuf P, Pt, w, lams;
+    bool p_valid = true, pt_valid = false;  // which of P (k,d) / Pt (d,k) is current
+    std::vector<double> h_lams;
+
+    // config
+    int solver = -1, loss = 0, reg = 0, top_degree = 0;
+    bool configured = false;
+    DevBuf abs_p, norms, cache, dcache;
+
+    // schedule
+    std::vector<int32_t> order, batch_ptr;
+    DevBuf d_order;
+    int max_batch_cols = 0;
+    bool have_schedule = false;
+    int64_t sched_version = 0;
+
+    // work
+    DevBuf part, delta, pold, viol_col, scalar, ctl, comp_order, pred_tmp, partial;
+    double* h_scalar = nullptr;  // pinned
+
+    // graphs
+    bool use_graph = true;
+    std::map<std::string, hipGraphExec_t> graphs;
+
+    // comm
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1, rank = 0;
+
+    // profile
+    bool prof_on = false;
+    ProfSlot prof[5];
+
+    ~spfm_engine() {
+        clear_graphs();
+        for (auto& ps : prof)
+            for (auto e : ps.ev) (void)hipEventDestroy(e);
+        if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+        if (h_scalar) (void)hipHostFree(h_scalar);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    void clear_graphs() {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear();
+    }
+
+    RegState regstate() {
+        RegState rs;
+        rs.abs_p = abs_p.as<double>();
+        rs.norms = norms.as<double>();
+        rs.cache = cache.as<double>();
+        rs.dcache = dcache.as<double>();
+        return rs;
+    }
+
+    size_t tsize() const { return dtype == SPFM_F32 ? 4 : 8; }
+
+    int sync() {
+        HIPC(hipStreamSynchronize(stream));
+        return SPFM_OK;
+    }
+
+    // ---------------------------------------------------------------- profiling
+    // One event pair per recorded launch (bounded pool); launches beyond the pool
+    // are not counted, so ms / launches / nnz always describe the same set.
+    static constexpr size_t kProfPool = 32768;
+    bool prof_armed = false;
+    void prof_begin(int which, int64_t nnz_launch) {
+        prof_armed = false;
+        if (!prof_on) return;
+        ProfSlot& ps = prof[which];
+        if (ps.used + 2 > kProfPool) return;
+        if (ps.used + 2 > ps.ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess) return;
+            if (hipEventCreate(&b) != hipSuccess) {
+                (void)hipEventDestroy(a);
+                return;
+            }
+            ps.ev.push_back(a);
+            ps.ev.push_back(b);
+        }
+        ps.launches++;
+        ps.nnz += nnz_launch;
+        (void)hipEventRecord(ps.ev[ps.used], stream);
+        prof_armed = true;
+    }
+    void prof_end(int which) {
+        if (!prof_armed) return;
+        ProfSlot& ps = prof[which];
+        (void)hipEventRecord(ps.ev[ps.used + 1], stream);
+        ps.used += 2;
+        prof_armed = false;
+    }
+    void prof_collect() {
+        if (!prof_on) return;
+        (void)hipStreamSynchronize(stream);
+        for (auto& ps : prof) {
+            for (size_t i = 0; i + 1 < ps.used; i += 2) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ps.ev[i], ps.ev[i + 1]) == hipSuccess) ps.ms += ms;
+            }
+            ps.used = 0;
+        }
+    }
+
+    int64_t batch_nnz(int b) const {
+        int64_t s = 0;
+        for (int q = batch_ptr[b]; q < batch_ptr[b + 1]; ++q)
+            s += h_cptr[order[q] + 1] - h_cptr[order[q]];
+        return s;
+    }
+
+    // ------------------------------------------------------------------- comm
+    int allreduce(double* buf, size_t count) {
+        if (!comm) return SPFM_OK;
+        int rc = g_rccl.AllReduce(buf, buf, count, ncclFloat64_, ncclSum_, comm, stream);
+        if (rc != 0) {
+            err = std::string("ncclAllReduce: ") +
+                  (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+            return SPFM_ERR_RUNTIME;
+        }
+        return SPFM_OK;
+    }
+
+    int ensure_col_norm() {
+        if (col_norm_reduced || !comm) return SPFM_OK;
+        int rc = allreduce(col_norm.as<double>(), (size_t)d);
+        if (rc) return rc;
+        col_norm_reduced = true;
+        return SPFM_OK;
+    }
+
+    // --------------------------------------------------------- P <-> Pt images
+    int ensure_p() {
+        if (p_valid) return SPFM_OK;
+        for (int o = 0; o < n_orders; ++o) {
+            const size_t off = (size_t)o * k * d;
+            hipLaunchKernelGGL(transpose_kernel, dim3(cdiv((int64_t)k * d, 256)), dim3(256), 0,
+                               stream, Pt.as<double>() + off, d, k, P.as<double>() + off);
+        }
+        HIPC(hipGetLastError());
+        p_valid = true;
+        return SPFM_OK;
+    }
+    int ensure_pt() {
+        if (pt_valid) return SPFM_OK;
+        HIPC(Pt.alloc(sizeof(double) * (size_t)n_orders * k * d));
+        for (int o = 0; o < n_orders; ++o) {
+            const size_t off = (size_t)o * k * d;
+            hipLaunchKernelGGL(transpose_kernel, dim3(cdiv((int64_t)k * d, 256)), dim3(256), 0,
+                               stream, P.as<double>() + off, k, d, Pt.as<double>() + off);
+        }
+        HIPC(hipGetLastError());
+        pt_valid = true;
+        return SPFM_OK;
+    }
+
+    // ---------------------------------------------------------------- graph util
+    // Runs `body` (which only enqueues work on `stream`) either directly or, when
+    // graphs are enabled, captured once under `key` and replayed.
+    template <typename F>
+    int run_cached(const std::string& key, F&& body) {
+        const bool graph_ok = use_graph && !prof_on && !comm;
+        if (!graph_ok) return body();
+        auto it = graphs.find(key);
+        if (it == graphs.end()) {
+            hipGraph_t g = nullptr;
+            HIPC(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            int rc = body();
+            hipError_t e = hipStreamEndCapture(stream, &g);
+            if (rc != SPFM_OK) {
+                if (g) (void)hipGraphDestroy(g);
+                return rc;
+            }
+            if (e != hipSuccess) {
+                err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e);
+                return SPFM_ERR_RUNTIME;
+            }
+            hipGraphExec_t ge = nullptr;
+            e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) {
+                err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+                return SPFM_ERR_RUNTIME;
+            }
+            it = graphs.emplace(key, ge).first;
+        }
+        HIPC(hipGraphLaunch(it->second, stream));
+        return SPFM_OK;
+    }
+
+    // =================================================================== data
+    template <typename T>
+    int set_data_t(const int64_t* indptr, const int32_t* indices, const double* data,
+                   const double* y) {
+        std::vector<int64_t> h_rptr, perm;
+        std::vector<int32_t> h_ridx;
+        csc_to_csr(n, d, indptr, indices, h_rptr, h_ridx, perm);
+        std::vector<T> cv((size_t)nnz), rv((size_t)nnz);
+        for (int64_t ii = 0; ii < nnz; ++ii) cv[(size_t)ii] = (T)data[ii];
+        for (int64_t ii = 0; ii < nnz; ++ii) rv[(size_t)ii] = cv[(size_t)perm[(size_t)ii]];
+        std::vector<T> hy((size_t)n * 2);
+        for (int64_t i = 0; i < n; ++i) {
+            hy[(size_t)2 * i] = (T)0;
+            hy[(size_t)2 * i + 1] = (T)y[i];
+        }
+        HIPC(cptr.alloc(sizeof(int64_t) * ((size_t)d + 1)));
+        HIPC(cidx.alloc(sizeof(int32_t) * (size_t)nnz));
+        HIPC(cval.alloc(sizeof(T) * (size_t)nnz));
+        HIPC(rptr.alloc(sizeof(int64_t) * ((size_t)n + 1)));
+        HIPC(ridx.alloc(sizeof(int32_t) * (size_t)nnz));
+        HIPC(rval.alloc(sizeof(T) * (size_t)nnz));
+        HIPC(yy.alloc(sizeof(T) * 2 * (size_t)n));
+        HIPC(col_norm.alloc(sizeof(double) * (size_t)d));
+        HIPC(hipMemcpyAsync(cptr.p, indptr, sizeof(int64_t) * ((size_t)d + 1),
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(cidx.p, indices, sizeof(int32_t) * (size_t)nnz,
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(cval.p, cv.data(), sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice,
+                            stream));
+        HIPC(hipMemcpyAsync(rptr.p, h_rptr.data(), sizeof(int64_t) * ((size_t)n + 1),
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(ridx.p, h_ridx.data(), sizeof(int32_t) * (size_t)nnz,
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(rval.p, rv.data(), sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice,
+                            stream));
+        HIPC(hipMemcpyAsync(yy.p, hy.data(), sizeof(T) * 2 * (size_t)n, hipMemcpyHostToDevice,
+                            stream));
+        hipLaunchKernelGGL((col_norm_kernel<T>), dim3(cdiv((int64_t)d * 64, kBlock)),
+                           dim3(kBlock), 0, stream, d, cptr.as<int64_t>(), cval.as<T>(),
+                           col_norm.as<double>());
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(stream));  // host staging vectors die here
+        return SPFM_OK;
+    }
+
+    int set_data(int64_t n_, int32_t d_, const int64_t* indptr, const int32_t* indices,
+                 const double* data, const double* y) {
+        if (n_ < 0 || d_ <= 0 || !indptr || !y) FAIL(SPFM_ERR_INVALID, "set_data: bad arguments");
+        if (n_ >= (int64_t)1 << 31) FAIL(SPFM_ERR_UNSUPPORTED, "n_samples must be < 2^31");
+        if (indptr[0] != 0) FAIL(SPFM_ERR_INVALID, "set_data: indptr[0] != 0");
+        for (int j = 0; j < d_; ++j)
+            if (indptr[j + 1] < indptr[j]) FAIL(SPFM_ERR_INVALID, "set_data: indptr not monotone");
+        const int64_t nz = indptr[d_];
+        for (int64_t ii = 0; ii < nz; ++ii)
+            if (indices[ii] < 0 || indices[ii] >= n_)
+                FAIL(SPFM_ERR_INVALID, "set_data: row index out of range");
+        // canonical CSC required: ascending, duplicate-free rows inside each column
+        for (int j = 0; j < d_; ++j)
+            for (int64_t ii = indptr[j] + 1; ii < indptr[j + 1]; ++ii)
+                if (indices[ii] <= indices[ii - 1])
+                    FAIL(SPFM_ERR_INVALID,
+                         "set_data: CSC must have sorted, duplicate-free row indices");
+        if (have_params && d_ != d) have_params = false;
+        n = n_;
+        d = d_;
+        nnz = nz;
+        h_cptr.assign(indptr, indptr + d + 1);
+        h_cidx.assign(indices, indices + nnz);
+        have_data = true;
+        have_schedule = false;
+        configured = false;
+        col_norm_reduced = false;
+        clear_graphs();
+        int rc = (dtype == SPFM_F32) ? set_data_t<float>(indptr, indices, data, y)
+                                     : set_data_t<double>(indptr, indices, data, y);
+        if (rc) return rc;
+        HIPC(viol_col.alloc(sizeof(double) * (size_t)d));
+        HIPC(pred_tmp.alloc(sizeof(double) * (size_t)(n > 0 ? n : 1)));
+        HIPC(partial.alloc(sizeof(double) * 1024));
+        return SPFM_OK;
+    }
+
+    // ================================================================= params
+    int set_params(int n_orders_, int k_, int32_t d_, const double* P_, const double* w_,
+                   const double* lams_) {
+        if (n_orders_ <= 0 || k_ <= 0 || d_ <= 0 || !P_ || !w_ || !lams_)
+            FAIL(SPFM_ERR_INVALID, "set_params: bad arguments");
+        if (have_data && d_ != d)
+            FAIL(SPFM_ERR_INVALID, "set_params: n_features differs from the data");
+        if (!have_data) d = d_;
+        for (int s = 0; s < k_; ++s)
+            if (std::fabs(lams_[s]) != 1.0) FAIL(SPFM_ERR_INVALID, "Lambdas must be +1 or -1.");
+        if (n_orders_ != n_orders || k_ != k) {
+            configured = false;
+            clear_graphs();
+        }
+        n_orders = n_orders_;
+        k = k_;
+        h_lams.assign(lams_, lams_ + k);
+        HIPC(P.alloc(sizeof(double) * (size_t)n_orders * k * d));
+        HIPC(w.alloc(sizeof(double) * (size_t)d));
+        HIPC(lams.alloc(sizeof(double) * (size_t)k));
+        HIPC(hipMemcpyAsync(P.p, P_, sizeof(double) * (size_t)n_orders * k * d,
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(w.p, w_, sizeof(double) * (size_t)d, hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(lams.p, lams_, sizeof(double) * (size_t)k, hipMemcpyHostToDevice,
+                            stream));
+        HIPC(hipStreamSynchronize(stream));
+        p_valid = true;
+        pt_valid = false;
+        have_params = true;
+        return SPFM_OK;
+    }
+
+    int get_params(double* P_, double* w_) {
+        if (!have_params) FAIL(SPFM_ERR_INVALID, "get_params: no parameters set");
+        int rc = ensure_p();
+        if (rc) return rc;
+        if (P_)
+            HIPC(hipMemcpyAsync(P_, P.p, sizeof(double) * (size_t)n_orders * k * d,
+                                hipMemcpyDeviceToHost, stream));
+        if (w_)
+            HIPC(hipMemcpyAsync(w_, w.p, sizeof(double) * (size_t)d, hipMemcpyDeviceToHost,
+                                stream));
+        HIPC(hipStreamSynchronize(stream));
+        return SPFM_OK;
+    }
+
+    // ============================================================== configure
+    int configure(int solver_, int loss_, int reg_, int top_degree_) {
+        if (!have_data || !have_params)
+            FAIL(SPFM_ERR_INVALID, "configure: set data and parameters first");
+        if (loss_ < 0 || loss_ > 2) FAIL(SPFM_ERR_INVALID, "Loss function not supported.");
+        if (reg_ < 0 || reg_ > 5) FAIL(SPFM_ERR_INVALID, "Regularizer not supported.");
+        if (solver_ != SPFM_SOLVER_PCD && solver_ != SPFM_SOLVER_PBCD)
+            FAIL(SPFM_ERR_INVALID, "Solver is not supported.");
+        if (top_degree_ < 2)
+            FAIL(SPFM_ERR_UNSUPPORTED, "degree must be >= 2 for the factorization-machine path");
+        if (top_degree_ > SPFM_MAX_DEGREE)
+            FAIL(SPFM_ERR_UNSUPPORTED, "degree > 6 is not supported by the HIP engine");
+        if (solver_ == SPFM_SOLVER_PCD) {
+            // init_cache_pcd exists only for l1 / squaredl12 / omegati (README.md:28-32)
+            if (reg_ != SPFM_REG_L1 && reg_ != SPFM_REG_SQUAREDL12 && reg_ != SPFM_REG_OMEGATI)
+                FAIL(SPFM_ERR_INVALID, "this regularizer cannot be used with solver='pcd'");
+            if (reg_ == SPFM_REG_SQUAREDL12 && top_degree_ > 2)
+                FAIL(SPFM_ERR_INVALID, "SquaredL12 supports only degree=2.");
+        } else {
+            if (reg_ != SPFM_REG_L1 && reg_ != SPFM_REG_L21 && reg_ != SPFM_REG_SQUAREDL21 &&
+                reg_ != SPFM_REG_OMEGACS)
+                FAIL(SPFM_ERR_INVALID, "this regularizer cannot be used with solver='pbcd'");
+            if (reg_ == SPFM_REG_SQUAREDL21 && top_degree_ != 2)
+                FAIL(SPFM_ERR_INVALID, "SquaredL21 supports only degree=2.");
+            if (k > 256) FAIL(SPFM_ERR_UNSUPPORTED, "pbcd: n_components > 256 not supported");
+        }
+        solver = solver_;
+        loss = loss_;
+        reg = reg_;
+        top_degree = top_degree_;
+        clear_graphs();
+        const size_t ncache = kMaxDegree + 2;
+        HIPC(abs_p.alloc(sizeof(double) * (size_t)d));
+        HIPC(norms.alloc(sizeof(double) * (size_t)d));
+        HIPC(cache.alloc(sizeof(double) * ncache));
+        HIPC(dcache.alloc(sizeof(double) * ncache));
+        HIPC(hipMemsetAsync(abs_p.p, 0, sizeof(double) * (size_t)d, stream));
+        HIPC(hipMemsetAsync(norms.p, 0, sizeof(double) * (size_t)d, stream));
+        HIPC(hipMemsetAsync(cache.p, 0, sizeof(double) * ncache, stream));
+        double hd[kMaxDegree + 2] = {0};
+        hd[1] = 1.0;  // omegacs.py:46 ; omegati sets it in compute_cache_pcd
+        HIPC(hipMemcpyAsync(dcache.p, hd, sizeof(double) * ncache, hipMemcpyHostToDevice, stream));
+        const size_t arow = (solver == SPFM_SOLVER_PCD) ? (size_t)(top_degree - 1)
+                                                       : (size_t)(top_degree - 1) * k;
+        HIPC(A.alloc(tsize() * (size_t)(n > 0 ? n : 1) * arow));
+        HIPC(ctl.alloc(sizeof(Ctl)));
+        HIPC(hipMemsetAsync(ctl.p, 0, sizeof(Ctl), stream));
+        HIPC(comp_order.alloc(sizeof(int32_t) * (size_t)k));
+        HIPC(scalar.alloc(sizeof(double) * 8));
+        if (!h_scalar) HIPC(hipHostMalloc((void**)&h_scalar, sizeof(double) * 8));
+        HIPC(hipStreamSynchronize(stream));
+        configured = true;
+        return alloc_work();
+    }
+
+    int alloc_work() {
+        if (!configured || !have_schedule) return SPFM_OK;
+        const size_t per_part = (solver == SPFM_SOLVER_PBCD) ? (size_t)k + 1 : 2;
+        const size_t per_delta = (solver == SPFM_SOLVER_PBCD) ? (size_t)k : 1;
+        HIPC(part.alloc(sizeof(double) * per_part * (size_t)max_batch_cols));
+        HIPC(delta.alloc(sizeof(double) * per_delta * (size_t)max_batch_cols));
+        HIPC(pold.alloc(sizeof(double) * per_delta * (size_t)max_batch_cols));
+        return SPFM_OK;
+    }
+
+    // =============================================================== schedule
+    int set_schedule(int mode, const int32_t* indices_feature, const int64_t* cf_indptr,
+                     const int32_t* cf_indices, int64_t cf_rows, int32_t* order_out,
+                     int32_t* n_batches_out) {
+        if (!have_data) FAIL(SPFM_ERR_INVALID, "set_schedule: no data");
+        if (!indices_feature) FAIL(SPFM_ERR_INVALID, "set_schedule: indices_feature is NULL");
+        std::vector<char> seen((size_t)d, 0);
+        for (int q = 0; q < d; ++q) {
+            const int j = indices_feature[q];
+            if (j < 0 || j >= d || seen[(size_t)j])
+                FAIL(SPFM_ERR_INVALID, "set_schedule: indices_feature is not a permutation");
+            seen[(size_t)j] = 1;
+        }
+        const int64_t* cp = cf_indptr ? cf_indptr : h_cptr.data();
+        const int32_t* ci = cf_indptr ? cf_indices : h_cidx.data();
+        const int64_t rows = cf_indptr ? cf_rows : n;
+        if (cf_indptr && (!cf_indices || cf_rows <= 0))
+            FAIL(SPFM_ERR_INVALID, "set_schedule: bad conflict structure");
+        const int max_batch = 4096;
+        if (mode == SPFM_SCHED_EXACT) {
+            order.assign(indices_feature, indices_feature + d);
+            schedule_exact(rows, d, cp, ci, indices_feature, max_batch, batch_ptr);
+        } else if (mode == SPFM_SCHED_COLORED) {
+            schedule_colored(rows, d, cp, ci, indices_feature, max_batch, order, batch_ptr);
+        } else {
+            FAIL(SPFM_ERR_INVALID, "set_schedule: unknown mode");
+        }
+        max_batch_cols = 1;
+        for (size_t b = 0; b + 1 < batch_ptr.size(); ++b)
+            max_batch_cols = std::max(max_batch_cols, batch_ptr[b + 1] - batch_ptr[b]);
+        HIPC(d_order.alloc(sizeof(int32_t) * (size_t)d));
+        HIPC(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * (size_t)d,
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipStreamSynchronize(stream));
+        have_schedule = true;
+        ++sched_version;
+        clear_graphs();
+        if (order_out) std::memcpy(order_out, order.data(), sizeof(int32_t) * (size_t)d);
+        if (n_batches_out) *n_batches_out = (int32_t)batch_ptr.size() - 1;
+        return alloc_work();
+    }
+
+    int n_batches() const { return (int)batch_ptr.size() - 1; }
+
+    // ================================================================ predict
+    template <typename T, int M>
+    void launch_anova(int64_t rows, const int64_t* rp, const int32_t* ri, const T* rv,
+                      const double* Pt_o, double* out) {
+        hipLaunchKernelGGL((anova_predict_kernel<T, M>), dim3(cdiv(rows * 64, kBlock)),
+                           dim3(kBlock), 0, stream, rows, k, rp, ri, rv, Pt_o, lams.as<double>(),
+                           out);
+    }
+    template <typename T>
+    int anova_dispatch(int M, int64_t rows, const int64_t* rp, const int32_t* ri, const T* rv,
+                       const double* Pt_o, double* out) {
+        switch (M) {
+            case 2: launch_anova<T, 2>(rows, rp, ri, rv, Pt_o, out); break;
+            case 3: launch_anova<T, 3>(rows, rp, ri, rv, Pt_o, out); break;
+            case 4: launch_anova<T, 4>(rows, rp, ri, rv, Pt_o, out); break;
+            case 5: launch_anova<T, 5>(rows, rp, ri, rv, Pt_o, out); break;
+            case 6: launch_anova<T, 6>(rows, rp, ri, rv, Pt_o, out); break;
+            default: FAIL(SPFM_ERR_UNSUPPORTED, "degree outside 2..6");
+        }
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+
+    // out (device, f64, length rows) = _get_output on the given CSR image
+    template <typename T>
+    int output_t(int64_t rows, const int64_t* rp, const int32_t* ri, const T* rv, int degree,
+                 int fit_linear, int add_lower, double* out) {
+        if (rows == 0) return SPFM_OK;
+        int rc = ensure_p();
+        if (rc) return rc;
+        pt_valid = false;  // P is the source of truth here
+        rc = ensure_pt();
+        if (rc) return rc;
+        HIPC(hipMemsetAsync(out, 0, sizeof(double) * (size_t)rows, stream));
+        rc = anova_dispatch<T>(degree, rows, rp, ri, rv, Pt.as<double>(), out);
+        if (rc) return rc;
+        if (add_lower) {
+            if (n_orders < 2) FAIL(SPFM_ERR_INVALID, "add_lower_deg2 needs P_[1]");
+            rc = anova_dispatch<T>(2, rows, rp, ri, rv, Pt.as<double>() + (size_t)k * d, out);
+            if (rc) return rc;
+        }
+        if (fit_linear) {
+            hipLaunchKernelGGL((linear_predict_kernel<T>), dim3(cdiv(rows, kBlock)), dim3(kBlock),
+                               0, stream, rows, rp, ri, rv, w.as<double>(), out);
+            HIPC(hipGetLastError());
+        }
+        return SPFM_OK;
+    }
+
+    template <typename T>
+    int init_pred_t(int degree, int fit_linear, int add_lower) {
+        int rc = output_t<T>(n, rptr.as<int64_t>(), ridx.as<int32_t>(), rval.as<T>(), degree,
+                             fit_linear, add_lower, pred_tmp.as<double>());
+        if (rc) return rc;
+        if (n > 0) {
+            hipLaunchKernelGGL((store_pred_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, stream, n,
+                               pred_tmp.as<double>(), yy.as<T>());
+            HIPC(hipGetLastError());
+        }
+        return sync();
+    }
+
+    int init_pred(int degree, int fit_linear, int add_lower) {
+        if (!have_data || !have_params) FAIL(SPFM_ERR_INVALID, "init_pred: no data/params");
+        return dtype == SPFM_F32 ? init_pred_t<float>(degree, fit_linear, add_lower)
+                                 : init_pred_t<double>(degree, fit_linear, add_lower);
+    }
+
+    template <typename T>
+    int get_y_pred_t(double* out) {
+        if (n == 0) return SPFM_OK;
+        hipLaunchKernelGGL((load_pred_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, stream, n,
+                           yy.as<T>(), pred_tmp.as<double>());
+        HIPC(hipGetLastError());
+        HIPC(hipMemcpyAsync(out, pred_tmp.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
+                            stream));
+        return sync();
+    }
+
+    template <typename T>
+    int loss_sum_t(double* out) {
+        const int nb = 512;
+        hipLaunchKernelGGL((loss_partial_kernel<T>), dim3(nb), dim3(kBlock), 0, stream, n,
+                           yy.as<typename Vec2<T>::type>(), loss, partial.as<double>());
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(kBlock), 0, stream,
+                           partial.as<double>(), nb, scalar.as<double>());
+        HIPC(hipGetLastError());
+        int rc = allreduce(scalar.as<double>(), 1);
+        if (rc) return rc;
+        HIPC(hipMemcpyAsync(h_scalar, scalar.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        rc = sync();
+        if (rc) return rc;
+        *out = h_scalar[0];
+        return SPFM_OK;
+    }
+
+    template <typename T>
+    int predict_csr_t(int64_t rows, const int64_t* indptr, const int32_t* indices,
+                      const double* data, int degree, int fit_linear, int add_lower,
+                      double* out) {
+        if (rows == 0) return SPFM_OK;
+        const int64_t nz = indptr[rows];
+        for (int64_t ii = 0; ii < nz; ++ii)
+            if (indices[ii] < 0 || indices[ii] >= d)
+                FAIL(SPFM_ERR_INVALID, "predict: column index out of range");
+        std::vector<T> hv((size_t)nz);
+        for (int64_t ii = 0; ii < nz; ++ii) hv[(size_t)ii] = (T)data[ii];
+        DevBuf rp, ri, rv, o;
+        HIPC(rp.alloc(sizeof(int64_t) * ((size_t)rows + 1)));
+        HIPC(ri.alloc(sizeof(int32_t) * (size_t)nz));
+        HIPC(rv.alloc(sizeof(T) * (size_t)nz));
+        HIPC(o.alloc(sizeof(double) * (size_t)rows));
+        HIPC(hipMemcpyAsync(rp.p, indptr, sizeof(int64_t) * ((size_t)rows + 1),
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(ri.p, indices, sizeof(int32_t) * (size_t)nz, hipMemcpyHostToDevice,
+                            stream));
+        HIPC(hipMemcpyAsync(rv.p, hv.data(), sizeof(T) * (size_t)nz, hipMemcpyHostToDevice,
+                            stream));
+        int rc = output_t<T>(rows, rp.as<int64_t>(), ri.as<int32_t>(), rv.as<T>(), degree,
+                             fit_linear, add_lower, o.as<double>());
+        if (rc) return rc;
+        HIPC(hipMemcpyAsync(out, o.p, sizeof(double) * (size_t)rows, hipMemcpyDeviceToHost,
+                            stream));
+        return sync();
+    }
+
+    // ================================================================== epochs
+    int epoch_prologue() {
+        if (!have_data || !have_params || !configured)
+            FAIL(SPFM_ERR_INVALID, "epoch: data, parameters and configuration are required");
+        if (!have_schedule) FAIL(SPFM_ERR_INVALID, "epoch: call spfm_set_schedule first");
+        int rc = ensure_col_norm();
+        if (rc) return rc;
+        HIPC(hipMemsetAsync(viol_col.p, 0, sizeof(double) * (size_t)d, stream));
+        return SPFM_OK;
+    }
+
+    int epoch_epilogue(double* viol) {
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(kBlock), 0, stream,
+                           viol_col.as<double>(), d, scalar.as<double>());
+        HIPC(hipGetLastError());
+        HIPC(hipMemcpyAsync(h_scalar, scalar.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPC(hipStreamSynchronize(stream));
+        prof_collect();
+        if (viol) *viol = h_scalar[0];
+        return SPFM_OK;
+    }
+
+    static std::string fkey(const char* tag, std::initializer_list<double> v,
+                            std::initializer_list<int64_t> iv) {
+        std::string s(tag);
+        char buf[64];
+        for (double x : v) {
+            snprintf(buf, sizeof buf, "|%a", x);
+            s += buf;
+        }
+        for (int64_t x : iv) {
+            snprintf(buf, sizeof buf, "|%lld", (long long)x);
+            s += buf;
+        }
+        return s;
+    }
+
+    // ------------------------------------------------------------- cd_linear
+    template <typename T>
+    int lin_body(double alpha) {
+        const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
+        const int nb = n_batches();
+        for (int b = 0; b < nb; ++b) {
+            const int c0 = batch_ptr[b], nc = batch_ptr[b + 1] - c0;
+            if (nc == 0) continue;
+            const int32_t* cols = d_order.as<int32_t>() + c0;
+            prof_begin(4, prof_on ? batch_nnz(b) : 0);
+            if (!comm) {
+                hipLaunchKernelGGL((lin_fused_kernel<T>), dim3(nc), dim3(kBlock), 0, stream, cols,
+                                   cptr.as<int64_t>(), cidx.as<int32_t>(), cval.as<T>(),
+                                   yy.as<T>(), loss, w.as<double>(), col_norm.as<double>(), alpha,
+                                   mu, viol_col.as<double>());
+            } else {
+                hipLaunchKernelGGL((lin_grad_kernel<T>), dim3(nc), dim3(kBlock), 0, stream, cols,
+                                   cptr.as<int64_t>(), cidx.as<int32_t>(), cval.as<T>(),
+                                   yy.as<typename Vec2<T>::type>(), loss, part.as<double>());
+                int rc = allreduce(part.as<double>(), (size_t)nc);
+                if (rc) return rc;
+                hipLaunchKernelGGL((lin_sync_kernel<T>), dim3(nc), dim3(kBlock), 0, stream, cols,
+                                   cptr.as<int64_t>(), cidx.as<int32_t>(), cval.as<T>(),
+                                   yy.as<T>(), part.as<double>(), w.as<double>(),
+                                   col_norm.as<double>(), alpha, mu, viol_col.as<double>());
+            }
+            prof_end(4);
+        }
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+
+    int cd_linear_epoch(double alpha, double* viol) {
+        int rc = epoch_prologue();
+        if (rc) return rc;
+        const std::string key = fkey("lin", {alpha}, {loss, sched_version});
+        rc = run_cached(key, [&]() {
+            return dtype == SPFM_F32 ? lin_body<float>(alpha) : lin_body<double>(alpha);
+        });
+        if (rc) return rc;
+        return epoch_epilogue(viol);
+    }
+
+    // -------------------------------------------------------------------- pcd
+    template <typename T, int M>
+    int pcd_pass_body(int order_idx, double beta, double gamma, double eta) {
+        const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
+        double* Po = P.as<double>() + (size_t)order_idx * k * d;
+        Ctl* c = ctl.as<Ctl>();
+        RegState rs = regstate();
+        hipLaunchKernelGGL(begin_pass_kernel, dim3(1), dim3(64), 0, stream, c,
+                           comp_order.as<int32_t>(), lams.as<double>());
+        if (n > 0)
+            hipLaunchKernelGGL((pcd_precompute_kernel<T, M>), dim3(cdiv(n, kBlock)), dim3(kBlock),
+                               0, stream, c, n, rptr.as<int64_t>(), ridx.as<int32_t>(),
+                               rval.as<T>(), Po, d, A.as<T>());
+        if (reg != SPFM_REG_L1)
+            hipLaunchKernelGGL((pcd_compute_cache_kernel<M>), dim3(1), dim3(kBlock), 0, stream, c,
+                               Po, d, reg, rs);
+        const int nb = n_batches();
+        for (int b = 0; b < nb; ++b) {
+            const int c0 = batch_ptr[b], nc = batch_ptr[b + 1] - c0;
+            if (nc == 0) continue;
+            const int32_t* cols = d_order.as<int32_t>() + c0;
+            const int64_t bn = prof_on ? batch_nnz(b) : 0;
+            prof_begin(0, bn);
+            hipLaunchKernelGGL((pcd_grad_kernel<T, M>), dim3(nc), dim3(kBlock), 0, stream, c, cols,
+                               cptr.as<int64_t>(), cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
+                               yy.as<typename Vec2<T>::type>(), Po, d, loss, part.as<double>());
+            prof_end(0);
+            int rc = allreduce(part.as<double>(), (size_t)2 * nc);
+            if (rc) return rc;
+            hipLaunchKernelGGL((pcd_chain_kernel<M>), dim3(1), dim3(kWave), 0, stream, c, cols, nc,
+                               Po, d, part.as<double>(), reg, rs, mu, beta, gamma, eta,
+                               delta.as<double>(), pold.as<double>(), viol_col.as<double>());
+            prof_begin(1, bn);
+            hipLaunchKernelGGL((pcd_sync_kernel<T, M>), dim3(nc), dim3(kBlock), 0, stream, c, cols,
+                               cptr.as<int64_t>(), cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
+                               yy.as<T>(), delta.as<double>(), pold.as<double>());
+            prof_end(1);
+        }
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+
+    template <typename T>
+    int pcd_pass_dispatch(int M, int order_idx, double beta, double gamma, double eta) {
+        switch (M) {
+            case 2: return pcd_pass_body<T, 2>(order_idx, beta, gamma, eta);
+            case 3: return pcd_pass_body<T, 3>(order_idx, beta, gamma, eta);
+            case 4: return pcd_pass_body<T, 4>(order_idx, beta, gamma, eta);
+            case 5: return pcd_pass_body<T, 5>(order_idx, beta, gamma, eta);
+            case 6: return pcd_pass_body<T, 6>(order_idx, beta, gamma, eta);
+        }
+        FAIL(SPFM_ERR_UNSUPPORTED, "degree outside 2..6");
+    }
+
+    int pcd_epoch(int order_idx, int degree, double beta, double gamma, double eta,
+                  const int32_t* ic, int n_comp, double* viol) {
+        int rc = epoch_prologue();
+        if (rc) return rc;
+        if (solver != SPFM_SOLVER_PCD) FAIL(SPFM_ERR_INVALID, "engine is not configured for pcd");
+        if (order_idx < 0 || order_idx >= n_orders) FAIL(SPFM_ERR_INVALID, "bad order index");
+        if (degree < 2 || degree > top_degree) FAIL(SPFM_ERR_INVALID, "bad degree");
+        if (!ic || n_comp < 0 || n_comp > k) FAIL(SPFM_ERR_INVALID, "bad indices_component");
+        for (int q = 0; q < n_comp; ++q)
+            if (ic[q] < 0 || ic[q] >= k) FAIL(SPFM_ERR_INVALID, "indices_component out of range");
+        rc = ensure_p();
+        if (rc) return rc;
+        pt_valid = false;
+        if (n_comp > 0)
+            HIPC(hipMemcpyAsync(comp_order.p, ic, sizeof(int32_t) * (size_t)n_comp,
+                                hipMemcpyHostToDevice, stream));
+        HIPC(hipMemsetAsync(ctl.p, 0, sizeof(Ctl), stream));
+        const std::string key = fkey("pcd", {beta, gamma, eta},
+                                     {order_idx, degree, loss, reg, sched_version});
+        for (int pass = 0; pass < n_comp; ++pass) {
+            rc = run_cached(key, [&]() {
+                return dtype == SPFM_F32
+                           ? pcd_pass_dispatch<float>(degree, order_idx, beta, gamma, eta)
+                           : pcd_pass_dispatch<double>(degree, order_idx, beta, gamma, eta);
+            });
+            if (rc) return rc;
+        }
+        return epoch_epilogue(viol);
+    }
+
+    // ------------------------------------------------------------------- pbcd
+    template <typename T, int M, int L, int C>
+    int pbcd_body_lc(int order_idx, double beta, double gamma, double eta) {
+        const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
+        double* Po = Pt.as<double>() + (size_t)order_idx * k * d;  // (d,k)
+        RegState rs = regstate();
+        constexpr int CW = (L == 64) ? C : 1;  // chain kernel: lanes = 64
+        if (n > 0)
+            hipLaunchKernelGGL((pbcd_precompute_kernel<T, M>), dim3(cdiv(n * k, kBlock)),
+                               dim3(kBlock), 0, stream, n, k, rptr.as<int64_t>(),
+                               ridx.as<int32_t>(), rval.as<T>(), Po, A.as<T>());
+        if (reg == SPFM_REG_SQUAREDL21 || reg == SPFM_REG_OMEGACS) {
+            hipLaunchKernelGGL(pbcd_norms_kernel, dim3(cdiv((int64_t)d * 64, kBlock)),
+                               dim3(kBlock), 0, stream, d, k, Po, rs.norms);
+            hipLaunchKernelGGL((pbcd_compute_cache_kernel<M>), dim3(1), dim3(kBlock), 0, stream, d,
+                               reg, rs);
+        }
+        const size_t shm = sizeof(double) * ((size_t)(kBlock / L) * k + 16);
+        const int nb = n_batches();
+        for (int b = 0; b < nb; ++b) {
+            const int c0 = batch_ptr[b], nc = batch_ptr[b + 1] - c0;
+            if (nc == 0) continue;
+            const int32_t* cols = d_order.as<int32_t>() + c0;
+            const int64_t bn = prof_on ? batch_nnz(b) : 0;
+            prof_begin(2, bn);
+            hipLaunchKernelGGL((pbcd_grad_kernel<T, M, L, C>), dim3(nc), dim3(kBlock), shm, stream,
+                               cols, cptr.as<int64_t>(), cidx.as<int32_t>(), cval.as<T>(),
+                               A.as<T>(), yy.as<typename Vec2<T>::type>(), Po, k, loss,
+                               part.as<double>());
+            prof_end(2);
+            int rc = allreduce(part.as<double>(), (size_t)nc * (k + 1));
+            if (rc) return rc;
+            hipLaunchKernelGGL((pbcd_chain_kernel<M, CW>), dim3(1), dim3(kWave), 0, stream, cols,
+                               nc, Po, k, d, part.as<double>(), lams.as<double>(), reg, rs,
+                               top_degree + 1, mu, beta, gamma, eta, delta.as<double>(),
+                               pold.as<double>(), viol_col.as<double>());
+            prof_begin(3, bn);
+            hipLaunchKernelGGL((pbcd_sync_kernel<T, M, L, C>), dim3(nc), dim3(kBlock), 0, stream,
+                               cols, cptr.as<int64_t>(), cidx.as<int32_t>(), cval.as<T>(),
+                               A.as<T>(), yy.as<T>(), lams.as<double>(), k, delta.as<double>(),
+                               pold.as<double>());
+            prof_end(3);
+        }
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+
+    template <typename T, int M>
+    int pbcd_body(int order_idx, double beta, double gamma, double eta) {
+        if (k <= 8) return pbcd_body_lc<T, M, 8, 1>(order_idx, beta, gamma, eta);
+        if (k <= 16) return pbcd_body_lc<T, M, 16, 1>(order_idx, beta, gamma, eta);
+        if (k <= 32) return pbcd_body_lc<T, M, 32, 1>(order_idx, beta, gamma, eta);
+        if (k <= 64) return pbcd_body_lc<T, M, 64, 1>(order_idx, beta, gamma, eta);
+        if (k <= 128) return pbcd_body_lc<T, M, 64, 2>(order_idx, beta, gamma, eta);
+        return pbcd_body_lc<T, M, 64, 4>(order_idx, beta, gamma, eta);
+    }
+
+    template <typename T>
+    int pbcd_dispatch(int M, int order_idx, double beta, double gamma, double eta) {
+        switch (M) {
+            case 2: return pbcd_body<T, 2>(order_idx, beta, gamma, eta);
+            case 3: return pbcd_body<T, 3>(order_idx, beta, gamma, eta);
+            case 4: return pbcd_body<T, 4>(order_idx, beta, gamma, eta);
+            case 5: return pbcd_body<T, 5>(order_idx, beta, gamma, eta);
+            case 6: return pbcd_body<T, 6>(order_idx, beta, gamma, eta);
+        }
+        FAIL(SPFM_ERR_UNSUPPORTED, "degree outside 2..6");
+    }
+
+    int pbcd_epoch(int order_idx, int degree, double beta, double gamma, double eta,
+                   double* viol) {
+        int rc = epoch_prologue();
+        if (rc) return rc;
+        if (solver != SPFM_SOLVER_PBCD) FAIL(SPFM_ERR_INVALID, "engine is not configured for pbcd");
+        if (order_idx < 0 || order_idx >= n_orders) FAIL(SPFM_ERR_INVALID, "bad order index");
+        if (degree < 2 || degree > top_degree) FAIL(SPFM_ERR_INVALID, "bad degree");
+        rc = ensure_pt();
+        if (rc) return rc;
+        p_valid = false;
+        const std::string key = fkey("pbcd", {beta, gamma, eta},
+                                     {order_idx, degree, loss, reg, sched_version});
+        rc = run_cached(key, [&]() {
+            return dtype == SPFM_F32 ? pbcd_dispatch<float>(degree, order_idx, beta, gamma, eta)
+                                     : pbcd_dispatch<double>(degree, order_idx, beta, gamma, eta);
+        });
+        if (rc) return rc;
+        return epoch_epilogue(viol);
+    }
+};
+
+// ======================================================================= C ABI
+#define GUARD(h)                  \
+    if (!(h)) return SPFM_ERR_INVALID; \
+    if (hipSetDevice((h)->device) != hipSuccess) { \
+        (h)->err = "hipSetDevice failed";          \
+        return SPFM_ERR_RUNTIME;                   \
+    }
+
+extern "C" {
+
+int spfm_create(spfm_handle* out, int device_id, int dtype) {
+    if (!out) return SPFM_ERR_INVALID;
+    *out = nullptr;
+    if (dtype != SPFM_F32 && dtype != SPFM_F64) {
+        g_create_error = "dtype must be SPFM_F32 or SPFM_F64";
+        return SPFM_ERR_INVALID;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return SPFM_ERR_RUNTIME;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        g_create_error = "device id out of range";
+        return SPFM_ERR_INVALID;
+    }
+    if ((e = hipSetDevice(device_id)) != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return SPFM_ERR_RUNTIME;
+    }
+    spfm_engine* h = new spfm_engine();
+    h->device = device_id;
+    h->dtype = dtype;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->devname = prop.gcnArchName;
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        delete h;
+        return SPFM_ERR_RUNTIME;
+    }
+    *out = h;
+    return SPFM_OK;
+}
+
+void spfm_destroy(spfm_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+const char* spfm_last_error(spfm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int spfm_device_name(spfm_handle h, char* out, int cap) {
+    if (!h || !out || cap <= 0) return SPFM_ERR_INVALID;
+    snprintf(out, (size_t)cap, "%s", h->devname.c_str());
+    return SPFM_OK;
+}
+
+int spfm_set_data_csc(spfm_handle h, int64_t n, int32_t d, const int64_t* indptr,
+                      const int32_t* indices, const double* data, const double* y) {
+    GUARD(h);
+    return h->set_data(n, d, indptr, indices, data, y);
+}
+
+int spfm_set_params(spfm_handle h, int n_orders, int k, int32_t d, const double* P,
+                    const double* w, const double* lams) {
+    GUARD(h);
+    return h->set_params(n_orders, k, d, P, w, lams);
+}
+
+int spfm_get_params(spfm_handle h, double* P, double* w) {
+    GUARD(h);
+    return h->get_params(P, w);
+}
+
+int spfm_configure(spfm_handle h, int solver, int loss, int regularizer, int top_degree) {
+    GUARD(h);
+    return h->configure(solver, loss, regularizer, top_degree);
+}
+
+int spfm_init_pred(spfm_handle h, int degree, int fit_linear, int add_lower_deg2) {
+    GUARD(h);
+    return h->init_pred(degree, fit_linear, add_lower_deg2);
+}
+
+int spfm_get_y_pred(spfm_handle h, double* out) {
+    GUARD(h);
+    if (!h->have_data || !out) return SPFM_ERR_INVALID;
+    return h->dtype == SPFM_F32 ? h->get_y_pred_t<float>(out) : h->get_y_pred_t<double>(out);
+}
+
+int spfm_loss_sum(spfm_handle h, double* out) {
+    GUARD(h);
+    if (!h->have_data || !h->configured || !out) {
+        h->err = "loss_sum: data and configuration required";
+        return SPFM_ERR_INVALID;
+    }
+    return h->dtype == SPFM_F32 ? h->loss_sum_t<float>(out) : h->loss_sum_t<double>(out);
+}
+
+int spfm_predict_csr(spfm_handle h, int64_t n, const int64_t* indptr, const int32_t* indices,
+                     const double* data, int degree, int fit_linear, int add_lower_deg2,
+                     double* out) {
+    GUARD(h);
+    if (!h->have_params) {
+        h->err = "predict: no parameters set";
+        return SPFM_ERR_INVALID;
+    }
+    if (n < 0 || !indptr || !out) return SPFM_ERR_INVALID;
+    return h->dtype == SPFM_F32
+               ? h->predict_csr_t<float>(n, indptr, indices, data, degree, fit_linear,
+                                         add_lower_deg2, out)
+               : h->predict_csr_t<double>(n, indptr, indices, data, degree, fit_linear,
+                                          add_lower_deg2, out);
+}
+
+int spfm_set_schedule(spfm_handle h, int mode, const int32_t* indices_feature,
+                      const int64_t* conflict_indptr, const int32_t* conflict_indices,
+                      int64_t conflict_n_rows, int32_t* order_out, int32_t* n_batches_out) {
+    GUARD(h);
+    return h->set_schedule(mode, indices_feature, conflict_indptr, conflict_indices,
+                           conflict_n_rows, order_out, n_batches_out);
+}
+
+int spfm_schedule_build(int mode, int64_t n_rows, int32_t d, const int64_t* indptr,
+                        const int32_t* indices, const int32_t* indices_feature, int max_batch,
+                        int32_t* order_out, int32_t* batch_ptr_out, int32_t* n_batches_out) {
+    if (n_rows < 0 || d <= 0 || !indptr || !indices_feature || !order_out || !batch_ptr_out ||
+        !n_batches_out)
+        return SPFM_ERR_INVALID;
+    if (max_batch <= 0) max_batch = 4096;
+    std::vector<char> seen((size_t)d, 0);
+    for (int q = 0; q < d; ++q) {
+        const int j = indices_feature[q];
+        if (j < 0 || j >= d || seen[(size_t)j]) return SPFM_ERR_INVALID;
+        seen[(size_t)j] = 1;
+    }
+    std::vector<int32_t> order, bp;
+    if (mode == SPFM_SCHED_EXACT) {
+        order.assign(indices_feature, indices_feature + d);
+        schedule_exact(n_rows, d, indptr, indices, indices_feature, max_batch, bp);
+    } else if (mode == SPFM_SCHED_COLORED) {
+        schedule_colored(n_rows, d, indptr, indices, indices_feature, max_batch, order, bp);
+    } else {
+        return SPFM_ERR_INVALID;
+    }
+    std::memcpy(order_out, order.data(), sizeof(int32_t) * (size_t)d);
+    std::memcpy(batch_ptr_out, bp.data(), sizeof(int32_t) * bp.size());
+    *n_batches_out = (int32_t)bp.size() - 1;
+    return SPFM_OK;
+}
+
+int spfm_cd_linear_epoch(spfm_handle h, double alpha, double* viol) {
+    GUARD(h);
+    return h->cd_linear_epoch(alpha, viol);
+}
+
+int spfm_pcd_epoch(spfm_handle h, int order_idx, int degree, double beta, double gamma,
+                   double eta, const int32_t* indices_component, int n_comp, double* viol) {
+    GUARD(h);
+    return h->pcd_epoch(order_idx, degree, beta, gamma, eta, indices_component, n_comp, viol);
+}
+
+int spfm_pbcd_epoch(spfm_handle h, int order_idx, int degree, double beta, double gamma,
+                    double eta, double* viol) {
+    GUARD(h);
+    return h->pbcd_epoch(order_idx, degree, beta, gamma, eta, viol);
+}
+
+int spfm_comm_unique_id(char* id128) {
+    if (!id128) return SPFM_ERR_INVALID;
+    std::string e;
+    if (!g_rccl.load(e)) {
+        g_create_error = e;
+        return SPFM_ERR_RUNTIME;
+    }
+    ncclUniqueId_ id;
+    if (g_rccl.GetUniqueId(&id) != 0) {
+        g_create_error = "ncclGetUniqueId failed";
+        return SPFM_ERR_RUNTIME;
+    }
+    std::memcpy(id128, id.internal, 128);
+    return SPFM_OK;
+}
+
+int spfm_comm_init(spfm_handle h, const char* id128, int n_ranks, int rank) {
+    GUARD(h);
+    if (!id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return SPFM_ERR_INVALID;
+    if (!g_rccl.load(h->err)) return SPFM_ERR_RUNTIME;
+    ncclUniqueId_ id;
+    std::memcpy(id.internal, id128, 128);
+    int rc = g_rccl.CommInitRank(&h->comm, n_ranks, id, rank);
+    if (rc != 0) {
+        h->err = std::string("ncclCommInitRank: ") +
+                 (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+        h->comm = nullptr;
+        return SPFM_ERR_RUNTIME;
+    }
+    h->n_ranks = n_ranks;
+    h->rank = rank;
+    h->col_norm_reduced = false;
+    h->clear_graphs();
+    return SPFM_OK;
+}
+
+int spfm_profile_enable(spfm_handle h, int on) {
+    if (!h) return SPFM_ERR_INVALID;
+    h->prof_on = on != 0;
+    return SPFM_OK;
+}
+
+int spfm_profile_get(spfm_handle h, int which, double* ms, int64_t* launches, int64_t* nnz) {
+    if (!h || which < 0 || which > 4) return SPFM_ERR_INVALID;
+    if (ms) *ms = h->prof[which].ms;
+    if (launches) *launches = h->prof[which].launches;
+    if (nnz) *nnz = h->prof[which].nnz;
+    return SPFM_OK;
+}
+
+int spfm_profile_reset(spfm_handle h) {
+    if (!h) return SPFM_ERR_INVALID;
+    for (auto& ps : h->prof) {
+        ps.ms = 0;
+        ps.launches = 0;
+        ps.nnz = 0;
+        ps.used = 0;
+    }
+    return SPFM_OK;
+}
+
+int spfm_set_use_graph(spfm_handle h, int on) {
+    if (!h) return SPFM_ERR_INVALID;
+    h->use_graph = on != 0;
+    if (!on) h->clear_graphs();
+    return SPFM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// spfm_schedule.cpp -- host-side construction of conflict-free coordinate batches.
+//
+// The reference sweeps coordinates strictly sequentially (optimizer/pcd.py:97,
+// pbcd.py:110, cd_linear.py:10).  Two columns that share no row touch disjoint
+// parts of A / y_pred, so their gradient reductions and their scatter updates
+// commute; only the (scalar) prox + regularizer-cache recurrence must keep the
+// order.  A batch = a set of pairwise row-disjoint columns; the device runs one
+// batch as one dependent step and the result equals the reference sweep over the
+// concatenated batch order (the reference accepts any order: pcd.py:86-87).
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace spfm {
+
+// EXACT: keep `order`; cut it into maximal runs of pairwise row-disjoint columns.
+void schedule_exact(int64_t n_rows, int32_t d, const int64_t* cptr, const int32_t* cidx,
+                    const int32_t* order, int max_batch, std::vector<int32_t>& batch_ptr) {
+    std::vector<int32_t> stamp((size_t)n_rows, -1);
+    batch_ptr.clear();
+    batch_ptr.push_back(0);
+    int32_t cur = 0;
+    int size = 0;
+    for (int32_t pos = 0; pos < d; ++pos) {
+        const int32_t j = order[pos];
+        bool conflict = (size >= max_batch);
+        if (!conflict) {
+            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii)
+                if (stamp[cidx[ii]] == cur) {
+                    conflict = true;
+                    break;
+                }
+        }
+        if (conflict) {
+            ++cur;
+            batch_ptr.push_back(pos);
+            size = 0;
+        }
+        for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) stamp[cidx[ii]] = cur;
+        ++size;
+    }
+    batch_ptr.push_back(d);
+}
+
+// COLORED: first-fit greedy colouring of the column conflict graph, visiting the
+// columns in `order`.  Per row a bitset of the colours already present in that
+// row; a column takes the lowest colour absent from all of its rows (and not
+// full).  out_order = colour classes concatenated (columns keep their relative
+// visiting order inside a class).
+void schedule_colored(int64_t n_rows, int32_t d, const int64_t* cptr, const int32_t* cidx,
+                      const int32_t* order, int max_batch, std::vector<int32_t>& out_order,
+                      std::vector<int32_t>& batch_ptr) {
+    size_t W = 8;  // 64-bit words per row (grows)
+    std::vector<uint64_t> bits((size_t)n_rows * W, 0);
+    std::vector<uint64_t> full(W, 0), acc(W, 0);
+    std::vector<std::vector<int32_t>> classes;
+    for (int32_t pos = 0; pos < d; ++pos) {
+        const int32_t j = order[pos];
+        std::copy(full.begin(), full.end(), acc.begin());
+        for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+            const uint64_t* rb = &bits[(size_t)cidx[ii] * W];
+            for (size_t w = 0; w < W; ++w) acc[w] |= rb[w];
+        }
+        size_t c = W * 64;
+        for (size_t w = 0; w < W; ++w) {
+            if (~acc[w]) {
+                c = w * 64 + (size_t)__builtin_ctzll(~acc[w]);
+                break;
+            }
+        }
+        if (c > classes.size()) c = classes.size();  // first unused colour
+        if (c == classes.size()) {
+            classes.emplace_back();
+            if (c >= W * 64) {  // grow the per-row bitsets
+                const size_t W2 = W * 2;
+                std::vector<uint64_t> nb((size_t)n_rows * W2, 0);
+                for (int64_t r = 0; r < n_rows; ++r)
+                    std::memcpy(&nb[(size_t)r * W2], &bits[(size_t)r * W], W * sizeof(uint64_t));
+                bits.swap(nb);
+                full.resize(W2, 0);
+                acc.resize(W2, 0);
+                W = W2;
+            }
+        }
+        classes[c].push_back(j);
+        if ((int)classes[c].size() >= max_batch) full[c >> 6] |= (1ull << (c & 63));
+        const uint64_t m = 1ull << (c & 63);
+        const size_t cw = c >> 6;
+        for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) bits[(size_t)cidx[ii] * W + cw] |= m;
+    }
+    out_order.clear();
+    out_order.reserve((size_t)d);
+    batch_ptr.clear();
+    batch_ptr.push_back(0);
+    for (auto& cl : classes) {
+        if (cl.empty()) continue;
+        out_order.insert(out_order.end(), cl.begin(), cl.end());
+        batch_ptr.push_back((int32_t)out_order.size());
+    }
+    if (batch_ptr.size() == 1) batch_ptr.push_back(0);
+}
+
+// CSC -> CSR (counting sort; keeps ascending column order inside each row)
+void csc_to_csr(int64_t n, int32_t d, const int64_t* cptr, const int32_t* cidx,
+                std::vector<int64_t>& rptr, std::vector<int32_t>& ridx,
+                std::vector<int64_t>& perm /* csr position -> csc position */) {
+    const int64_t nnz = cptr[d];
+    rptr.assign((size_t)n + 1, 0);
+    for (int64_t ii = 0; ii < nnz; ++ii) rptr[(size_t)cidx[ii] + 1]++;
+    for (int64_t i = 0; i < n; ++i) rptr[(size_t)i + 1] += rptr[(size_t)i];
+    ridx.resize((size_t)nnz);
+    perm.resize((size_t)nnz);
+    std::vector<int64_t> fill(rptr.begin(), rptr.end() - 1);
+    for (int32_t j = 0; j < d; ++j)
+        for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+            const int64_t dst = fill[(size_t)cidx[ii]]++;
+            ridx[(size_t)dst] = j;
+            perm[(size_t)dst] = ii;
+        }
+}
+
+}  // namespace spfm

@@ -1,0 +1,56 @@
+"""One process per GPU: row sharding + RCCL bootstrap through ``torch.distributed``.
+
+The reference has no distributed code; the data-parallel
+structure used here is the one its loops imply: every per-sample quantity
+(``A[i]``, ``y_pred[i]``, ``y[i]``) belongs to the rank that owns row i, and the
+only cross-sample operations are the column sums of ``pcd._update``
+(optimizer/pcd.py:54-59), ``pbcd._update`` (pbcd.py:60-72) and
+``_cd_linear_epoch`` (cd_linear.py:15-18).  Those partial sums are all-reduced
+(sum, f64) once per dependent step inside the C++ engine with RCCL; the prox and
+regularizer recurrences then run replicated and bit-identical on every rank.
+
+``torch.distributed`` is used only to learn rank / world size and to ship the
+128-byte RCCL unique id; the data path never touches torch.
+"""
+import numpy as np
+
+
+def _dist():
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("distributed=True needs an initialised torch.distributed group "
+                           "(one process per GPU; backend 'nccl' = RCCL, or 'gloo')")
+    return dist
+
+
+def rank_world():
+    d = _dist()
+    return d.get_rank(), d.get_world_size()
+
+
+def row_block(n_samples, rank=None, world=None):
+    """Contiguous block of rows owned by `rank`: [lo, hi)."""
+    if rank is None:
+        rank, world = rank_world()
+    base, rem = divmod(int(n_samples), int(world))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def broadcast_bytes(payload, src=0):
+    """Broadcast a bytes object from `src` to all ranks (tiny control message)."""
+    d = _dist()
+    box = [payload if d.get_rank() == src else None]
+    d.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def init_engine_comm(engine):
+    """Create the engine's RCCL communicator spanning the torch process group."""
+    rank, world = rank_world()
+    uid = engine.comm_unique_id() if rank == 0 else None
+    uid = broadcast_bytes(uid, src=0)
+    engine.comm_init(uid, world, rank)
+    return rank, world

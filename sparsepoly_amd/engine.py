@@ -1,0 +1,230 @@
+"""Python face of one ``spfm_handle`` (include/spfm.h): NumPy in, NumPy out.
+
+The methods map one-to-one onto the reference calls they replace
+(``sparsepoly/sparse_factorization_machines.py`` epoch drivers):
+
+=====================  =====================================================
+``set_data``           ``get_dataset(X, 'fortran')`` + ``row_norms`` (:406-409)
+``init_pred``          ``_get_output(X)`` (:408, :437-451)
+``cd_linear_epoch``    ``cd_linear._cd_linear_epoch`` (optimizer/cd_linear.py:8-33)
+``pcd_epoch``          ``pcd.pcd_epoch`` (optimizer/pcd.py:71-137)
+``pbcd_epoch``         ``pbcd.pbcd_epoch`` (optimizer/pbcd.py:82-148)
+``predict``            ``_predict`` (:453-458)
+=====================  =====================================================
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _capi
+
+
+class SpfmError(RuntimeError):
+    pass
+
+
+def canonical_csc(X):
+    """CSC with sorted, duplicate-free row indices, float64.  Dense input is
+    converted entry-wise (the reference's FortranDataset, dataset.py:39-57, also
+    visits explicit zeros; they contribute exact zeros to every sum and update)."""
+    if sp.issparse(X):
+        Xc = sp.csc_matrix(X, dtype=np.float64, copy=True)
+        Xc.sum_duplicates()
+        Xc.sort_indices()
+    else:
+        Xc = sp.csc_matrix(np.asarray(X, dtype=np.float64))
+        Xc.sort_indices()
+    return Xc
+
+
+class HipEngine(object):
+    def __init__(self, device=0, precision="f32"):
+        if precision not in _capi.DTYPES:
+            raise ValueError("precision must be 'f32' or 'f64'")
+        self._lib = _capi.load()
+        h = C.c_void_p()
+        rc = self._lib.spfm_create(C.byref(h), int(device), _capi.DTYPES[precision])
+        if rc != 0:
+            msg = self._lib.spfm_last_error(None).decode()
+            raise SpfmError("spfm_create failed: %s" % msg)
+        self._h = h
+        self.precision = precision
+        self.n = self.d = self.k = self.n_orders = None
+        self.order = None
+        self.n_batches = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.spfm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == 0:
+            return
+        msg = self._lib.spfm_last_error(self._h).decode()
+        if rc == _capi.SPFM_ERR_INVALID:
+            raise ValueError(msg)
+        if rc == _capi.SPFM_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        raise SpfmError(msg)
+
+    @property
+    def device_name(self):
+        buf = C.create_string_buffer(128)
+        self._check(self._lib.spfm_device_name(self._h, buf, 128))
+        return buf.value.decode()
+
+    # ------------------------------------------------------------------ data
+    def set_data(self, X, y):
+        Xc = X if (sp.isspmatrix_csc(X) and X.has_canonical_format) else canonical_csc(X)
+        n, d = Xc.shape
+        self._keep = [_capi.i64(Xc.indptr), _capi.i32(Xc.indices), _capi.f64(Xc.data),
+                      _capi.f64(y)]
+        if self._keep[3][0].shape[0] != n:
+            raise ValueError("y has %d entries, X has %d rows" % (self._keep[3][0].shape[0], n))
+        self._check(self._lib.spfm_set_data_csc(
+            self._h, n, d, self._keep[0][1], self._keep[1][1], self._keep[2][1],
+            self._keep[3][1]))
+        self._keep = None
+        self.n, self.d = n, d
+
+    def set_params(self, P, w, lams):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        if P.ndim != 3:
+            raise ValueError("P must be (n_orders, n_components, n_features)")
+        n_orders, k, d = P.shape
+        Pa, Pp = _capi.f64(P)
+        wa, wp = _capi.f64(w)
+        la, lp = _capi.f64(lams)
+        if wa.shape[0] != d or la.shape[0] != k:
+            raise ValueError("w / lams shapes do not match P")
+        self._check(self._lib.spfm_set_params(self._h, n_orders, k, d, Pp, wp, lp))
+        self.n_orders, self.k, self.d = n_orders, k, d
+
+    def get_params(self, P=None, w=None, skip_P=False):
+        """Copy the live device state into P (n_orders, k, d) and w (d), in place when
+        arrays are given.  ``skip_P`` leaves P untouched (pbcd callbacks)."""
+        if P is None and not skip_P:
+            P = np.empty((self.n_orders, self.k, self.d))
+        if w is None:
+            w = np.empty(self.d)
+        assert w.flags.c_contiguous and w.dtype == np.float64
+        Pp = None
+        if not skip_P:
+            assert P.flags.c_contiguous and P.dtype == np.float64
+            Pp = P.ctypes.data_as(_capi._dp)
+        self._check(self._lib.spfm_get_params(self._h, Pp, w.ctypes.data_as(_capi._dp)))
+        return P, w
+
+    def configure(self, solver, loss, regularizer, degree):
+        if solver not in _capi.SOLVERS:
+            raise ValueError("Solver %s is not supported." % solver)
+        self._check(self._lib.spfm_configure(
+            self._h, _capi.SOLVERS[solver], _capi.LOSSES[loss], _capi.REGULARIZERS[regularizer],
+            int(degree)))
+
+    def init_pred(self, degree, fit_linear, add_lower_deg2):
+        self._check(self._lib.spfm_init_pred(self._h, int(degree), int(bool(fit_linear)),
+                                             int(bool(add_lower_deg2))))
+
+    def get_y_pred(self):
+        out = np.empty(self.n)
+        self._check(self._lib.spfm_get_y_pred(self._h, out.ctypes.data_as(_capi._dp)))
+        return out
+
+    def loss_sum(self):
+        out = C.c_double()
+        self._check(self._lib.spfm_loss_sum(self._h, C.byref(out)))
+        return out.value
+
+    def predict(self, X, degree, fit_linear, add_lower_deg2):
+        Xr = sp.csr_matrix(X, dtype=np.float64)
+        Xr.sum_duplicates()
+        n = Xr.shape[0]
+        if Xr.shape[1] != self.d:
+            raise ValueError("X has %d features, the model has %d" % (Xr.shape[1], self.d))
+        ia, ip = _capi.i64(Xr.indptr)
+        ja, jp = _capi.i32(Xr.indices)
+        da, dp = _capi.f64(Xr.data)
+        out = np.zeros(n)
+        self._check(self._lib.spfm_predict_csr(
+            self._h, n, ip, jp, dp, int(degree), int(bool(fit_linear)),
+            int(bool(add_lower_deg2)), out.ctypes.data_as(_capi._dp)))
+        return out
+
+    # -------------------------------------------------------------- schedule
+    def set_schedule(self, mode, indices_feature, conflict_csc=None):
+        """Fix the coordinate order for the next epochs; returns the order used.
+        ``conflict_csc``: global CSC structure (multi-GPU) for the disjointness test."""
+        jf, jp = _capi.i32(indices_feature)
+        order = np.empty(self.d, dtype=np.int32)
+        nb = C.c_int32()
+        if conflict_csc is None:
+            cp, ci, rows = None, None, 0
+        else:
+            cpa, cp = _capi.i64(conflict_csc.indptr)
+            cia, ci = _capi.i32(conflict_csc.indices)
+            rows = conflict_csc.shape[0]
+        self._check(self._lib.spfm_set_schedule(
+            self._h, _capi.SCHEDULES[mode], jp, cp, ci, rows,
+            order.ctypes.data_as(_capi._ip), C.byref(nb)))
+        self.order, self.n_batches = order, nb.value
+        return order
+
+    # ---------------------------------------------------------------- epochs
+    def cd_linear_epoch(self, alpha):
+        v = C.c_double()
+        self._check(self._lib.spfm_cd_linear_epoch(self._h, float(alpha), C.byref(v)))
+        return v.value
+
+    def pcd_epoch(self, order_idx, degree, beta, gamma, eta, indices_component):
+        ic, icp = _capi.i32(indices_component)
+        v = C.c_double()
+        self._check(self._lib.spfm_pcd_epoch(
+            self._h, int(order_idx), int(degree), float(beta), float(gamma), float(eta), icp,
+            ic.shape[0], C.byref(v)))
+        return v.value
+
+    def pbcd_epoch(self, order_idx, degree, beta, gamma, eta):
+        v = C.c_double()
+        self._check(self._lib.spfm_pbcd_epoch(
+            self._h, int(order_idx), int(degree), float(beta), float(gamma), float(eta),
+            C.byref(v)))
+        return v.value
+
+    # ------------------------------------------------------------- multi-GPU
+    @staticmethod
+    def comm_unique_id():
+        lib = _capi.load()
+        buf = C.create_string_buffer(128)
+        rc = lib.spfm_comm_unique_id(buf)
+        if rc != 0:
+            raise SpfmError("spfm_comm_unique_id: %s" % lib.spfm_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, uid, n_ranks, rank):
+        assert len(uid) == 128
+        self._check(self._lib.spfm_comm_init(self._h, uid, int(n_ranks), int(rank)))
+
+    # -------------------------------------------------------- instrumentation
+    def profile_enable(self, on=True):
+        self._check(self._lib.spfm_profile_enable(self._h, int(bool(on))))
+
+    def profile_reset(self):
+        self._check(self._lib.spfm_profile_reset(self._h))
+
+    def profile_get(self, which):
+        ms, nl, nz = C.c_double(), C.c_int64(), C.c_int64()
+        self._check(self._lib.spfm_profile_get(self._h, int(which), C.byref(ms), C.byref(nl),
+                                               C.byref(nz)))
+        return ms.value, nl.value, nz.value
+
+    def set_use_graph(self, on):
+        self._check(self._lib.spfm_set_use_graph(self._h, int(bool(on))))

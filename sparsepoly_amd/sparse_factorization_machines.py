@@ -1,0 +1,422 @@
+"""Sparse factorization machines on MI355X -- sklearn-style estimators.
+
+Drop-in for ``sparsepoly.SparseFactorizationMachine{Regressor,Classifier}``
+(reference ``sparsepoly/sparse_factorization_machines.py``) for
+``solver in {'pcd', 'pbcd'}``: same constructor keywords in the same order with
+the same defaults, same fitted attributes (``P_ (n_orders, k, d)``, ``w_``,
+``lams_``, ``n_iter_`` = 0-based index of the last iteration), same warnings and
+error types.  The epoch loops below restate ``_fit_pcd`` (:175-258) and
+``_fit_pbcd`` (:260-353); each reference epoch-function call is one call through
+the C ABI (``include/spfm.h``) into hand-written HIP kernels.  There is no CPU
+path: without the HIP library or a GPU, ``fit``/``predict`` raise.
+
+Additional keywords (after the reference's, so positional use is unchanged):
+
+``schedule``   'exact' (default): coordinates are visited exactly in the
+               reference's order (``np.arange`` or the shuffled order); consecutive
+               columns that share no row are processed as one dependent step.
+               'colored': the column conflict graph is coloured once and the
+               colour classes are visited one after another -- the same algorithm
+               run in the permuted order ``feature_order_`` (the reference's epoch
+               functions take any order, pcd.py:86-87).
+``precision``  'f32' (default) stores X, the ANOVA caches and y_pred in float32
+               (reductions, prox and parameters stay float64); 'f64' stores them
+               in float64.
+``device``     HIP device ordinal (default: ``LOCAL_RANK`` or 0).
+``distributed`` shard the rows over the ranks of the initialised
+               ``torch.distributed`` process group (one process per GPU); the
+               per-step column partial sums are all-reduced with RCCL.
+"""
+import os
+import warnings
+from abc import ABCMeta, abstractmethod
+
+import numpy as np
+import scipy.sparse as sp
+from sklearn.preprocessing import add_dummy_feature
+from sklearn.utils import check_random_state
+from sklearn.utils.validation import NotFittedError, check_array
+
+from .base import BaseSparsePoly, SparsePolyClassifierMixin, SparsePolyRegressorMixin
+from .engine import HipEngine, canonical_csc
+from .loss import CLASSIFICATION_LOSSES, REGRESSION_LOSSES
+from .regularizer import REGULARIZATION
+
+
+def _default_device():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
+    _REGULARIZERS = REGULARIZATION
+
+    @abstractmethod
+    def __init__(
+        self,
+        degree=2,
+        loss="squared",
+        n_components=2,
+        solver="pcd",
+        regularizer="squaredl12",
+        alpha=1,
+        beta=1,
+        gamma=1,
+        mean=False,
+        tol=1e-6,
+        fit_lower="explicit",
+        fit_linear=True,
+        warm_start=False,
+        init_lambdas="ones",
+        max_iter=100,
+        shuffle=False,
+        batch_size="auto",
+        eta0=1.0,
+        learning_rate="optimal",
+        power_t=1.0,
+        n_iter_no_change=5,
+        verbose=False,
+        callback=None,
+        n_calls=10,
+        random_state=None,
+        schedule="exact",
+        precision="f32",
+        device=None,
+        distributed=False,
+    ):
+        self.degree = degree
+        self.loss = loss
+        self.n_components = n_components
+        self.solver = solver
+        self.regularizer = regularizer
+        self.alpha = alpha
+        self.beta = beta
+        self.gamma = gamma
+        self.mean = mean
+        self.tol = tol
+        self.fit_lower = fit_lower
+        self.fit_linear = fit_linear
+        self.warm_start = warm_start
+        self.init_lambdas = init_lambdas
+        self.max_iter = max_iter
+        self.shuffle = shuffle
+        self.batch_size = batch_size
+        self.eta0 = eta0
+        self.learning_rate = learning_rate
+        self.power_t = power_t
+        self.n_iter_no_change = n_iter_no_change
+        self.verbose = verbose
+        self.callback = callback
+        self.n_calls = n_calls
+        self.random_state = random_state
+        self.schedule = schedule
+        self.precision = precision
+        self.device = device
+        self.distributed = distributed
+
+    # ------------------------------------------------------------------ helpers
+    def _augment(self, X):
+        """sparse_factorization_machines.py:86-92"""
+        if self.fit_lower == "augment":
+            k = 2 if self.fit_linear else 1
+            for _ in range(self.degree - k):
+                X = add_dummy_feature(X, value=1)
+        return X
+
+    def _add_lower_deg2(self):
+        """the order-2 term of _get_output, :445-449"""
+        return self.fit_lower == "explicit" and self.degree == 3
+
+    def _scaled(self, n_samples):
+        """:181-188 / :265-272"""
+        if self.mean:
+            return self.alpha * n_samples, self.beta * n_samples, self.gamma * n_samples
+        return self.alpha, self.beta, self.gamma
+
+    def _new_engine(self):
+        dev = _default_device() if self.device is None else self.device
+        return HipEngine(device=dev, precision=self.precision)
+
+    def _sync_params(self, engine, with_P=True):
+        """Copy the live device parameters into P_ / w_ (in place)."""
+        engine.get_params(self.P_, self.w_, skip_P=not with_P)
+
+    # ------------------------------------------------------------ epoch drivers
+    def _fit_pcd(self, engine, n_samples, n_features, rng, conflict_csc):
+        """Restates _fit_pcd, sparse_factorization_machines.py:175-258."""
+        indices_feature = np.arange(n_features, dtype=np.int32)
+        indices_component = np.arange(self.n_components, dtype=np.int32)
+        converged = False
+        alpha, beta, gamma = self._scaled(n_samples)
+        if not self.shuffle:
+            self.feature_order_ = engine.set_schedule(self.schedule, indices_feature,
+                                                      conflict_csc)
+        it = 0
+        for it in range(self.max_iter):
+            viol = 0
+            if self.shuffle:
+                rng.shuffle(indices_component)
+                rng.shuffle(indices_feature)
+                self.feature_order_ = engine.set_schedule(self.schedule, indices_feature,
+                                                          conflict_csc)
+            if self.fit_linear:
+                viol += engine.cd_linear_epoch(alpha)
+            if self.fit_lower == "explicit":
+                for deg in range(2, self.degree):
+                    viol += engine.pcd_epoch(self.degree - deg, deg, beta, gamma, self.eta0,
+                                             indices_component)
+            viol += engine.pcd_epoch(0, self.degree, beta, gamma, self.eta0, indices_component)
+
+            if (self.callback is not None) and it % self.n_calls == 0:
+                self._sync_params(engine)  # pcd writes through self.P_[0] (:227-228)
+                if self.callback(self) is not None:
+                    break
+            if self.verbose:
+                print(f"Iteration {it+1} violation sum {viol}")
+            if viol < self.tol:
+                if self.verbose:
+                    print(f"Converged at iteration {it+1}")
+                converged = True
+                break
+        self._sync_params(engine)
+        return converged, it
+
+    def _fit_pbcd(self, engine, n_samples, n_features, rng, conflict_csc):
+        """Restates _fit_pbcd, sparse_factorization_machines.py:260-353.  The reference
+        trains a transposed COPY of P_ (:285) and writes it back after the loop (:352),
+        so callbacks see the initial P_ but the live w_; kept."""
+        indices_feature = np.arange(n_features, dtype=np.int32)
+        converged = False
+        alpha, beta, gamma = self._scaled(n_samples)
+        if not self.shuffle:
+            self.feature_order_ = engine.set_schedule(self.schedule, indices_feature,
+                                                      conflict_csc)
+        it = 0
+        for it in range(self.max_iter):
+            viol = 0
+            if self.shuffle:
+                rng.shuffle(indices_feature)
+                self.feature_order_ = engine.set_schedule(self.schedule, indices_feature,
+                                                          conflict_csc)
+            if self.fit_linear:
+                viol += engine.cd_linear_epoch(alpha)
+            if self.fit_lower == "explicit":
+                for deg in range(2, self.degree):
+                    viol += engine.pbcd_epoch(self.degree - deg, deg, beta, gamma, self.eta0)
+            viol += engine.pbcd_epoch(0, self.degree, beta, gamma, self.eta0)
+
+            if (self.callback is not None) and it % self.n_calls == 0:
+                self._sync_params(engine, with_P=False)
+                if self.callback(self) is not None:
+                    break
+            if self.verbose:
+                print(f"Iteration {it+1} violation sum {viol}")
+            if viol < self.tol:
+                if self.verbose:
+                    print(f"Converged at iteration {it+1}")
+                converged = True
+                break
+        self._sync_params(engine)
+        return converged, it
+
+    # ---------------------------------------------------------------------- fit
+    def fit(self, X, y):
+        """Fit factorization machine to training data
+        (sparse_factorization_machines.py:355-435).
+
+        With ``distributed=True`` every rank passes the same global ``X, y``; each
+        rank trains on its contiguous block of rows.
+        """
+        X, y = self._check_X_y(X, y)
+        X = self._augment(X)
+        n_samples, n_features = X.shape
+        rng = check_random_state(self.random_state)
+        self._get_loss(self.loss)
+        self._get_regularizer(self.regularizer)
+
+        if not (self.warm_start and hasattr(self, "w_")):
+            self.w_ = np.zeros(n_features, dtype=np.double)
+
+        if self.fit_lower == "explicit":
+            n_orders = self.degree - 1
+        else:
+            n_orders = 1
+
+        if not (self.warm_start and hasattr(self, "P_")):
+            self.P_ = 0.01 * rng.randn(n_orders, self.n_components, n_features)
+
+        if not (self.warm_start and hasattr(self, "lams_")):
+            if self.init_lambdas == "ones":
+                self.lams_ = np.ones(self.n_components)
+            elif self.init_lambdas == "random_signs":
+                self.lams_ = np.sign(rng.randn(self.n_components))
+            else:
+                raise ValueError(
+                    "Lambdas must be initialized as ones "
+                    "(init_lambdas='ones') or as random "
+                    "+/- 1 (init_lambdas='random_signs')."
+                )
+
+        if np.unique(np.abs(self.lams_)) != np.array([1.0]):
+            raise ValueError("Lambdas must be +1 or -1.")
+
+        if self.solver not in ("pcd", "pbcd"):
+            if self.solver == "psgd":
+                raise NotImplementedError(
+                    "solver='psgd' is outside the MI355X hot path (pcd / pbcd); "
+                    "see DESIGN.md, out of scope."
+                )
+            msg = f"Solver {self.solver} is not supported."
+            raise ValueError(msg)
+        if self.schedule not in ("exact", "colored"):
+            raise ValueError("schedule must be 'exact' or 'colored'.")
+
+        Xc = canonical_csc(X)
+        conflict_csc = None
+        engine = self._new_engine()
+        try:
+            if self.distributed:
+                from . import distributed as _dist
+
+                lo, hi = _dist.row_block(n_samples)
+                conflict_csc = Xc
+                Xl = canonical_csc(Xc.tocsr()[lo:hi])
+                _dist.init_engine_comm(engine)
+                engine.set_data(Xl, y[lo:hi])
+            else:
+                engine.set_data(Xc, y)
+            self.P_ = np.ascontiguousarray(self.P_, dtype=np.double)
+            self.w_ = np.ascontiguousarray(self.w_, dtype=np.double)
+            engine.set_params(self.P_, self.w_, self.lams_)
+            # regularizer.init_cache_pcd / init_cache_pbcd (:194, :282), incl. their errors
+            engine.configure(self.solver, self.loss, self.regularizer, self.degree)
+            # y_pred = self._get_output(X) (:408)
+            engine.init_pred(self.degree, self.fit_linear, self._add_lower_deg2())
+            if self.solver == "pcd":
+                converged, self.n_iter_ = self._fit_pcd(engine, n_samples, n_features, rng,
+                                                        conflict_csc)
+            else:
+                converged, self.n_iter_ = self._fit_pbcd(engine, n_samples, n_features, rng,
+                                                         conflict_csc)
+            self.n_steps_per_sweep_ = engine.n_batches
+        finally:
+            engine.close()
+
+        if not converged:
+            warnings.warn("Objective did not converge. Increase max_iter.")
+        return self
+
+    # ------------------------------------------------------------------ predict
+    def _get_output(self, X):
+        """sparse_factorization_machines.py:437-451, on the device."""
+        engine = self._new_engine()
+        try:
+            engine.set_params(np.ascontiguousarray(self.P_, dtype=np.double), self.w_,
+                              self.lams_)
+            return engine.predict(X, self.degree, self.fit_linear, self._add_lower_deg2())
+        finally:
+            engine.close()
+
+    def _predict(self, X):
+        """sparse_factorization_machines.py:453-458"""
+        if not hasattr(self, "P_"):
+            raise NotFittedError("Estimator not fitted.")
+        X = check_array(X, accept_sparse="csc", dtype=np.double)
+        X = self._augment(X)
+        return self._get_output(X)
+
+
+class SparseFactorizationMachineRegressor(_BaseSparseFactorizationMachine,
+                                          SparsePolyRegressorMixin):
+    """Sparse factorization machine for regression (squared loss).
+
+    Reference: sparse_factorization_machines.py:461-684.
+    """
+
+    _LOSSES = REGRESSION_LOSSES
+
+    def __init__(
+        self,
+        degree=2,
+        n_components=2,
+        solver="pcd",
+        regularizer="squaredl12",
+        alpha=1,
+        beta=1,
+        gamma=1,
+        mean=False,
+        tol=1e-6,
+        fit_lower="explicit",
+        fit_linear=True,
+        warm_start=False,
+        init_lambdas="ones",
+        max_iter=100,
+        shuffle=False,
+        batch_size="auto",
+        eta0=1.0,
+        learning_rate="optimal",
+        power_t=1.0,
+        n_iter_no_change=5,
+        verbose=False,
+        callback=None,
+        n_calls=10,
+        random_state=None,
+        schedule="exact",
+        precision="f32",
+        device=None,
+        distributed=False,
+    ):
+        super(SparseFactorizationMachineRegressor, self).__init__(
+            degree, "squared", n_components, solver, regularizer, alpha, beta, gamma, mean, tol,
+            fit_lower, fit_linear, warm_start, init_lambdas, max_iter, shuffle, batch_size, eta0,
+            learning_rate, power_t, n_iter_no_change, verbose, callback, n_calls, random_state,
+            schedule, precision, device, distributed,
+        )
+
+
+class SparseFactorizationMachineClassifier(_BaseSparseFactorizationMachine,
+                                           SparsePolyClassifierMixin):
+    """Sparse factorization machine for binary classification.
+
+    Reference: sparse_factorization_machines.py:687-920.
+    """
+
+    _LOSSES = CLASSIFICATION_LOSSES
+
+    def __init__(
+        self,
+        degree=2,
+        loss="squared_hinge",
+        n_components=2,
+        solver="pcd",
+        regularizer="squaredl12",
+        alpha=1,
+        beta=1,
+        gamma=1,
+        mean=False,
+        tol=1e-6,
+        fit_lower="explicit",
+        fit_linear=True,
+        warm_start=False,
+        init_lambdas="ones",
+        max_iter=100,
+        shuffle=False,
+        batch_size="auto",
+        eta0=1.0,
+        learning_rate="optimal",
+        power_t=1.0,
+        n_iter_no_change=5,
+        verbose=False,
+        callback=None,
+        n_calls=10,
+        random_state=None,
+        schedule="exact",
+        precision="f32",
+        device=None,
+        distributed=False,
+    ):
+        super(SparseFactorizationMachineClassifier, self).__init__(
+            degree, loss, n_components, solver, regularizer, alpha, beta, gamma, mean, tol,
+            fit_lower, fit_linear, warm_start, init_lambdas, max_iter, shuffle, batch_size, eta0,
+            learning_rate, power_t, n_iter_no_change, verbose, callback, n_calls, random_state,
+            schedule, precision, device, distributed,
+        )

@@ -170,6 +170,10 @@ int spfm_profile_get(spfm_handle h, int which, double* ms, int64_t* launches, in
 int spfm_profile_reset(spfm_handle h);
 /* use hipGraph replay for the per-pass launch sequences (default on) */
 int spfm_set_use_graph(spfm_handle h, int on);
+/* engine tunables, by name: "use_graph" (0/1), "fuse_chain" (0/1: fused chain+sync
+ * kernel for steps of <= 64 columns), "max_batch" (columns per dependent step,
+ * applies to the next spfm_set_schedule).  Results do not depend on any of them. */
+int spfm_set_option(spfm_handle h, const char* key, int value);
 
 #ifdef __cplusplus
 }

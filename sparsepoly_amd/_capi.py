@@ -27,6 +27,7 @@ SYMBOLS = [
     "spfm_cd_linear_epoch",
     "spfm_pcd_epoch", "spfm_pbcd_epoch", "spfm_comm_unique_id", "spfm_comm_init",
     "spfm_profile_enable", "spfm_profile_get", "spfm_profile_reset", "spfm_set_use_graph",
+    "spfm_set_option",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -76,6 +77,7 @@ def load():
     L.spfm_profile_get.argtypes = [_h, C.c_int, _dp, _lp, _lp]
     L.spfm_profile_reset.argtypes = [_h]
     L.spfm_set_use_graph.argtypes = [_h, C.c_int]
+    L.spfm_set_option.argtypes = [_h, C.c_char_p, C.c_int]
     for name in SYMBOLS:
         f = getattr(L, name)
         if name not in ("spfm_destroy", "spfm_last_error"):

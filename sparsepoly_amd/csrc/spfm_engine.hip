@@ -146,7 +146,7 @@ struct spfm_engine {
 
     // schedule
     std::vector<int32_t> order, batch_ptr;
-    DevBuf d_order;
+    DevBuf d_order, d_desc;
     int max_batch_cols = 0;
     bool have_schedule = false;
     int64_t sched_version = 0;
@@ -157,6 +157,8 @@ struct spfm_engine {
 
     // graphs
     bool use_graph = true;
+    bool fuse_chain = true;  // fused chain+sync kernel for batches of <= 64 columns
+    int max_batch_opt = 4096;
     std::map<std::string, hipGraphExec_t> graphs;
 
     // comm
@@ -489,11 +491,11 @@ struct spfm_engine {
         const size_t ncache = kMaxDegree + 2;
         HIPC(abs_p.alloc(sizeof(double) * (size_t)d));
         HIPC(norms.alloc(sizeof(double) * (size_t)d));
-        HIPC(cache.alloc(sizeof(double) * ncache));
+        HIPC(cache.alloc(sizeof(double) * ncache * 2));  // pcd: double-buffered per batch
         HIPC(dcache.alloc(sizeof(double) * ncache));
         HIPC(hipMemsetAsync(abs_p.p, 0, sizeof(double) * (size_t)d, stream));
         HIPC(hipMemsetAsync(norms.p, 0, sizeof(double) * (size_t)d, stream));
-        HIPC(hipMemsetAsync(cache.p, 0, sizeof(double) * ncache, stream));
+        HIPC(hipMemsetAsync(cache.p, 0, sizeof(double) * ncache * 2, stream));
         double hd[kMaxDegree + 2] = {0};
         hd[1] = 1.0;  // omegacs.py:46 ; omegati sets it in compute_cache_pcd
         HIPC(hipMemcpyAsync(dcache.p, hd, sizeof(double) * ncache, hipMemcpyHostToDevice, stream));
@@ -538,7 +540,7 @@ struct spfm_engine {
         const int64_t rows = cf_indptr ? cf_rows : n;
         if (cf_indptr && (!cf_indices || cf_rows <= 0))
             FAIL(SPFM_ERR_INVALID, "set_schedule: bad conflict structure");
-        const int max_batch = 4096;
+        const int max_batch = max_batch_opt;
         if (mode == SPFM_SCHED_EXACT) {
             order.assign(indices_feature, indices_feature + d);
             schedule_exact(rows, d, cp, ci, indices_feature, max_batch, batch_ptr);
@@ -550,8 +552,18 @@ struct spfm_engine {
         max_batch_cols = 1;
         for (size_t b = 0; b + 1 < batch_ptr.size(); ++b)
             max_batch_cols = std::max(max_batch_cols, batch_ptr[b + 1] - batch_ptr[b]);
+        std::vector<ColDesc> hdesc((size_t)d);
+        for (int q = 0; q < d; ++q) {
+            const int j = order[(size_t)q];
+            hdesc[(size_t)q].start = h_cptr[(size_t)j];
+            hdesc[(size_t)q].len = (int32_t)(h_cptr[(size_t)j + 1] - h_cptr[(size_t)j]);
+            hdesc[(size_t)q].j = j;
+        }
         HIPC(d_order.alloc(sizeof(int32_t) * (size_t)d));
+        HIPC(d_desc.alloc(sizeof(ColDesc) * (size_t)d));
         HIPC(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * (size_t)d,
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(d_desc.p, hdesc.data(), sizeof(ColDesc) * (size_t)d,
                             hipMemcpyHostToDevice, stream));
         HIPC(hipStreamSynchronize(stream));
         have_schedule = true;
@@ -776,7 +788,7 @@ struct spfm_engine {
         const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
         double* Po = P.as<double>() + (size_t)order_idx * k * d;
         Ctl* c = ctl.as<Ctl>();
-        RegState rs = regstate();
+        double* cbuf[2] = {cache.as<double>(), cache.as<double>() + (kMaxDegree + 2)};
         hipLaunchKernelGGL(begin_pass_kernel, dim3(1), dim3(64), 0, stream, c,
                            comp_order.as<int32_t>(), lams.as<double>());
         if (n > 0)
@@ -785,28 +797,42 @@ struct spfm_engine {
                                rval.as<T>(), Po, d, A.as<T>());
         if (reg != SPFM_REG_L1)
             hipLaunchKernelGGL((pcd_compute_cache_kernel<M>), dim3(1), dim3(kBlock), 0, stream, c,
-                               Po, d, reg, rs);
+                               Po, d, reg, cbuf[0]);
         const int nb = n_batches();
+        int par = 0;  // batch b reads cbuf[par], writes cbuf[par ^ 1]
         for (int b = 0; b < nb; ++b) {
             const int c0 = batch_ptr[b], nc = batch_ptr[b + 1] - c0;
             if (nc == 0) continue;
-            const int32_t* cols = d_order.as<int32_t>() + c0;
+            const ColDesc* desc = d_desc.as<ColDesc>() + c0;
             const int64_t bn = prof_on ? batch_nnz(b) : 0;
             prof_begin(0, bn);
-            hipLaunchKernelGGL((pcd_grad_kernel<T, M>), dim3(nc), dim3(kBlock), 0, stream, c, cols,
-                               cptr.as<int64_t>(), cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
-                               yy.as<typename Vec2<T>::type>(), Po, d, loss, part.as<double>());
+            hipLaunchKernelGGL((pcd_grad_kernel<T, M>), dim3(nc), dim3(kBlock), 0, stream, c, desc,
+                               cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
+                               yy.as<typename Vec2<T>::type>(), Po, d, loss, part.as<double>(),
+                               pold.as<double>());
             prof_end(0);
             int rc = allreduce(part.as<double>(), (size_t)2 * nc);
             if (rc) return rc;
-            hipLaunchKernelGGL((pcd_chain_kernel<M>), dim3(1), dim3(kWave), 0, stream, c, cols, nc,
-                               Po, d, part.as<double>(), reg, rs, mu, beta, gamma, eta,
-                               delta.as<double>(), pold.as<double>(), viol_col.as<double>());
-            prof_begin(1, bn);
-            hipLaunchKernelGGL((pcd_sync_kernel<T, M>), dim3(nc), dim3(kBlock), 0, stream, c, cols,
-                               cptr.as<int64_t>(), cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
-                               yy.as<T>(), delta.as<double>(), pold.as<double>());
-            prof_end(1);
+            if (nc <= kWave && fuse_chain) {
+                prof_begin(1, bn);
+                hipLaunchKernelGGL((pcd_chain_sync_kernel<T, M>), dim3(nc), dim3(kBlock), 0, stream,
+                                   c, desc, nc, Po, d, part.as<double>(), pold.as<double>(), reg,
+                                   cbuf[par], cbuf[par ^ 1], mu, beta, gamma, eta,
+                                   cidx.as<int32_t>(), cval.as<T>(), A.as<T>(), yy.as<T>(),
+                                   viol_col.as<double>());
+                prof_end(1);
+            } else {
+                hipLaunchKernelGGL((pcd_chain_kernel<M>), dim3(1), dim3(kWave), 0, stream, c, desc,
+                                   nc, Po, d, part.as<double>(), pold.as<double>(), reg, cbuf[par],
+                                   cbuf[par ^ 1], mu, beta, gamma, eta, delta.as<double>(),
+                                   viol_col.as<double>());
+                prof_begin(1, bn);
+                hipLaunchKernelGGL((pcd_sync_kernel<T, M>), dim3(nc), dim3(kBlock), 0, stream, c,
+                                   desc, cidx.as<int32_t>(), cval.as<T>(), A.as<T>(), yy.as<T>(),
+                                   delta.as<double>(), pold.as<double>());
+                prof_end(1);
+            }
+            par ^= 1;
         }
         HIPC(hipGetLastError());
         return SPFM_OK;
@@ -1173,6 +1199,27 @@ int spfm_profile_reset(spfm_handle h) {
         ps.nnz = 0;
         ps.used = 0;
     }
+    return SPFM_OK;
+}
+
+int spfm_set_option(spfm_handle h, const char* key, int value) {
+    if (!h || !key) return SPFM_ERR_INVALID;
+    const std::string k(key);
+    if (k == "use_graph") {
+        h->use_graph = value != 0;
+    } else if (k == "fuse_chain") {
+        h->fuse_chain = value != 0;
+    } else if (k == "max_batch") {
+        if (value < 1) {
+            h->err = "max_batch must be >= 1";
+            return SPFM_ERR_INVALID;
+        }
+        h->max_batch_opt = value;
+    } else {
+        h->err = "unknown option: " + k;
+        return SPFM_ERR_INVALID;
+    }
+    h->clear_graphs();
     return SPFM_OK;
 }
 

@@ -34,6 +34,14 @@ struct Ctl {
     int pad[2];
 };
 
+// One column of the schedule: where its entries live in the CSC arrays.  Built
+// per schedule in visiting order, so a workgroup finds its column with one load.
+struct ColDesc {
+    int64_t start;
+    int32_t len;
+    int32_t j;
+};
+
 // Regularizer state on the device (regularizer/*.py jitclass members)
 struct RegState {
     double* abs_p;   // (d)      SquaredL12/OmegaTI _abs_p
@@ -74,6 +82,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
     return v;
+}
+
+// broadcast lane `src` (wave-uniform index) of a double through SGPRs
+__device__ __forceinline__ double readlane_d(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
 }
 
 // sum over `width` consecutive lanes (width = power of two <= 64)
@@ -174,7 +190,8 @@ __global__ __launch_bounds__(kBlock) void pcd_precompute_kernel(
 template <int M>
 __global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __restrict__ ctl,
                                                                     const double* __restrict__ P,
-                                                                    int d, int reg, RegState rs) {
+                                                                    int d, int reg,
+                                                                    double* __restrict__ cache) {
     __shared__ double sh[kBlock * (M + 1)];
     const double* ps = P + (size_t)ctl->s * d;
     const int tid = threadIdx.x;
@@ -182,11 +199,10 @@ __global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __
         double a = 0, b = 0;
         for (int j = tid; j < d; j += kBlock) {
             const double v = fabs(ps[j]);
-            rs.abs_p[j] = v;
             a += v;
         }
         block_sum2(a, b, sh);
-        if (tid == 0) rs.cache[0] = a;
+        if (tid == 0) cache[0] = a;
         return;
     }
     if (reg != REG_OMEGATI) return;
@@ -196,7 +212,6 @@ __global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __
     for (int t = 1; t <= M; ++t) c[t] = 0.0;
     for (int j = tid; j < d; j += kBlock) {
         const double v = fabs(ps[j]);
-        rs.abs_p[j] = v;
 #pragma unroll
         for (int t = M; t >= 1; --t) c[t] += c[t - 1] * v;
     }
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __
     }
     if (tid == 0) {
 #pragma unroll
-        for (int t = 0; t <= M; ++t) rs.cache[t] = sh[t];
+        for (int t = 0; t <= M; ++t) cache[t] = sh[t];
     }
 }
 
@@ -229,19 +244,19 @@ __global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __
 
 // First pass of pcd._update (optimizer/pcd.py:52-59) for every column of one
 // batch: part[2q] = sum_i dloss(yhat_i, y_i) * dA_i[M-1], part[2q+1] = sum_i
-// dA_i[M-1]^2 with dA from _grad_anova (pcd.py:8-12).  One workgroup per column.
+// dA_i[M-1]^2 with dA from _grad_anova (pcd.py:8-12); pold[q] = P[s, j] (the
+// snapshot every workgroup of the following chain reads).  One workgroup per column.
 template <typename T, int M>
 __global__ __launch_bounds__(kBlock) void pcd_grad_kernel(
-    const Ctl* __restrict__ ctl, const int32_t* __restrict__ cols,
-    const int64_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
-    const T* __restrict__ cval, const T* __restrict__ A,
+    const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc,
+    const int32_t* __restrict__ cidx, const T* __restrict__ cval, const T* __restrict__ A,
     const typename Vec2<T>::type* __restrict__ yy, const double* __restrict__ P, int d, int loss,
-    double* __restrict__ part) {
+    double* __restrict__ part, double* __restrict__ pold) {
     __shared__ double red[16];
     const int q = blockIdx.x;
-    const int j = cols[q];
-    const double p = P[(size_t)ctl->s * d + j];
-    const int64_t b = cptr[j], e = cptr[j + 1];
+    const ColDesc cd = desc[q];
+    const double p = P[(size_t)ctl->s * d + cd.j];
+    const int64_t b = cd.start, e = cd.start + cd.len;
     double g = 0.0, h = 0.0;
     for (int64_t ii = b + threadIdx.x; ii < e; ii += kBlock) {
         const int i = cidx[ii];
@@ -260,119 +275,126 @@ __global__ __launch_bounds__(kBlock) void pcd_grad_kernel(
     if (threadIdx.x == 0) {
         part[2 * q] = g;
         part[2 * q + 1] = h;
+        pold[q] = p;
     }
 }
 
 // ---------------------------------------------------------------- pcd: chain
 
-// Second half of pcd._update (optimizer/pcd.py:61-68) + P[s,j] write-back and
-// sum_viol (pcd.py:119-121) + regularizer.update_cache_pcd (pcd.py:135), for all
-// columns of one batch IN BATCH ORDER.  One wavefront: the step-size / gradient
-// arithmetic is lane-parallel (one column per lane), the prox and the cache
-// recurrence run as a uniform serial loop over the batch (prox_cd:
-// l1.py:32-33, squaredl12.py:52-57, omegati.py:82-99,104; update_cache_pcd:
-// squaredl12.py:47-50, omegati.py:76-80).
+// Second half of pcd._update (optimizer/pcd.py:61-68) for up to 64 columns held one
+// per lane: step size and gradient step are lane-parallel, then the prox and the
+// regularizer's cache recurrence run as a wave-uniform serial loop over columns
+// 0..last in batch order (prox_cd: l1.py:32-33, squaredl12.py:52-57,
+// omegati.py:82-99,104; update_cache_pcd: squaredl12.py:47-50, omegati.py:76-80).
+// Returns this lane's new coordinate.  _abs_p[j] of the reference equals |p_old|
+// here because a sweep visits every j exactly once per pass.
+// Rounding note: squaredl12's 2*st*dcache/(1+2*st) is evaluated as
+// (2*st/(1+2*st))*dcache so that the division leaves the serial loop.
+template <int M>
+__device__ __forceinline__ double pcd_chain_lanes(int reg, int lane, int last, bool valid,
+                                                  double p_old, double g, double h, double lam,
+                                                  double mu, double beta, double gamma,
+                                                  double eta, double (&cache)[M + 1]) {
+    double pin = 0.0, st = 0.0;
+    if (valid) {
+        double inv = h * mu;
+        inv += beta;
+        double upd = g * lam;
+        upd += beta * p_old;
+        upd /= inv;
+        pin = p_old - eta * upd;
+        st = eta * gamma / inv;
+    }
+    if (reg == REG_L1) {
+        const double sg = (pin > 0) ? 1.0 : ((pin < 0) ? -1.0 : 0.0);
+        const double m = fabs(pin) - st;
+        return sg * (m > 0.0 ? m : 0.0);
+    }
+    const double ab = fabs(p_old);
+    double mine = 0.0;
+    if (reg == REG_SQL12) {
+        const double den = 1 + 2 * st;
+        const double pp = pin / den;
+        const double app = fabs(pp);
+        const double tt = 2 * st / den;
+        const double sg = (pp > 0) ? 1.0 : -1.0;
+        double c0 = cache[0];
+        for (int i = 0; i <= last; ++i) {
+            const double ai = readlane_d(ab, i), ti = readlane_d(tt, i), pi = readlane_d(app, i);
+            const double dc = c0 - ai;
+            const double m = pi - ti * dc;
+            const double r = (m > 0) ? m : 0.0;
+            c0 = dc + r;
+            if (lane == i) mine = r;
+        }
+        cache[0] = c0;
+        return sg * mine;
+    }
+    // REG_OMEGATI
+    {
+        const double apin = fabs(pin);
+        const double sg = (pin > 0) ? 1.0 : -1.0;
+        for (int i = 0; i <= last; ++i) {
+            const double ai = readlane_d(ab, i), si = readlane_d(st, i), pi = readlane_d(apin, i);
+            double dc[M + 2];
+            dc[1] = 1.0;
+#pragma unroll
+            for (int deg = 2; deg <= M; ++deg) {
+                double v = cache[deg - 1];
+                v -= dc[deg - 1] * ai;
+                dc[deg] = (v < 0) ? 0.0 : v;
+            }
+            const double m = pi - si * dc[M];
+            const double r = (m > 0) ? m : 0.0;
+#pragma unroll
+            for (int deg = 1; deg < M; ++deg) cache[deg] = dc[deg + 1] + dc[deg] * r;
+            if (lane == i) mine = r;
+        }
+        return sg * mine;
+    }
+}
+
+// Stand-alone chain for batches of more than 64 columns (and for the multi-kernel
+// path): one wavefront, 64 columns at a time; writes P[s,j], sum_viol
+// (pcd.py:119-121) and delta = p_old - p_new for the sync kernel.
 template <int M>
 __global__ __launch_bounds__(kWave) void pcd_chain_kernel(
-    const Ctl* __restrict__ ctl, const int32_t* __restrict__ cols, int ncols,
-    double* __restrict__ P, int d, const double* __restrict__ part, int reg, RegState rs,
-    double mu, double beta, double gamma, double eta, double* __restrict__ delta,
-    double* __restrict__ pold, double* __restrict__ viol_col) {
-    __shared__ double pin_s[kWave], st_s[kWave], ab_s[kWave];
+    const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc, int ncols,
+    double* __restrict__ P, int d, const double* __restrict__ part,
+    const double* __restrict__ pold, int reg, const double* __restrict__ cache_in,
+    double* __restrict__ cache_out, double mu, double beta, double gamma, double eta,
+    double* __restrict__ delta, double* __restrict__ viol_col) {
     const int lane = threadIdx.x;
-    const int s = ctl->s;
     const double lam = ctl->lam;
-    double* ps = P + (size_t)s * d;
-
+    double* ps = P + (size_t)ctl->s * d;
     double cache[M + 1];
 #pragma unroll
-    for (int t = 0; t <= M; ++t) cache[t] = 0.0;
-    if (reg == REG_SQL12) cache[0] = rs.cache[0];
-    if (reg == REG_OMEGATI) {
-#pragma unroll
-        for (int t = 0; t <= M; ++t) cache[t] = rs.cache[t];
-    }
-
+    for (int t = 0; t <= M; ++t) cache[t] = cache_in[t];
     for (int base = 0; base < ncols; base += kWave) {
         const int q = base + lane;
         const bool valid = q < ncols;
         const int cnt = min(kWave, ncols - base);
+        double p_old = 0.0, g = 0.0, h = 0.0;
         int j = 0;
-        double p_old = 0.0, pin = 0.0, st = 0.0, ab = 0.0;
         if (valid) {
-            j = cols[q];
-            p_old = ps[j];
-            const double g = part[2 * q], h = part[2 * q + 1];
-            double inv = h * mu;
-            inv += beta;
-            double upd = g * lam;
-            upd += beta * p_old;
-            upd /= inv;
-            pin = p_old - eta * upd;
-            st = eta * gamma / inv;
-            if (reg == REG_SQL12 || reg == REG_OMEGATI) ab = rs.abs_p[j];
+            j = desc[q].j;
+            p_old = pold[q];
+            g = part[2 * q];
+            h = part[2 * q + 1];
         }
-        double res = 0.0;
-        if (reg == REG_L1) {
-            const double sg = (pin > 0) ? 1.0 : ((pin < 0) ? -1.0 : 0.0);
-            const double m = fabs(pin) - st;
-            res = sg * (m > 0.0 ? m : 0.0);
-        } else {
-            pin_s[lane] = pin;
-            st_s[lane] = st;
-            ab_s[lane] = ab;
-            __syncthreads();
-            if (reg == REG_SQL12) {
-                double c0 = cache[0];
-                for (int i = 0; i < cnt; ++i) {
-                    const double pi = pin_s[i], si = st_s[i], ai = ab_s[i];
-                    const double dc = c0 - ai;
-                    const double pp = pi / (1 + 2 * si);
-                    const double sg = (pp > 0) ? 1.0 : -1.0;
-                    const double m = fabs(pp) - 2 * si * dc / (1 + 2 * si);
-                    const double r = sg * (m > 0 ? m : 0);
-                    c0 -= ai;
-                    c0 += fabs(r);
-                    if (lane == i) res = r;
-                }
-                cache[0] = c0;
-            } else {  // REG_OMEGATI
-                for (int i = 0; i < cnt; ++i) {
-                    const double pi = pin_s[i], si = st_s[i], ai = ab_s[i];
-                    const double sg = (pi > 0) ? 1.0 : -1.0;
-                    double dc[M + 2];
-                    dc[1] = 1.0;
-#pragma unroll
-                    for (int deg = 2; deg <= M; ++deg) {
-                        double v = cache[deg - 1];
-                        v -= dc[deg - 1] * ai;
-                        dc[deg] = (v < 0) ? 0.0 : v;
-                    }
-                    const double m = fabs(pi) - si * dc[M];
-                    const double r = sg * (m > 0 ? m : 0.0);
-                    const double a = fabs(r);
-#pragma unroll
-                    for (int deg = 1; deg < M; ++deg) cache[deg] = dc[deg + 1] + dc[deg] * a;
-                    if (lane == i) res = r;
-                }
-            }
-            __syncthreads();
-        }
+        const double res =
+            pcd_chain_lanes<M>(reg, lane, cnt - 1, valid, p_old, g, h, lam, mu, beta, gamma, eta,
+                               cache);
         if (valid) {
             const double dl = p_old - res;
             ps[j] = res;
             delta[q] = dl;
-            pold[q] = p_old;
             viol_col[j] += fabs(dl);
-            if (reg == REG_OMEGATI) rs.abs_p[j] = fabs(res);
         }
     }
     if (lane == 0) {
-        if (reg == REG_SQL12) rs.cache[0] = cache[0];
-        if (reg == REG_OMEGATI) {
 #pragma unroll
-            for (int t = 1; t < M; ++t) rs.cache[t] = cache[t];
-        }
+        for (int t = 0; t <= M; ++t) cache_out[t] = cache[t];
     }
 }
 
@@ -382,33 +404,102 @@ __global__ __launch_bounds__(kWave) void pcd_chain_kernel(
 // column of one batch.  A column whose coordinate did not move is skipped (the
 // reference's loop is an exact no-op for update == 0).
 template <typename T, int M>
+__device__ __forceinline__ void pcd_sync_entry(size_t i, double x, double p_old, double upd,
+                                               double lam, T* __restrict__ A,
+                                               T* __restrict__ yy) {
+    double dprev = x;
+#pragma unroll
+    for (int t = 1; t < M; ++t) {
+        const size_t at = i * (M - 1) + (t - 1);
+        const double a = (double)A[at];
+        const double dcur = x * (a - p_old * dprev);
+        A[at] = (T)(a - upd * dprev);
+        dprev = dcur;
+    }
+    const double yh = (double)yy[2 * i];
+    yy[2 * i] = (T)(yh - lam * upd * dprev);
+}
+
+template <typename T, int M>
 __global__ __launch_bounds__(kBlock) void pcd_sync_kernel(
-    const Ctl* __restrict__ ctl, const int32_t* __restrict__ cols,
-    const int64_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
-    const T* __restrict__ cval, T* __restrict__ A, T* __restrict__ yy /* (yhat,y) pairs */,
-    const double* __restrict__ delta, const double* __restrict__ pold) {
+    const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc,
+    const int32_t* __restrict__ cidx, const T* __restrict__ cval, T* __restrict__ A,
+    T* __restrict__ yy /* (yhat,y) pairs */, const double* __restrict__ delta,
+    const double* __restrict__ pold) {
     const int q = blockIdx.x;
     const double upd = delta[q];
     if (upd == 0.0) return;
     const double p_old = pold[q];
     const double lam = ctl->lam;
-    const int j = cols[q];
-    const int64_t b = cptr[j], e = cptr[j + 1];
-    for (int64_t ii = b + threadIdx.x; ii < e; ii += kBlock) {
-        const int i = cidx[ii];
-        const double x = (double)cval[ii];
-        double dprev = x;
+    const ColDesc cd = desc[q];
+    const int64_t b = cd.start, e = cd.start + cd.len;
+    for (int64_t ii = b + threadIdx.x; ii < e; ii += kBlock)
+        pcd_sync_entry<T, M>((size_t)cidx[ii], (double)cval[ii], p_old, upd, lam, A, yy);
+}
+
+// Fused chain + sync for batches of at most 64 columns: every workgroup runs the
+// (cheap, scalar) chain redundantly up to its own column while its other waves
+// already have the column's entries and their A / yhat values in flight; only the
+// last workgroup publishes the regularizer cache (double-buffered: cache_in is
+// never written in this launch).  Saves one dependent kernel boundary per step.
+template <typename T, int M>
+__global__ __launch_bounds__(kBlock) void pcd_chain_sync_kernel(
+    const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc, int ncols,
+    double* __restrict__ P, int d, const double* __restrict__ part,
+    const double* __restrict__ pold, int reg, const double* __restrict__ cache_in,
+    double* __restrict__ cache_out, double mu, double beta, double gamma, double eta,
+    const int32_t* __restrict__ cidx, const T* __restrict__ cval, T* __restrict__ A,
+    T* __restrict__ yy, double* __restrict__ viol_col) {
+    __shared__ double sh[2];
+    constexpr int PF = 2;  // entries per thread fetched before the chain result is known
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ColDesc cd = desc[q];
+    const double lam = ctl->lam;
+    int ri[PF];
+    double rx[PF];
+    bool rv[PF];
 #pragma unroll
-        for (int t = 1; t < M; ++t) {
-            const size_t at = (size_t)i * (M - 1) + (t - 1);
-            const double a = (double)A[at];
-            const double dcur = x * (a - p_old * dprev);
-            A[at] = (T)(a - upd * dprev);
-            dprev = dcur;
-        }
-        const double yh = (double)yy[2 * (size_t)i];
-        yy[2 * (size_t)i] = (T)(yh - lam * upd * dprev);
+    for (int u = 0; u < PF; ++u) {
+        const int off = tid + u * kBlock;
+        rv[u] = off < cd.len;
+        ri[u] = rv[u] ? cidx[cd.start + off] : 0;
+        rx[u] = rv[u] ? (double)cval[cd.start + off] : 0.0;
     }
+    if (wave == 0) {
+        const bool valid = lane < ncols;
+        double p_old = 0.0, g = 0.0, h = 0.0;
+        if (valid) {
+            p_old = pold[lane];
+            g = part[2 * lane];
+            h = part[2 * lane + 1];
+        }
+        double cache[M + 1];
+#pragma unroll
+        for (int t = 0; t <= M; ++t) cache[t] = cache_in[t];
+        const double res = pcd_chain_lanes<M>(reg, lane, q, valid, p_old, g, h, lam, mu, beta,
+                                              gamma, eta, cache);
+        if (lane == q) {
+            const double dl = p_old - res;
+            P[(size_t)ctl->s * d + cd.j] = res;
+            viol_col[cd.j] += fabs(dl);
+            sh[0] = dl;
+            sh[1] = p_old;
+        }
+        if (q == ncols - 1 && lane == 0) {
+#pragma unroll
+            for (int t = 0; t <= M; ++t) cache_out[t] = cache[t];
+        }
+    }
+    __syncthreads();
+    const double upd = sh[0];
+    if (upd == 0.0) return;
+    const double p_old = sh[1];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (rv[u]) pcd_sync_entry<T, M>((size_t)ri[u], rx[u], p_old, upd, lam, A, yy);
+    for (int64_t ii = cd.start + tid + PF * kBlock; ii < cd.start + cd.len; ii += kBlock)
+        pcd_sync_entry<T, M>((size_t)cidx[ii], (double)cval[ii], p_old, upd, lam, A, yy);
 }
 
 // ------------------------------------------------------------------ cd_linear

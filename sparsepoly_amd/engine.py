@@ -228,3 +228,6 @@ class HipEngine(object):
 
     def set_use_graph(self, on):
         self._check(self._lib.spfm_set_use_graph(self._h, int(bool(on))))
+
+    def set_option(self, key, value):
+        self._check(self._lib.spfm_set_option(self._h, key.encode(), int(value)))

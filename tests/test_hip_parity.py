@@ -84,13 +84,15 @@ class _Run(object):
     records viol / sum-loss per iteration."""
 
     def __init__(self, X, y, meta, P0, lams, precision, schedule="exact", orders=None,
-                 corders=None, eta0=1.0, n_epochs=4, use_graph=True):
+                 corders=None, eta0=1.0, n_epochs=4, use_graph=True, options=None):
         from sparsepoly_amd.engine import HipEngine
 
         n, d = X.shape
         k, degree = meta["k"], meta["degree"]
         eng = HipEngine(0, precision)
         eng.set_use_graph(use_graph)
+        for key, val in (options or {}).items():
+            eng.set_option(key, val)
         eng.set_data(X, y)
         eng.set_params(P0, np.zeros(d), lams)
         eng.configure(meta["solver"], meta["loss"], meta["regularizer"], degree)
@@ -202,6 +204,36 @@ def test_graph_replay_equals_eager(case):
     assert a.viol == b.viol
     np.testing.assert_array_equal(a.P, b.P)
     np.testing.assert_array_equal(a.y_pred, b.y_pred)
+
+
+@pytest.mark.parametrize("options", [{"fuse_chain": 0}, {"max_batch": 3},
+                                     {"max_batch": 1, "fuse_chain": 0}])
+@pytest.mark.parametrize("case", ["c2|squared", "c3|logistic", "c4d3|squared"])
+def test_engine_options_do_not_change_results(oracle, case, options):
+    """Fused vs stand-alone chain kernels and the batch-size cap only change how the
+    sweep is cut into launches, not the arithmetic."""
+    z = load_golden("g3_small_configs.npz")
+    X = golden_csr(z)
+    meta = json.loads(str(z["meta|" + case]))
+    y = z["y"]
+    if meta["loss"] != "squared":
+        y = np.where(y > np.median(y), 1.0, -1.0)
+    a = _Run(X, y, meta, z["P0|" + case], z["lams|" + case], "f64", schedule="colored")
+    b = _Run(X, y, meta, z["P0|" + case], z["lams|" + case], "f64", schedule="colored",
+             options=options)
+    if "max_batch" in options:  # possibly a different (still valid) order: ask the oracle
+        assert b.n_batches >= a.n_batches
+        fm = oracle.OracleFM(degree=meta["degree"], loss=meta["loss"], n_components=meta["k"],
+                             solver=meta["solver"], regularizer=meta["regularizer"],
+                             alpha=meta["alpha"], beta=meta["beta"], gamma=meta["gamma"], tol=0,
+                             fit_linear=True, max_iter=4, feature_order=b.order)
+        fm.fit(X, y, P_init=z["P0|" + case], lams_init=z["lams|" + case])
+        np.testing.assert_allclose(b.viol, [h[0] for h in fm.history], rtol=1e-9)
+        np.testing.assert_allclose(b.P, fm.P_, rtol=0, atol=1e-8)
+    else:
+        np.testing.assert_array_equal(a.order, b.order)
+        np.testing.assert_allclose(a.viol, b.viol, rtol=1e-12)
+        np.testing.assert_allclose(a.P, b.P, rtol=0, atol=1e-12)
 
 
 @pytest.mark.parametrize("degree", [2, 3, 4, 5])

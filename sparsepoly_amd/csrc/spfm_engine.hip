@@ -45,10 +45,20 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
     bool load(std::string& err) {
         if (lib) return true;
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // 1) a copy the process already holds (PyTorch maps its own librccl.so): share it;
+        // 2) otherwise load ROCm's, with local scope so that it never interposes on a
+        //    copy another library may bring later.
+        const char* names[] = {"librccl.so", "librccl.so.1"};
         for (const char* nm : names) {
-            lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
             if (lib) break;
+        }
+        if (!lib) {
+            const char* fresh[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+            for (const char* nm : fresh) {
+                lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+                if (lib) break;
+            }
         }
         if (!lib) {
             err = std::string("cannot load librccl: ") + dlerror();

@@ -377,3 +377,69 @@ def test_errors_match_reference():
     with pytest.raises(ValueError):
         SparseFactorizationMachineRegressor(solver="pbcd", regularizer="omegati",
                                             max_iter=1).fit(X, y)
+
+
+def test_rccl_path_single_rank_equals_plain(tmp_path):
+    """The multi-GPU code path (RCCL communicator, split linear kernels, per-step
+    ncclAllReduce of the partials, no graph) exercised with a 1-rank communicator must
+    reproduce the single-GPU result bit for bit."""
+    from sparsepoly_amd.engine import HipEngine
+
+    z = load_golden("g3_small_configs.npz")
+    X = golden_csr(z)
+    for case in ("c2|squared", "c4|squared"):
+        meta = json.loads(str(z["meta|" + case]))
+        a = _Run(X, z["y"], meta, z["P0|" + case], z["lams|" + case], "f32", schedule="colored")
+
+        class _CommRun(_Run):
+            pass
+
+        # same driver, but with a communicator installed right after engine creation
+        orig_init = HipEngine.__init__
+
+        def patched(self, *args, **kw):
+            orig_init(self, *args, **kw)
+            self.comm_init(HipEngine.comm_unique_id(), 1, 0)
+
+        HipEngine.__init__ = patched
+        try:
+            b = _Run(X, z["y"], meta, z["P0|" + case], z["lams|" + case], "f32",
+                     schedule="colored")
+        finally:
+            HipEngine.__init__ = orig_init
+        assert a.viol == b.viol
+        np.testing.assert_array_equal(a.P, b.P)
+        np.testing.assert_array_equal(a.w, b.w)
+        np.testing.assert_array_equal(a.y_pred, b.y_pred)
+
+
+def test_estimator_distributed_world1():
+    """distributed=True through torch.distributed (world size 1): row block = all rows,
+    global structure used for the schedule, RCCL communicator created from the broadcast id."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from sparsepoly_amd import SparseFactorizationMachineRegressor
+
+    z = load_golden("g2_config1.npz")
+    X = golden_csr(z)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        kw = dict(degree=2, n_components=4, regularizer="l1", solver="pcd", gamma=1e-3,
+                  max_iter=3, tol=0, random_state=0, precision="f64")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            a = SparseFactorizationMachineRegressor(**kw).fit(X, z["y"])
+            b = SparseFactorizationMachineRegressor(distributed=True, **kw).fit(X, z["y"])
+        np.testing.assert_array_equal(a.P_, b.P_)
+        np.testing.assert_array_equal(a.w_, b.w_)
+    finally:
+        dist.destroy_process_group()

@@ -88,6 +88,9 @@ def main():
         log("data %dx%d nnz=%d generated in %.1fs" % (n, d, nnz, time.time() - t0))
 
     eng = HipEngine(local_rank, args.precision)
+    for kv in filter(None, os.environ.get("SPFM_OPTS", "").split(",")):  # e.g. prb_groups=32
+        key, val = kv.split("=")
+        eng.set_option(key, int(val))
     conflict = None
     if world > 1:
         lo, hi = spdist.row_block(n, rank, world)

@@ -172,8 +172,15 @@ int spfm_profile_reset(spfm_handle h);
 int spfm_set_use_graph(spfm_handle h, int on);
 /* engine tunables, by name: "use_graph" (0/1), "fuse_chain" (0/1: fused chain+sync
  * kernel for steps of <= 64 columns), "max_batch" (columns per dependent step,
- * applies to the next spfm_set_schedule).  Results do not depend on any of them. */
+ * applies to the next spfm_set_schedule), "persistent" (0/1: one persistent launch
+ * per pcd component pass, single GPU; caps steps at 64 columns), "prb_groups"
+ * (workgroups of the persistent pass).  They change how a sweep is cut into
+ * launches, never the arithmetic of a given coordinate order. */
 int spfm_set_option(spfm_handle h, const char* key, int value);
+
+/* diagnostic ("prb_stamps" option): accumulated shader cycles per phase of the last
+ * persistent pass, 8 values per workgroup; returns the number of values written. */
+int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap);
 
 #ifdef __cplusplus
 }

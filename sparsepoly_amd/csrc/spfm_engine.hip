@@ -20,6 +20,9 @@ void schedule_colored(int64_t, int32_t, const int64_t*, const int32_t*, const in
                       std::vector<int32_t>&, std::vector<int32_t>&);
 void csc_to_csr(int64_t, int32_t, const int64_t*, const int32_t*, std::vector<int64_t>&,
                 std::vector<int32_t>&, std::vector<int64_t>&);
+void build_rowblock_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
+                           const std::vector<int32_t>&, int, std::vector<int32_t>&,
+                           std::vector<int32_t>&);
 }  // namespace spfm
 
 using namespace spfm;
@@ -169,6 +172,15 @@ struct spfm_engine {
     bool use_graph = true;
     bool fuse_chain = true;  // fused chain+sync kernel for batches of <= 64 columns
     int max_batch_opt = 4096;
+
+    // persistent row-block pass (single GPU, pcd): one launch per component pass
+    bool persistent = true;
+    int prb_G = 64;
+    bool prb_ready = false;
+    DevBuf prb_sp, prb_erow, prb_eval, prb_slab, prb_cnt, prb_abort, prow_old, d_bptr, prb_stamps,
+        prb_viol;
+    bool prb_stamp_on = false;
+    static constexpr size_t kPrbLds = 84 * 1024;  // > half of the CU's 160 KiB: 1 WG per CU
     std::map<std::string, hipGraphExec_t> graphs;
 
     // comm
@@ -550,7 +562,7 @@ struct spfm_engine {
         const int64_t rows = cf_indptr ? cf_rows : n;
         if (cf_indptr && (!cf_indices || cf_rows <= 0))
             FAIL(SPFM_ERR_INVALID, "set_schedule: bad conflict structure");
-        const int max_batch = max_batch_opt;
+        const int max_batch = (persistent && !comm) ? std::min(max_batch_opt, 64) : max_batch_opt;
         if (mode == SPFM_SCHED_EXACT) {
             order.assign(indices_feature, indices_feature + d);
             schedule_exact(rows, d, cp, ci, indices_feature, max_batch, batch_ptr);
@@ -576,7 +588,13 @@ struct spfm_engine {
         HIPC(hipMemcpyAsync(d_desc.p, hdesc.data(), sizeof(ColDesc) * (size_t)d,
                             hipMemcpyHostToDevice, stream));
         HIPC(hipStreamSynchronize(stream));
+        std::vector<int32_t> hb(batch_ptr.begin(), batch_ptr.end());
+        HIPC(d_bptr.alloc(sizeof(int32_t) * hb.size()));
+        HIPC(hipMemcpyAsync(d_bptr.p, hb.data(), sizeof(int32_t) * hb.size(),
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipStreamSynchronize(stream));
         have_schedule = true;
+        prb_ready = false;
         ++sched_version;
         clear_graphs();
         if (order_out) std::memcpy(order_out, order.data(), sizeof(int32_t) * (size_t)d);
@@ -848,6 +866,134 @@ struct spfm_engine {
         return SPFM_OK;
     }
 
+    // ---------------------------------------------------- persistent row-block pass
+    bool prb_usable() const {
+        return persistent && !comm && max_batch_cols <= 64 && nnz < ((int64_t)1 << 31) && n > 0;
+    }
+
+    template <typename T>
+    int ensure_prb() {
+        if (prb_ready) return SPFM_OK;
+        int ncu = 0;
+        HIPC(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        if (prb_G > ncu) prb_G = ncu;
+        if (prb_G < 1) prb_G = 1;
+        std::vector<int32_t> sp, src;
+        build_rowblock_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, prb_G, sp, src);
+        DevBuf d_src;
+        HIPC(d_src.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+        HIPC(prb_sp.alloc(sizeof(int32_t) * sp.size()));
+        HIPC(prb_erow.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+        HIPC(prb_eval.alloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1)));
+        HIPC(prb_slab.alloc(sizeof(double) * 2 * (size_t)prb_G * 64 * 2));
+        HIPC(prb_cnt.alloc(sizeof(unsigned) * (size_t)n_batches()));
+        HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
+        HIPC(prow_old.alloc(sizeof(double) * (size_t)d));
+        HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
+        HIPC(prb_stamps.alloc(sizeof(long long) * 8 * (size_t)prb_G));
+        HIPC(hipMemsetAsync(prb_stamps.p, 0, prb_stamps.bytes, stream));
+        HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
+        HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));
+        HIPC(hipMemcpyAsync(prb_sp.p, sp.data(), sizeof(int32_t) * sp.size(),
+                            hipMemcpyHostToDevice, stream));
+        if (nnz > 0) {
+            HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * (size_t)nnz,
+                                hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL((prb_gather_kernel<T>), dim3(cdiv(nnz, 256)), dim3(256), 0, stream,
+                               nnz, d_src.as<int32_t>(), cidx.as<int32_t>(), cval.as<T>(),
+                               prb_erow.as<int32_t>(), prb_eval.as<T>());
+            HIPC(hipGetLastError());
+        }
+        HIPC(hipStreamSynchronize(stream));
+        prb_ready = true;
+        return SPFM_OK;
+    }
+
+    PrbArgs prb_args() {
+        PrbArgs a;
+        a.G = prb_G;
+        a.nb = n_batches();
+        a.bptr = d_bptr.as<int32_t>();
+        a.desc = d_desc.as<ColDesc>();
+        a.sp = prb_sp.as<int32_t>();
+        a.erow = prb_erow.as<int32_t>();
+        a.slab = prb_slab.as<double>();
+        a.cnt = prb_cnt.as<unsigned>();
+        a.abort_flag = prb_abort.as<unsigned>();
+        a.stamps = prb_stamp_on ? prb_stamps.as<long long>() : nullptr;
+        return a;
+    }
+
+    template <typename T, int M, int LOSS>
+    int pcd_pass_prb(int order_idx, double beta, double gamma, double eta) {
+        const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
+        int rc = ensure_prb<T>();
+        if (rc) return rc;
+        double* Po = P.as<double>() + (size_t)order_idx * k * d;
+        Ctl* c = ctl.as<Ctl>();
+        double* cb = cache.as<double>();
+        HIPC(hipFuncSetAttribute((const void*)pcd_prb_kernel<T, M, LOSS>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrbLds));
+        hipLaunchKernelGGL(begin_pass_kernel, dim3(1), dim3(64), 0, stream, c,
+                           comp_order.as<int32_t>(), lams.as<double>());
+        hipLaunchKernelGGL((pcd_precompute_kernel<T, M>), dim3(cdiv(n, kBlock)), dim3(kBlock), 0,
+                           stream, c, n, rptr.as<int64_t>(), ridx.as<int32_t>(), rval.as<T>(), Po,
+                           d, A.as<T>());
+        if (reg != SPFM_REG_L1)
+            hipLaunchKernelGGL((pcd_compute_cache_kernel<M>), dim3(1), dim3(kBlock), 0, stream, c,
+                               Po, d, reg, cb);
+        hipLaunchKernelGGL(snapshot_row_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, c, Po, d,
+                           d_desc.as<ColDesc>(), prow_old.as<double>());
+        HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));  // tag 0 = "not yet"
+        prof_begin(0, nnz);
+        hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS>), dim3(prb_G), dim3(kPrbThreads), kPrbLds,
+                           stream, c, prb_args(), prb_eval.as<T>(), A.as<T>(), yy.as<T>(),
+                           prow_old.as<double>(), Po, d, reg, cb, mu, beta, gamma, eta,
+                           prb_viol.as<double>());
+        prof_end(0);
+        hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
+                           d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+
+    template <typename T, int M>
+    int pcd_prb_loss(int order_idx, double beta, double gamma, double eta) {
+        switch (loss) {
+            case SPFM_LOSS_SQUARED:
+                return pcd_pass_prb<T, M, LOSS_SQUARED>(order_idx, beta, gamma, eta);
+            case SPFM_LOSS_SQUARED_HINGE:
+                return pcd_pass_prb<T, M, LOSS_SQUARED_HINGE>(order_idx, beta, gamma, eta);
+            default:
+                return pcd_pass_prb<T, M, LOSS_LOGISTIC>(order_idx, beta, gamma, eta);
+        }
+    }
+
+    template <typename T>
+    int pcd_prb_dispatch(int M, int order_idx, double beta, double gamma, double eta) {
+        switch (M) {
+            case 2: return pcd_prb_loss<T, 2>(order_idx, beta, gamma, eta);
+            case 3: return pcd_prb_loss<T, 3>(order_idx, beta, gamma, eta);
+            case 4: return pcd_prb_loss<T, 4>(order_idx, beta, gamma, eta);
+            case 5: return pcd_prb_loss<T, 5>(order_idx, beta, gamma, eta);
+            case 6: return pcd_prb_loss<T, 6>(order_idx, beta, gamma, eta);
+        }
+        FAIL(SPFM_ERR_UNSUPPORTED, "degree outside 2..6");
+    }
+
+    int prb_check_abort() {
+        if (!prb_ready) return SPFM_OK;
+        unsigned flag = 0;
+        HIPC(hipMemcpyAsync(&flag, prb_abort.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        HIPC(hipStreamSynchronize(stream));
+        if (flag) {
+            (void)hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream);
+            FAIL(SPFM_ERR_RUNTIME,
+                 "persistent pass timed out waiting for its workgroups (not all resident?)");
+        }
+        return SPFM_OK;
+    }
+
     template <typename T>
     int pcd_pass_dispatch(int M, int order_idx, double beta, double gamma, double eta) {
         switch (M) {
@@ -879,15 +1025,23 @@ struct spfm_engine {
         HIPC(hipMemsetAsync(ctl.p, 0, sizeof(Ctl), stream));
         const std::string key = fkey("pcd", {beta, gamma, eta},
                                      {order_idx, degree, loss, reg, sched_version});
+        const bool use_prb = prb_usable();
         for (int pass = 0; pass < n_comp; ++pass) {
-            rc = run_cached(key, [&]() {
-                return dtype == SPFM_F32
-                           ? pcd_pass_dispatch<float>(degree, order_idx, beta, gamma, eta)
-                           : pcd_pass_dispatch<double>(degree, order_idx, beta, gamma, eta);
-            });
+            if (use_prb) {
+                rc = dtype == SPFM_F32 ? pcd_prb_dispatch<float>(degree, order_idx, beta, gamma, eta)
+                                       : pcd_prb_dispatch<double>(degree, order_idx, beta, gamma, eta);
+            } else {
+                rc = run_cached(key, [&]() {
+                    return dtype == SPFM_F32
+                               ? pcd_pass_dispatch<float>(degree, order_idx, beta, gamma, eta)
+                               : pcd_pass_dispatch<double>(degree, order_idx, beta, gamma, eta);
+                });
+            }
             if (rc) return rc;
         }
-        return epoch_epilogue(viol);
+        rc = epoch_epilogue(viol);
+        if (rc) return rc;
+        return use_prb ? prb_check_abort() : SPFM_OK;
     }
 
     // ------------------------------------------------------------------- pbcd
@@ -1219,6 +1373,18 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->use_graph = value != 0;
     } else if (k == "fuse_chain") {
         h->fuse_chain = value != 0;
+    } else if (k == "persistent") {
+        h->persistent = value != 0;
+        h->prb_ready = false;
+    } else if (k == "prb_stamps") {
+        h->prb_stamp_on = value != 0;
+    } else if (k == "prb_groups") {
+        if (value < 1) {
+            h->err = "prb_groups must be >= 1";
+            return SPFM_ERR_INVALID;
+        }
+        h->prb_G = value;
+        h->prb_ready = false;
     } else if (k == "max_batch") {
         if (value < 1) {
             h->err = "max_batch must be >= 1";
@@ -1231,6 +1397,17 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
     }
     h->clear_graphs();
     return SPFM_OK;
+}
+
+int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap) {
+    GUARD(h);
+    if (!h->prb_ready || !out) return SPFM_ERR_INVALID;
+    const int nval = 8 * h->prb_G;
+    if (cap < nval) return SPFM_ERR_INVALID;
+    if (hipMemcpy(out, h->prb_stamps.p, sizeof(long long) * (size_t)nval, hipMemcpyDeviceToHost) !=
+        hipSuccess)
+        return SPFM_ERR_RUNTIME;
+    return nval;
 }
 
 int spfm_set_use_graph(spfm_handle h, int on) {

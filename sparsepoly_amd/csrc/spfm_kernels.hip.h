@@ -281,6 +281,37 @@ __global__ __launch_bounds__(kBlock) void pcd_grad_kernel(
 
 // ---------------------------------------------------------------- pcd: chain
 
+// ---- speculative affine scan for the degree-2 cache recurrences --------------
+// For degree 2 the regularizer cache is one scalar c and column i maps it through a
+// piecewise-affine f_i (squaredl12.py:47-57: c' = (c - a) + max(p - t (c - a), 0);
+// omegati.py:76-99 at degree 2: u = max(c - a, 0), c' = u + max(p - s u, 0)).  Given
+// the branch each column takes, f_i is affine, and the values seen by all 64 columns
+// follow from ONE wave-parallel prefix composition of affine maps (6 shuffle steps)
+// instead of a 64-long dependent loop.  The branches are guessed (from the previous
+// round's values, initially from c at the start of the batch), the scan is evaluated,
+// and every lane re-checks its own branch with the value it actually receives; all
+// lanes before the first mismatch are then provably right, so each round fixes at
+// least one more column and the fixed point is exactly the sequential result (up to
+// the rounding of composed vs. step-by-step affine evaluation, ~1e-16 relative).
+__device__ __forceinline__ void affine_scan_inclusive(double& al, double& be, int lane) {
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const double oa = __shfl_up(al, o, kWave);
+        const double ob = __shfl_up(be, o, kWave);
+        if (lane >= o) {  // mine after other: x -> al*(oa*x + ob) + be
+            be = al * ob + be;
+            al = al * oa;
+        }
+    }
+}
+
+// value of the cache in front of column `lane` given c0 and the inclusive scan
+__device__ __forceinline__ double affine_before(double al_inc, double be_inc, double c0, int lane) {
+    const double pa = __shfl_up(al_inc, 1, kWave);
+    const double pb = __shfl_up(be_inc, 1, kWave);
+    return (lane == 0) ? c0 : (pa * c0 + pb);
+}
+
 // Second half of pcd._update (optimizer/pcd.py:61-68) for up to 64 columns held one
 // per lane: step size and gradient step are lane-parallel, then the prox and the
 // regularizer's cache recurrence run as a wave-uniform serial loop over columns
@@ -318,22 +349,68 @@ __device__ __forceinline__ double pcd_chain_lanes(int reg, int lane, int last, b
         const double app = fabs(pp);
         const double tt = 2 * st / den;
         const double sg = (pp > 0) ? 1.0 : -1.0;
-        double c0 = cache[0];
-        for (int i = 0; i <= last; ++i) {
-            const double ai = readlane_d(ab, i), ti = readlane_d(tt, i), pi = readlane_d(app, i);
-            const double dc = c0 - ai;
-            const double m = pi - ti * dc;
-            const double r = (m > 0) ? m : 0.0;
-            c0 = dc + r;
-            if (lane == i) mine = r;
+        const double c0 = cache[0];
+        const bool act = valid && lane <= last;
+        // branch guess: evaluate every column at c0
+        bool nz = (app - tt * (c0 - ab)) > 0;
+        double cb = c0, m = 0.0, al = 1.0, be = 0.0;
+        for (int round = 0; round <= kWave; ++round) {
+            al = act ? (nz ? (1.0 - tt) : 1.0) : 1.0;
+            be = act ? (nz ? (app - (1.0 - tt) * ab) : -ab) : 0.0;
+            affine_scan_inclusive(al, be, lane);
+            cb = affine_before(al, be, c0, lane);
+            m = fma(-tt, cb - ab, app);
+            const bool nz2 = m > 0;
+            const unsigned long long bad = __ballot(act && (nz2 != nz));
+            nz = nz2;
+            if (bad == 0ull) break;
         }
-        cache[0] = c0;
-        return sg * mine;
+        const double r = (act && nz) ? m : 0.0;
+        cache[0] = readlane_d(al, last) * c0 + readlane_d(be, last);
+        return sg * r;
     }
     // REG_OMEGATI
     {
         const double apin = fabs(pin);
         const double sg = (pin > 0) ? 1.0 : -1.0;
+        if (M == 2) {
+            // degree 2: u = max(c - a, 0); r = max(p - s u, 0); c' = u + r  (dcache[1] = 1)
+            const double c0 = cache[1];
+            const bool act = valid && lane <= last;
+            bool pos = (c0 - ab) >= 0;                       // clip of omegati.py:97-98 inactive
+            bool nz = (apin - st * (pos ? (c0 - ab) : 0.0)) > 0;
+            double cb = c0, u = 0.0, m = 0.0, al = 1.0, be = 0.0;
+            for (int round = 0; round <= kWave; ++round) {
+                if (!act) {
+                    al = 1.0;
+                    be = 0.0;
+                } else if (!pos) {   // u = 0, r = p
+                    al = 0.0;
+                    be = apin;
+                } else if (nz) {     // c' = (1 - s)(c - a) + p
+                    al = 1.0 - st;
+                    be = apin - al * ab;
+                } else {             // c' = c - a
+                    al = 1.0;
+                    be = -ab;
+                }
+                affine_scan_inclusive(al, be, lane);
+                cb = affine_before(al, be, c0, lane);
+                const double v = cb - ab;
+                const bool pos2 = !(v < 0);
+                u = pos2 ? v : 0.0;
+                m = apin - st * u;
+                const bool nz2 = m > 0;
+                const unsigned long long bad =
+                    __ballot(act && ((pos2 != pos) || (pos2 && (nz2 != nz))));
+                pos = pos2;
+                nz = nz2;
+                if (bad == 0ull) break;
+            }
+            const double r = act ? ((m > 0) ? m : 0.0) : 0.0;
+            cache[1] = readlane_d(al, last) * c0 + readlane_d(be, last);
+            return sg * r;
+        }
         for (int i = 0; i <= last; ++i) {
             const double ai = readlane_d(ab, i), si = readlane_d(st, i), pi = readlane_d(apin, i);
             double dc[M + 2];
@@ -500,6 +577,404 @@ __global__ __launch_bounds__(kBlock) void pcd_chain_sync_kernel(
         if (rv[u]) pcd_sync_entry<T, M>((size_t)ri[u], rx[u], p_old, upd, lam, A, yy);
     for (int64_t ii = cd.start + tid + PF * kBlock; ii < cd.start + cd.len; ii += kBlock)
         pcd_sync_entry<T, M>((size_t)cidx[ii], (double)cval[ii], p_old, upd, lam, A, yy);
+}
+
+// ------------------------------------------- persistent row-block pass (PRB)
+//
+// One launch sweeps ALL batches of a component pass.  G workgroups (one per CU),
+// workgroup g owns the contiguous row block R_g; A and (yhat,y) rows of R_g are
+// read and written by that workgroup only, so they need no inter-workgroup
+// coherence and stay warm in its XCD's L2.  The entries of every batch are
+// pre-sorted on the host per (workgroup, batch, slot) (`erow/eval/sp`), so all
+// entry loads are plain streaming loads at known addresses.
+//
+// Per dependent step the only exchange is the all-gather of the per-slot partial
+// sums: workgroup g stores its (sum dloss*dA, sum dA^2) pairs write-through
+// (agent-scope relaxed atomic stores = global_store sc1) into slab[parity][g][slot],
+// drains them (s_waitcnt vmcnt(0)), and one lane adds 1 to the step's arrival
+// counter; one lane polls that counter with sc1 loads until G arrivals, after
+// which the same wave reads all G slabs with sc1 loads and sums them in fixed
+// order g = 0..G-1 (bitwise identical in every workgroup).  This is the hand-off
+// form "one signalling lane per storing workgroup, counter add / sc1 poll, all
+// stores and loads sc1, one workgroup per CU" of MI355X_MICROARCH.md (Valid forms,
+// first table row).  Every workgroup then runs the scalar chain redundantly and
+// scatter-updates its own rows.  Slabs are double-buffered by step parity: a
+// workgroup can only be two publishes ahead of a reader if it passed the
+// intermediate all-gather, which needs that reader's arrival.
+// Every spin is bounded; on time-out the abort word is set and all workgroups
+// leave the loop (the host reports the failure).
+
+struct PrbArgs {
+    int G;                 // workgroups
+    int nb;                // batches in the sweep
+    const int32_t* bptr;   // [nb+1] batch boundaries into desc
+    const ColDesc* desc;   // columns in visiting order
+    const int32_t* sp;     // [G][nb][65] slot boundaries into erow/eval
+    const int32_t* erow;   // entry row ids, sorted by (workgroup, batch, slot, row)
+    double* slab;          // [2][G][64][2]
+    unsigned* cnt;         // [nb] arrival counters (zeroed before the launch)
+    unsigned* abort_flag;  // [1]
+    long long* stamps;     // diagnostic: [G][8] accumulated cycles per phase, or nullptr
+};
+
+__device__ __forceinline__ void st_agent(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p),
+                       (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+    const unsigned long long u =
+        __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)u);
+}
+
+// ---- tagged-granule exchange ----------------------------------------------------
+// A partial sum travels as ONE naturally aligned 8-byte word: the double with its two
+// lowest mantissa bits replaced by a step tag (relative perturbation <= 2^-51, applied
+// before the value is used anywhere, so every workgroup sums identical numbers).  The
+// data is the flag (MI355X_MICROARCH.md "R2's granule"): one sc1 store publishes, sc1
+// loads poll the word itself; no drain, no counter, no fence.  Slabs are double-buffered
+// by step parity and zeroed before every launch; tag(b) = ((b >> 1) % 3) + 1 is never 0
+// and differs from the tag of the slab's previous occupant (step b - 2).
+__device__ __forceinline__ unsigned long long prb_tag(int b) {
+    return (unsigned long long)(((b >> 1) % 3) + 1);
+}
+__device__ __forceinline__ void prb_store_granule(double* p, double v, unsigned long long tag) {
+    const unsigned long long u =
+        ((unsigned long long)__double_as_longlong(v) & ~3ull) | tag;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), u, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long prb_load_granule(const double* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Worker wave `w` (0..3) sums the granules of workgroups [w*G/4, (w+1)*G/4) for slot
+// `lane` (all loads in flight together, re-swept until every tag matches); the control
+// wave later adds the four quarter sums in order w = 0..3, so the total is the same bit
+// pattern in every workgroup.  Returns false after a bounded number of sweeps.
+template <int NV>
+__device__ __forceinline__ bool prb_collect_quarter(const PrbArgs& a, int b, int w, int lane,
+                                                    int ncols, double* out /* [4][64][2] LDS */) {
+    const double* slab = a.slab + (size_t)(b & 1) * a.G * 64 * 2;
+    const unsigned long long tag = prb_tag(b);
+    const int g0 = (a.G * w) / 4, g1 = (a.G * (w + 1)) / 4;
+    double tot[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) tot[v] = 0.0;
+    bool ok = true;
+    if (lane < ncols) {
+        const double* sl = slab + (size_t)lane * 2;
+        for (int gg = g0; gg < g1; gg += 8) {
+            unsigned long long t[8][NV];
+            unsigned spins = 0;
+            for (;;) {
+                bool all = true;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const bool in = gg + u < g1;
+                        t[u][v] = in ? prb_load_granule(sl + (size_t)(gg + u) * 128 + v) : tag;
+                        all = all && ((t[u][v] & 3ull) == tag);
+                    }
+                if (all) break;
+                if ((++spins & 63u) == 0) {
+                    if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) ||
+                        spins > (1u << 21)) {
+                        __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        ok = false;
+                        break;
+                    }
+                }
+            }
+            if (!ok) break;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    if (gg + u < g1) tot[v] += __longlong_as_double((long long)(t[u][v] & ~3ull));
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[((size_t)w * 64 + lane) * 2 + v] = tot[v];
+    return ok;
+}
+
+// The entries one thread owns in one step: 4 lanes share a slot, each keeps up to
+// PRB_PF entries (row, value) in registers; a slot with more than 4*PRB_PF entries in
+// this row block falls back to a reload loop for the rest.
+constexpr int PRB_PF = 4;
+template <typename T>
+struct PrbEntries {
+    int e0, e1;
+    int row[PRB_PF];
+    T x[PRB_PF];
+};
+
+__device__ __forceinline__ void prb_load_sp(const PrbArgs& a, int g, int b, int slot, int ncols,
+                                            int& e0, int& e1) {
+    e0 = 0;
+    e1 = 0;
+    if (slot < ncols) {
+        const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
+        e0 = spb[slot];
+        e1 = spb[slot + 1];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void prb_load_entries(const PrbArgs& a, const T* __restrict__ eval,
+                                                 int e0, int e1, int sub, PrbEntries<T>& en) {
+    en.e0 = e0;
+    en.e1 = e1;
+#pragma unroll
+    for (int u = 0; u < PRB_PF; ++u) {
+        const int e = e0 + sub + 4 * u;
+        const bool v = e < e1;
+        en.row[u] = v ? a.erow[e] : 0;
+        en.x[u] = v ? eval[e] : (T)0;
+    }
+}
+
+// Workgroup = 5 wavefronts: wave 0 is the CONTROL wave (publish, poll, chain), waves
+// 1..4 are WORKERS (256 threads = 64 slots x 4 lanes) that own the entries.  Software
+// pipeline of step b: its entries are already in worker registers (loaded during step
+// b-1 from slot bounds loaded during step b-2), so phase 1 starts with the row gathers;
+// the workers issue the next step's streaming loads while the control wave waits for
+// the other workgroups.
+constexpr int kPrbThreads = 320;
+
+template <typename T, int M, int LOSS>
+__global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
+    const Ctl* __restrict__ ctl, PrbArgs a, const T* __restrict__ eval, T* __restrict__ A,
+    T* __restrict__ yy, const double* __restrict__ pold_sched, double* __restrict__ P, int d,
+    int reg, const double* __restrict__ cache_in, double mu, double beta, double gamma,
+    double eta, double* __restrict__ viol_pos) {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // sized to pin 1 WG / CU
+    double* sh_delta = dyn_lds + 128;  // [64]
+    double* sh_pold = dyn_lds + 192;   // [64]
+    double* sh_quart = dyn_lds + 256;  // [4][64][2] quarter sums over workgroups
+    int* sh_ok = reinterpret_cast<int*>(dyn_lds + 768);
+    const typename Vec2<T>::type* yy2 = reinterpret_cast<const typename Vec2<T>::type*>(yy);
+    const int g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool control = wave == 0;
+    const int wt = tid - 64;  // worker thread id (negative on the control wave)
+    const int slot = control ? 64 : (wt >> 2), sub = wt & 3;
+    const int s = ctl->s;
+    const double lam = ctl->lam;
+    double* ps = P + (size_t)s * d;
+    double cache[M + 1];
+#pragma unroll
+    for (int t = 0; t <= M; ++t) cache[t] = cache_in[t];
+
+    PrbEntries<T> cur, nxt;
+    int c0 = a.bptr[0], c1 = a.bptr[1];
+    int c2 = (a.nb > 1) ? a.bptr[2] : c1;
+    int c3 = (a.nb > 2) ? a.bptr[3] : c2;
+    {
+        int e0, e1;
+        prb_load_sp(a, g, 0, slot, c1 - c0, e0, e1);
+        prb_load_entries<T>(a, eval, e0, e1, sub, cur);
+    }
+    int ne0 = 0, ne1 = 0;  // slot bounds of step b+1
+    if (a.nb > 1) prb_load_sp(a, g, 1, slot, c2 - c1, ne0, ne1);
+    double p_slot = (slot < c1 - c0) ? pold_sched[c0 + slot] : 0.0;
+    if (tid == 0) *sh_ok = 1;
+    // diagnostic stamps (only when a.stamps != nullptr): cycles per phase, thread 0
+    const bool stamp = a.stamps != nullptr;
+    long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = stamp ? clock64() : 0;
+#define PRB_STAMP(k)                        \
+    if (stamp && tid == 0) {                \
+        const long long tn = clock64();     \
+        acc[k] += tn - tprev;               \
+        tprev = tn;                         \
+    }
+
+    for (int b = 0; b < a.nb; ++b) {
+        const int ncols = c1 - c0;
+        const int c4 = (b + 4 <= a.nb) ? a.bptr[b + 4] : c3;  // used two steps from now
+        // ---- phase 1 (workers): gather the rows of the prefetched entries, partial sums
+        // (pcd.py:52-59); A / yhat values stay in registers for phase 3
+        double av[PRB_PF][M > 1 ? M - 1 : 1];
+        double yh[PRB_PF], yt[PRB_PF], dlast[PRB_PF];
+        double pl = 0.0;
+        int jl = 0;
+        if (control) {
+            if (lane < ncols) {
+                pl = pold_sched[c0 + lane];
+                if (g == 0) jl = a.desc[c0 + lane].j;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < PRB_PF; ++u) {  // all gathers in flight before any use
+                const size_t i = (size_t)cur.row[u];
+                const typename Vec2<T>::type yv = yy2[i];
+                yh[u] = (double)yv.x;
+                yt[u] = (double)yv.y;
+#pragma unroll
+                for (int t = 1; t < M; ++t) av[u][t - 1] = (double)A[i * (M - 1) + (t - 1)];
+            }
+            double ag = 0.0, ah = 0.0;
+#pragma unroll
+            for (int u = 0; u < PRB_PF; ++u) {
+                const double x = (double)cur.x[u];
+                double dprev = x;
+#pragma unroll
+                for (int t = 1; t < M; ++t) dprev = x * (av[u][t - 1] - p_slot * dprev);
+                dlast[u] = dprev;
+                const double dl = dloss_dev(LOSS, yh[u], yt[u]);
+                const bool v = cur.e0 + sub + 4 * u < cur.e1;
+                ag += v ? dl * dprev : 0.0;
+                ah += v ? dprev * dprev : 0.0;
+            }
+            for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {  // rare: long slot
+                const int i = a.erow[e];
+                const double x = (double)eval[e];
+                const typename Vec2<T>::type yv = yy2[i];
+                double dprev = x;
+#pragma unroll
+                for (int t = 1; t < M; ++t) {
+                    const double a1 = (double)A[(size_t)i * (M - 1) + (t - 1)];
+                    dprev = x * (a1 - p_slot * dprev);
+                }
+                ag += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * dprev;
+                ah += dprev * dprev;
+            }
+            ag += __shfl_xor(ag, 1, kWave);
+            ah += __shfl_xor(ah, 1, kWave);
+            ag += __shfl_xor(ag, 2, kWave);
+            ah += __shfl_xor(ah, 2, kWave);
+            // publish this row block's partial sums of the slot (tagged granules).  Slots
+            // beyond the batch are published too (as zeros): every word of a slab is then
+            // rewritten at every use of the buffer, so a reader can never meet a stale
+            // word that happens to carry the current tag.
+            if (sub == 0) {
+                double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + slot) * 2;
+                const unsigned long long tag = prb_tag(b);
+                prb_store_granule(sl, ag, tag);
+                prb_store_granule(sl + 1, ah, tag);
+            }
+        }
+        PRB_STAMP(0)
+        double p_next = 0.0;
+        int n2e0 = 0, n2e1 = 0;
+        if (!control) {
+            const bool ok = prb_collect_quarter<2>(a, b, wave - 1, lane, ncols, sh_quart);
+            if (!ok) *sh_ok = 0;
+            if (b + 1 < a.nb) {
+                // prefetch (after the exchange: vmcnt retires in order, so streaming loads
+                // issued earlier would delay every granule check): entries of step b+1
+                // (bounds already in registers), bounds of b+2
+                prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt);
+                if (slot < c2 - c1) p_next = pold_sched[c1 + slot];
+                if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1);
+            }
+        }
+        // B3: quarter sums in LDS.  Raw barrier: only LDS traffic must have landed; the
+        // prefetch loads just issued stay in flight across it (a __syncthreads() would
+        // add s_waitcnt vmcnt(0) and expose their HBM latency on every step).
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        PRB_STAMP(3)
+        if (!*sh_ok) break;
+        if (control) {
+            double tot[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+                tot[v] = ((sh_quart[(0 * 64 + lane) * 2 + v] + sh_quart[(1 * 64 + lane) * 2 + v]) +
+                          sh_quart[(2 * 64 + lane) * 2 + v]) +
+                         sh_quart[(3 * 64 + lane) * 2 + v];
+            const bool valid = lane < ncols;
+            const double res = pcd_chain_lanes<M>(reg, lane, ncols - 1, valid, pl, tot[0], tot[1],
+                                                  lam, mu, beta, gamma, eta, cache);
+            const double dl = valid ? (pl - res) : 0.0;
+            sh_delta[lane] = dl;
+            sh_pold[lane] = pl;
+            if (g == 0 && valid) {
+                ps[jl] = res;
+                viol_pos[c0 + lane] = fabs(dl);  // by position; folded into viol_col later
+            }
+            PRB_STAMP(4)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B4: deltas in LDS
+        PRB_STAMP(5)
+        // ---- phase 3 (workers): scatter-update of the own rows (pcd.py:124-133)
+        if (slot < ncols) {
+            const double upd = sh_delta[slot];
+            if (upd != 0.0) {
+                const double p_old = sh_pold[slot];
+#pragma unroll
+                for (int u = 0; u < PRB_PF; ++u) {
+                    if (cur.e0 + sub + 4 * u < cur.e1) {
+                        const size_t i = (size_t)cur.row[u];
+                        const double x = (double)cur.x[u];
+                        double dprev = x;
+#pragma unroll
+                        for (int t = 1; t < M; ++t) {
+                            const double a1 = av[u][t - 1];
+                            const double dcur = x * (a1 - p_old * dprev);
+                            A[i * (M - 1) + (t - 1)] = (T)(a1 - upd * dprev);
+                            dprev = dcur;
+                        }
+                        yy[2 * i] = (T)(yh[u] - lam * upd * dlast[u]);
+                    }
+                }
+                for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4)
+                    pcd_sync_entry<T, M>((size_t)a.erow[e], (double)eval[e], p_old, upd, lam, A,
+                                         yy);
+            }
+        }
+        cur = nxt;
+        p_slot = p_next;
+        ne0 = n2e0;
+        ne1 = n2e1;
+        c0 = c1;
+        c1 = c2;
+        c2 = c3;
+        c3 = c4;
+        __syncthreads();  // B5: rows move between slots from step to step
+        PRB_STAMP(6)
+    }
+#undef PRB_STAMP
+    if (stamp && tid == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a.stamps[(size_t)g * 8 + q] = acc[q];
+    }
+}
+
+// viol_col[desc[pos].j] += viol_pos[pos]   (sum_viol bookkeeping of the persistent pass)
+__global__ void fold_viol_kernel(int d, const ColDesc* __restrict__ desc,
+                                 const double* __restrict__ viol_pos,
+                                 double* __restrict__ viol_col) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < d) viol_col[desc[pos].j] += viol_pos[pos];
+}
+
+// in visiting order: out[pos] = P[s, desc[pos].j]
+__global__ void snapshot_row_kernel(const Ctl* __restrict__ ctl, const double* __restrict__ P,
+                                    int d, const ColDesc* __restrict__ desc,
+                                    double* __restrict__ out) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < d) out[pos] = P[(size_t)ctl->s * d + desc[pos].j];
+}
+
+// erow/eval = cidx/cval gathered through the host-built entry permutation
+template <typename T>
+__global__ void prb_gather_kernel(int64_t nnz, const int32_t* __restrict__ src,
+                                  const int32_t* __restrict__ cidx, const T* __restrict__ cval,
+                                  int32_t* __restrict__ erow, T* __restrict__ eval) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) {
+        const int32_t q = src[e];
+        erow[e] = cidx[q];
+        eval[e] = cval[q];
+    }
 }
 
 // ------------------------------------------------------------------ cd_linear

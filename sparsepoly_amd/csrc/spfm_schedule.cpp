@@ -120,4 +120,44 @@ void csc_to_csr(int64_t n, int32_t d, const int64_t* cptr, const int32_t* cidx,
         }
 }
 
+// Entry stream of the persistent row-block pass: entries sorted by (row block g,
+// batch b, slot q, row).  sp[(g*nb + b)*65 + q] = first entry of slot q (65 = 64 slots
+// + end), src[e] = position of entry e in the CSC arrays.  Requires batches of at
+// most 64 columns and nnz < 2^31.
+void build_rowblock_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
+                           const std::vector<int32_t>& order,
+                           const std::vector<int32_t>& batch_ptr, int G,
+                           std::vector<int32_t>& sp, std::vector<int32_t>& src) {
+    const int nb = (int)batch_ptr.size() - 1;
+    const int64_t rows_per = (n + G - 1) / G > 0 ? (n + G - 1) / G : 1;
+    sp.assign((size_t)G * nb * 65 + 1, 0);
+    // pass 1: counts
+    for (int b = 0; b < nb; ++b)
+        for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
+            const int32_t j = order[(size_t)batch_ptr[b] + q];
+            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                const int g = (int)(cidx[ii] / rows_per);
+                sp[((size_t)g * nb + b) * 65 + q]++;
+            }
+        }
+    // exclusive prefix sum in (g, b, q) order; slots >= ncols of a batch hold 0 entries, so
+    // sp[..+q] for q in [ncols, 64] all equal the end of the (g, b) segment
+    int64_t run = 0;
+    for (size_t t = 0; t < sp.size(); ++t) {
+        const int64_t c = sp[t];
+        sp[t] = (int32_t)run;
+        run += c;
+    }
+    src.resize((size_t)run);
+    std::vector<int32_t> fill(sp.begin(), sp.end());
+    for (int b = 0; b < nb; ++b)
+        for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
+            const int32_t j = order[(size_t)batch_ptr[b] + q];
+            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                const int g = (int)(cidx[ii] / rows_per);
+                src[(size_t)fill[((size_t)g * nb + b) * 65 + q]++] = (int32_t)ii;
+            }
+        }
+}
+
 }  // namespace spfm

@@ -229,5 +229,12 @@ class HipEngine(object):
     def set_use_graph(self, on):
         self._check(self._lib.spfm_set_use_graph(self._h, int(bool(on))))
 
+    def debug_prb_stamps(self):
+        buf = np.zeros(8 * 256, dtype=np.int64)
+        nv = self._lib.spfm_debug_prb_stamps(self._h, buf.ctypes.data_as(_capi._lp), buf.size)
+        if nv < 0:
+            self._check(nv)
+        return buf[:nv].reshape(-1, 8)
+
     def set_option(self, key, value):
         self._check(self._lib.spfm_set_option(self._h, key.encode(), int(value)))

@@ -199,15 +199,18 @@ def test_graph_replay_equals_eager(case):
     z = load_golden("g3_small_configs.npz")
     X = golden_csr(z)
     meta = json.loads(str(z["meta|" + case]))
-    a = _Run(X, z["y"], meta, z["P0|" + case], z["lams|" + case], "f32", use_graph=True)
-    b = _Run(X, z["y"], meta, z["P0|" + case], z["lams|" + case], "f32", use_graph=False)
+    a = _Run(X, z["y"], meta, z["P0|" + case], z["lams|" + case], "f32", use_graph=True,
+             options={"persistent": 0})
+    b = _Run(X, z["y"], meta, z["P0|" + case], z["lams|" + case], "f32", use_graph=False,
+             options={"persistent": 0})
     assert a.viol == b.viol
     np.testing.assert_array_equal(a.P, b.P)
     np.testing.assert_array_equal(a.y_pred, b.y_pred)
 
 
-@pytest.mark.parametrize("options", [{"fuse_chain": 0}, {"max_batch": 3},
-                                     {"max_batch": 1, "fuse_chain": 0}])
+@pytest.mark.parametrize("options", [{"persistent": 0}, {"persistent": 0, "fuse_chain": 0},
+                                     {"prb_groups": 3}, {"prb_groups": 256}, {"max_batch": 3},
+                                     {"max_batch": 1, "fuse_chain": 0, "persistent": 0}])
 @pytest.mark.parametrize("case", ["c2|squared", "c3|logistic", "c4d3|squared"])
 def test_engine_options_do_not_change_results(oracle, case, options):
     """Fused vs stand-alone chain kernels and the batch-size cap only change how the
@@ -232,8 +235,8 @@ def test_engine_options_do_not_change_results(oracle, case, options):
         np.testing.assert_allclose(b.P, fm.P_, rtol=0, atol=1e-8)
     else:
         np.testing.assert_array_equal(a.order, b.order)
-        np.testing.assert_allclose(a.viol, b.viol, rtol=1e-12)
-        np.testing.assert_allclose(a.P, b.P, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(a.viol, b.viol, rtol=1e-10)
+        np.testing.assert_allclose(a.P, b.P, rtol=0, atol=1e-10)
 
 
 @pytest.mark.parametrize("degree", [2, 3, 4, 5])
@@ -389,10 +392,8 @@ def test_rccl_path_single_rank_equals_plain(tmp_path):
     X = golden_csr(z)
     for case in ("c2|squared", "c4|squared"):
         meta = json.loads(str(z["meta|" + case]))
-        a = _Run(X, z["y"], meta, z["P0|" + case], z["lams|" + case], "f32", schedule="colored")
-
-        class _CommRun(_Run):
-            pass
+        a = _Run(X, z["y"], meta, z["P0|" + case], z["lams|" + case], "f32", schedule="colored",
+                 options={"persistent": 0, "use_graph": 0})
 
         # same driver, but with a communicator installed right after engine creation
         orig_init = HipEngine.__init__
@@ -439,7 +440,7 @@ def test_estimator_distributed_world1():
             warnings.simplefilter("ignore")
             a = SparseFactorizationMachineRegressor(**kw).fit(X, z["y"])
             b = SparseFactorizationMachineRegressor(distributed=True, **kw).fit(X, z["y"])
-        np.testing.assert_array_equal(a.P_, b.P_)
-        np.testing.assert_array_equal(a.w_, b.w_)
+        np.testing.assert_allclose(a.P_, b.P_, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(a.w_, b.w_, rtol=0, atol=1e-10)
     finally:
         dist.destroy_process_group()

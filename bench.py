@@ -144,28 +144,40 @@ def main():
     epochs_per_s = args.steps / elapsed
     loss_after = eng.loss_sum()
 
-    # ---- roofline of the dominant kernel (profiled pass, outside the timed region)
+    # ---- roofline of the dominant kernel (profiled pass, outside the timed region):
+    # HIP events on the engine's stream around every launch of that kernel
     roof = None
+    persistent = bool(eng.get_option("persistent_active"))
     eng.profile_reset()
     eng.profile_enable(True)
-    eng.pcd_epoch(0, DEGREE, BETA, GAMMA, ETA0, ic[:2])  # 2 component passes
+    eng.pcd_epoch(0, DEGREE, BETA, GAMMA, ETA0, ic[:4] if persistent else ic[:2])
     eng.profile_enable(False)
     g_ms, g_launch, g_nnz = eng.profile_get(0)
     s_ms, s_launch, s_nnz = eng.profile_get(1)
     tsz = 4 if args.precision == "f32" else 8
-    # pcd_grad reads per column entry: row index 4 + value T + A[i,1..m-1] T(m-1) +
-    # (yhat,y) 2T  
-    grad_bytes_per_nnz = 4 + tsz + tsz * (DEGREE - 1) + 2 * tsz
+    if persistent:
+        # pcd_prb_kernel = one whole component pass (gather + exchange + chain + scatter);
+        # per column entry: row 4 + value T + (yhat, y) read 2T + yhat write T +
+        # A[i,1..m-1] read and write 2T(m-1)  (= SURVEY 8d's k*nnz*(20 + 8(m-1)) term)
+        kname, bytes_per_nnz = "pcd_prb_kernel", 4 + tsz + 3 * tsz + 2 * tsz * (DEGREE - 1)
+    else:
+        # pcd_grad_kernel reads per column entry: row 4 + value T + A[i,1..m-1] T(m-1) +
+        # (yhat, y) 2T
+        kname, bytes_per_nnz = "pcd_grad_kernel", 4 + tsz + tsz * (DEGREE - 1) + 2 * tsz
     if g_launch > 0 and g_ms > 0:
         avg_us = 1e3 * g_ms / g_launch
-        bytes_per_launch = grad_bytes_per_nnz * g_nnz / g_launch
+        bytes_per_launch = bytes_per_nnz * g_nnz / g_launch
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
-        roof = {"bound": "hbm", "kernel": "pcd_grad_kernel", "achieved": round(achieved, 2),
+        roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": None, "avg_launch_us": round(avg_us, 3),
                 "alg_bytes_per_launch": round(bytes_per_launch, 1),
-                "launches_timed": int(g_launch),
-                "sync_kernel_avg_us": round(1e3 * s_ms / max(s_launch, 1), 3)}
+                "launches_timed": int(g_launch)}
+        if persistent:
+            roof["dependent_steps_per_launch"] = n_batches
+            roof["us_per_dependent_step_in_kernel"] = round(avg_us / n_batches, 3)
+        else:
+            roof["sync_kernel_avg_us"] = round(1e3 * s_ms / max(s_launch, 1), 3)
     # whole-iteration algorithmic traffic, f32 layout
     nnz_glob = nnz
     b_alg = 8 * nnz_glob + 4 * (DEGREE - 1) * n * K + K * nnz_glob * (20 + 8 * (DEGREE - 1)) \

@@ -177,6 +177,9 @@ int spfm_set_use_graph(spfm_handle h, int on);
  * (workgroups of the persistent pass).  They change how a sweep is cut into
  * launches, never the arithmetic of a given coordinate order. */
 int spfm_set_option(spfm_handle h, const char* key, int value);
+/* read back a tunable, or the derived "persistent_active" (1 if the next pcd epoch
+ * will use the persistent pass: option on, single GPU, steps of <= 64 columns) */
+int spfm_get_option(spfm_handle h, const char* key, int* value);
 
 /* diagnostic ("prb_stamps" option): accumulated shader cycles per phase of the last
  * persistent pass, 8 values per workgroup; returns the number of values written. */

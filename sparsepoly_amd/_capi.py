@@ -27,7 +27,7 @@ SYMBOLS = [
     "spfm_cd_linear_epoch",
     "spfm_pcd_epoch", "spfm_pbcd_epoch", "spfm_comm_unique_id", "spfm_comm_init",
     "spfm_profile_enable", "spfm_profile_get", "spfm_profile_reset", "spfm_set_use_graph",
-    "spfm_set_option", "spfm_debug_prb_stamps",
+    "spfm_set_option", "spfm_get_option", "spfm_debug_prb_stamps",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -78,6 +78,7 @@ def load():
     L.spfm_profile_reset.argtypes = [_h]
     L.spfm_set_use_graph.argtypes = [_h, C.c_int]
     L.spfm_set_option.argtypes = [_h, C.c_char_p, C.c_int]
+    L.spfm_get_option.argtypes = [_h, C.c_char_p, C.POINTER(C.c_int)]
     L.spfm_debug_prb_stamps.argtypes = [_h, _lp, C.c_int]
     for name in SYMBOLS:
         f = getattr(L, name)

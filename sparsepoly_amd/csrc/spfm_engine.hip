@@ -521,8 +521,9 @@ struct spfm_engine {
         double hd[kMaxDegree + 2] = {0};
         hd[1] = 1.0;  // omegacs.py:46 ; omegati sets it in compute_cache_pcd
         HIPC(hipMemcpyAsync(dcache.p, hd, sizeof(double) * ncache, hipMemcpyHostToDevice, stream));
-        const size_t arow = (solver == SPFM_SOLVER_PCD) ? (size_t)(top_degree - 1)
-                                                       : (size_t)(top_degree - 1) * k;
+        // pcd keeps the caches of ALL components (one precompute pass per epoch): same
+        // footprint as pbcd's (n, (m-1), k) tensor
+        const size_t arow = (size_t)(top_degree - 1) * k;
         HIPC(A.alloc(tsize() * (size_t)(n > 0 ? n : 1) * arow));
         HIPC(ctl.alloc(sizeof(Ctl)));
         HIPC(hipMemsetAsync(ctl.p, 0, sizeof(Ctl), stream));
@@ -819,10 +820,7 @@ struct spfm_engine {
         double* cbuf[2] = {cache.as<double>(), cache.as<double>() + (kMaxDegree + 2)};
         hipLaunchKernelGGL(begin_pass_kernel, dim3(1), dim3(64), 0, stream, c,
                            comp_order.as<int32_t>(), lams.as<double>());
-        if (n > 0)
-            hipLaunchKernelGGL((pcd_precompute_kernel<T, M>), dim3(cdiv(n, kBlock)), dim3(kBlock),
-                               0, stream, c, n, rptr.as<int64_t>(), ridx.as<int32_t>(),
-                               rval.as<T>(), Po, d, A.as<T>());
+        const size_t a_stride = (size_t)n * (M - 1);
         if (reg != SPFM_REG_L1)
             hipLaunchKernelGGL((pcd_compute_cache_kernel<M>), dim3(1), dim3(kBlock), 0, stream, c,
                                Po, d, reg, cbuf[0]);
@@ -835,7 +833,7 @@ struct spfm_engine {
             const int64_t bn = prof_on ? batch_nnz(b) : 0;
             prof_begin(0, bn);
             hipLaunchKernelGGL((pcd_grad_kernel<T, M>), dim3(nc), dim3(kBlock), 0, stream, c, desc,
-                               cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
+                               cidx.as<int32_t>(), cval.as<T>(), A.as<T>(), a_stride,
                                yy.as<typename Vec2<T>::type>(), Po, d, loss, part.as<double>(),
                                pold.as<double>());
             prof_end(0);
@@ -846,8 +844,8 @@ struct spfm_engine {
                 hipLaunchKernelGGL((pcd_chain_sync_kernel<T, M>), dim3(nc), dim3(kBlock), 0, stream,
                                    c, desc, nc, Po, d, part.as<double>(), pold.as<double>(), reg,
                                    cbuf[par], cbuf[par ^ 1], mu, beta, gamma, eta,
-                                   cidx.as<int32_t>(), cval.as<T>(), A.as<T>(), yy.as<T>(),
-                                   viol_col.as<double>());
+                                   cidx.as<int32_t>(), cval.as<T>(), A.as<T>(), a_stride,
+                                   yy.as<T>(), viol_col.as<double>());
                 prof_end(1);
             } else {
                 hipLaunchKernelGGL((pcd_chain_kernel<M>), dim3(1), dim3(kWave), 0, stream, c, desc,
@@ -856,8 +854,8 @@ struct spfm_engine {
                                    viol_col.as<double>());
                 prof_begin(1, bn);
                 hipLaunchKernelGGL((pcd_sync_kernel<T, M>), dim3(nc), dim3(kBlock), 0, stream, c,
-                                   desc, cidx.as<int32_t>(), cval.as<T>(), A.as<T>(), yy.as<T>(),
-                                   delta.as<double>(), pold.as<double>());
+                                   desc, cidx.as<int32_t>(), cval.as<T>(), A.as<T>(), a_stride,
+                                   yy.as<T>(), delta.as<double>(), pold.as<double>());
                 prof_end(1);
             }
             par ^= 1;
@@ -936,9 +934,6 @@ struct spfm_engine {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrbLds));
         hipLaunchKernelGGL(begin_pass_kernel, dim3(1), dim3(64), 0, stream, c,
                            comp_order.as<int32_t>(), lams.as<double>());
-        hipLaunchKernelGGL((pcd_precompute_kernel<T, M>), dim3(cdiv(n, kBlock)), dim3(kBlock), 0,
-                           stream, c, n, rptr.as<int64_t>(), ridx.as<int32_t>(), rval.as<T>(), Po,
-                           d, A.as<T>());
         if (reg != SPFM_REG_L1)
             hipLaunchKernelGGL((pcd_compute_cache_kernel<M>), dim3(1), dim3(kBlock), 0, stream, c,
                                Po, d, reg, cb);
@@ -947,9 +942,9 @@ struct spfm_engine {
         HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));  // tag 0 = "not yet"
         prof_begin(0, nnz);
         hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS>), dim3(prb_G), dim3(kPrbThreads), kPrbLds,
-                           stream, c, prb_args(), prb_eval.as<T>(), A.as<T>(), yy.as<T>(),
-                           prow_old.as<double>(), Po, d, reg, cb, mu, beta, gamma, eta,
-                           prb_viol.as<double>());
+                           stream, c, prb_args(), prb_eval.as<T>(), A.as<T>(),
+                           (size_t)n * (M - 1), yy.as<T>(), prow_old.as<double>(), Po, d, reg, cb,
+                           mu, beta, gamma, eta, prb_viol.as<double>());
         prof_end(0);
         hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
                            d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());
@@ -994,6 +989,36 @@ struct spfm_engine {
         return SPFM_OK;
     }
 
+    // one precompute pass for all components (A_all[s][i][m-1]); needs P^T
+    template <typename T, int M>
+    int pcd_precompute_all(int order_idx) {
+        if (n == 0) return SPFM_OK;
+        pt_valid = false;
+        int rc = ensure_pt();
+        if (rc) return rc;
+        const size_t lds = sizeof(T) * (size_t)(M - 1) * kWave * 33;
+        HIPC(hipFuncSetAttribute((const void*)pcd_precompute_all_kernel<T, M>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int64_t tiles = (n + 31) / 32;
+        const unsigned grid = (unsigned)std::min<int64_t>(tiles, 256 * 8);
+        hipLaunchKernelGGL((pcd_precompute_all_kernel<T, M>), dim3(grid), dim3(kBlock), lds,
+                           stream, n, k, rptr.as<int64_t>(), ridx.as<int32_t>(), rval.as<T>(),
+                           Pt.as<double>() + (size_t)order_idx * k * d, A.as<T>());
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+    template <typename T>
+    int pcd_precompute_all_dispatch(int M, int order_idx) {
+        switch (M) {
+            case 2: return pcd_precompute_all<T, 2>(order_idx);
+            case 3: return pcd_precompute_all<T, 3>(order_idx);
+            case 4: return pcd_precompute_all<T, 4>(order_idx);
+            case 5: return pcd_precompute_all<T, 5>(order_idx);
+            case 6: return pcd_precompute_all<T, 6>(order_idx);
+        }
+        FAIL(SPFM_ERR_UNSUPPORTED, "degree outside 2..6");
+    }
+
     template <typename T>
     int pcd_pass_dispatch(int M, int order_idx, double beta, double gamma, double eta) {
         switch (M) {
@@ -1025,6 +1050,9 @@ struct spfm_engine {
         HIPC(hipMemsetAsync(ctl.p, 0, sizeof(Ctl), stream));
         const std::string key = fkey("pcd", {beta, gamma, eta},
                                      {order_idx, degree, loss, reg, sched_version});
+        rc = dtype == SPFM_F32 ? pcd_precompute_all_dispatch<float>(degree, order_idx)
+                               : pcd_precompute_all_dispatch<double>(degree, order_idx);
+        if (rc) return rc;
         const bool use_prb = prb_usable();
         for (int pass = 0; pass < n_comp; ++pass) {
             if (use_prb) {
@@ -1039,6 +1067,7 @@ struct spfm_engine {
             }
             if (rc) return rc;
         }
+        pt_valid = false;  // the passes rewrote P; the (d,k) image is stale again
         rc = epoch_epilogue(viol);
         if (rc) return rc;
         return use_prb ? prb_check_abort() : SPFM_OK;
@@ -1396,6 +1425,22 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         return SPFM_ERR_INVALID;
     }
     h->clear_graphs();
+    return SPFM_OK;
+}
+
+int spfm_get_option(spfm_handle h, const char* key, int* value) {
+    if (!h || !key || !value) return SPFM_ERR_INVALID;
+    const std::string k(key);
+    if (k == "use_graph") *value = h->use_graph;
+    else if (k == "fuse_chain") *value = h->fuse_chain;
+    else if (k == "max_batch") *value = h->max_batch_opt;
+    else if (k == "persistent") *value = h->persistent;
+    else if (k == "prb_groups") *value = h->prb_G;
+    else if (k == "persistent_active") *value = h->have_schedule && h->prb_usable();
+    else {
+        h->err = "unknown option: " + k;
+        return SPFM_ERR_INVALID;
+    }
     return SPFM_OK;
 }
 

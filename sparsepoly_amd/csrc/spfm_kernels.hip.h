@@ -180,6 +180,80 @@ __global__ __launch_bounds__(kBlock) void pcd_precompute_kernel(
     for (int t = 1; t < M; ++t) A[(size_t)i * (M - 1) + (t - 1)] = (T)a[t];
 }
 
+// All components in one pass over the CSR image (the "one precompute pass for all s"
+// of the roofline model): A_all[s][i][t-1] = A^{(s)}[i, t].  Valid because
+// P[s,:] changes only during pass s, so A^{(s)} computed from the epoch-start P equals
+// what the reference recomputes at the start of pass s (pcd.py:94).  One wavefront per
+// row at a time, lanes over components (P^T rows are coalesced 8k-byte reads), 8 P^T
+// loads in flight; results are staged through LDS so that the per-component slabs
+// are written in contiguous runs.  Pt is (d, k).
+template <typename T, int M>
+__global__ __launch_bounds__(kBlock) void pcd_precompute_all_kernel(
+    int64_t n, int k, const int64_t* __restrict__ rptr, const int32_t* __restrict__ ridx,
+    const T* __restrict__ rval, const double* __restrict__ Pt, T* __restrict__ A_all) {
+    constexpr int R = 32;       // rows per tile
+    constexpr int RP = R + 1;   // padded row stride in LDS
+    extern __shared__ __attribute__((aligned(16))) unsigned char pre_lds[];
+    T* tile = reinterpret_cast<T*>(pre_lds);  // [(M-1)][64][RP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int64_t tile0 = (int64_t)blockIdx.x * R; tile0 < n; tile0 += (int64_t)gridDim.x * R) {
+        for (int s0 = 0; s0 < k; s0 += kWave) {
+            const int s = s0 + lane;
+            const bool sv = s < k;
+            for (int r = wave; r < R; r += kBlock / kWave) {
+                const int64_t i = tile0 + r;
+                if (i >= n) break;
+                double a[M];
+                a[0] = 1.0;
+#pragma unroll
+                for (int t = 1; t < M; ++t) a[t] = 0.0;
+                const int64_t b = rptr[i], e = rptr[i + 1];
+                for (int64_t c = b; c < e; c += kWave) {
+                    const int cnt = (int)((e - c < kWave) ? (e - c) : kWave);
+                    const int my_col = (lane < cnt) ? ridx[c + lane] : 0;
+                    const float my_xf = (lane < cnt) ? (float)rval[c + lane] : 0.f;
+                    const double my_xd = (lane < cnt) ? (double)rval[c + lane] : 0.0;
+                    for (int q = 0; q < cnt; q += 8) {
+                        double pv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int src = (q + u < cnt) ? (q + u) : q;
+                            const int col = __builtin_amdgcn_readlane(my_col, src);
+                            pv[u] = sv ? Pt[(size_t)col * k + s] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (q + u < cnt) {
+                                double x;
+                                if (sizeof(T) == 4)
+                                    x = (double)__int_as_float(__builtin_amdgcn_readlane(
+                                        __float_as_int(my_xf), q + u));
+                                else
+                                    x = readlane_d(my_xd, q + u);
+#pragma unroll
+                                for (int t = M - 1; t >= 1; --t) a[t] += a[t - 1] * pv[u] * x;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 1; t < M; ++t) tile[((t - 1) * kWave + lane) * RP + r] = (T)a[t];
+            }
+            __syncthreads();
+            const int per_s = R * (M - 1);
+            for (int idx = tid; idx < kWave * per_s; idx += kBlock) {
+                const int sl = idx / per_s, rem = idx - sl * per_s;
+                const int r = rem / (M - 1), t1 = rem - r * (M - 1);
+                const int64_t i = tile0 + r;
+                if (s0 + sl < k && i < n)
+                    A_all[((size_t)(s0 + sl) * n + i) * (M - 1) + t1] =
+                        tile[(t1 * kWave + sl) * RP + r];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------- pcd: regularizer cache
 
 // regularizer.compute_cache_pcd(P, degree, s): squaredl12.py:42-45 (|P[s]| and
@@ -249,12 +323,13 @@ __global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __
 template <typename T, int M>
 __global__ __launch_bounds__(kBlock) void pcd_grad_kernel(
     const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc,
-    const int32_t* __restrict__ cidx, const T* __restrict__ cval, const T* __restrict__ A,
-    const typename Vec2<T>::type* __restrict__ yy, const double* __restrict__ P, int d, int loss,
-    double* __restrict__ part, double* __restrict__ pold) {
+    const int32_t* __restrict__ cidx, const T* __restrict__ cval, const T* __restrict__ A_all,
+    size_t a_stride, const typename Vec2<T>::type* __restrict__ yy, const double* __restrict__ P,
+    int d, int loss, double* __restrict__ part, double* __restrict__ pold) {
     __shared__ double red[16];
     const int q = blockIdx.x;
     const ColDesc cd = desc[q];
+    const T* __restrict__ A = A_all + (size_t)ctl->s * a_stride;
     const double p = P[(size_t)ctl->s * d + cd.j];
     const int64_t b = cd.start, e = cd.start + cd.len;
     double g = 0.0, h = 0.0;
@@ -500,12 +575,13 @@ __device__ __forceinline__ void pcd_sync_entry(size_t i, double x, double p_old,
 template <typename T, int M>
 __global__ __launch_bounds__(kBlock) void pcd_sync_kernel(
     const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc,
-    const int32_t* __restrict__ cidx, const T* __restrict__ cval, T* __restrict__ A,
-    T* __restrict__ yy /* (yhat,y) pairs */, const double* __restrict__ delta,
+    const int32_t* __restrict__ cidx, const T* __restrict__ cval, T* __restrict__ A_all,
+    size_t a_stride, T* __restrict__ yy /* (yhat,y) pairs */, const double* __restrict__ delta,
     const double* __restrict__ pold) {
     const int q = blockIdx.x;
     const double upd = delta[q];
     if (upd == 0.0) return;
+    T* __restrict__ A = A_all + (size_t)ctl->s * a_stride;
     const double p_old = pold[q];
     const double lam = ctl->lam;
     const ColDesc cd = desc[q];
@@ -525,9 +601,10 @@ __global__ __launch_bounds__(kBlock) void pcd_chain_sync_kernel(
     double* __restrict__ P, int d, const double* __restrict__ part,
     const double* __restrict__ pold, int reg, const double* __restrict__ cache_in,
     double* __restrict__ cache_out, double mu, double beta, double gamma, double eta,
-    const int32_t* __restrict__ cidx, const T* __restrict__ cval, T* __restrict__ A,
-    T* __restrict__ yy, double* __restrict__ viol_col) {
+    const int32_t* __restrict__ cidx, const T* __restrict__ cval, T* __restrict__ A_all,
+    size_t a_stride, T* __restrict__ yy, double* __restrict__ viol_col) {
     __shared__ double sh[2];
+    T* __restrict__ A = A_all + (size_t)ctl->s * a_stride;
     constexpr int PF = 2;  // entries per thread fetched before the chain result is known
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -751,10 +828,11 @@ constexpr int kPrbThreads = 320;
 
 template <typename T, int M, int LOSS>
 __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
-    const Ctl* __restrict__ ctl, PrbArgs a, const T* __restrict__ eval, T* __restrict__ A,
-    T* __restrict__ yy, const double* __restrict__ pold_sched, double* __restrict__ P, int d,
-    int reg, const double* __restrict__ cache_in, double mu, double beta, double gamma,
-    double eta, double* __restrict__ viol_pos) {
+    const Ctl* __restrict__ ctl, PrbArgs a, const T* __restrict__ eval, T* __restrict__ A_all,
+    size_t a_stride, T* __restrict__ yy, const double* __restrict__ pold_sched,
+    double* __restrict__ P, int d, int reg, const double* __restrict__ cache_in, double mu,
+    double beta, double gamma, double eta, double* __restrict__ viol_pos) {
+    T* __restrict__ A = A_all + (size_t)ctl->s * a_stride;
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // sized to pin 1 WG / CU
     double* sh_delta = dyn_lds + 128;  // [64]
     double* sh_pold = dyn_lds + 192;   // [64]

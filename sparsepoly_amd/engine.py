@@ -236,5 +236,10 @@ class HipEngine(object):
             self._check(nv)
         return buf[:nv].reshape(-1, 8)
 
+    def get_option(self, key):
+        v = C.c_int()
+        self._check(self._lib.spfm_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
     def set_option(self, key, value):
         self._check(self._lib.spfm_set_option(self._h, key.encode(), int(value)))

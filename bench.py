@@ -168,9 +168,20 @@ def main():
         avg_us = 1e3 * g_ms / g_launch
         bytes_per_launch = bytes_per_nnz * g_nnz / g_launch
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
+        # measured HBM-side traffic per launch: PMC counters cannot be read from inside
+        # this process; the value comes from the committed rocprofv3 --pmc passes of the
+        # same command (profiles/r01_traffic.json, collected per MI355X_MICROARCH.md HBM)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if kname in tj and N_SAMPLES == 1_000_000 and N_FEATURES == 100_000 and world == 1:
+                traffic = round(1024.0 * (tj[kname]["fetch_kb_per_launch"]
+                                          + tj[kname]["write_kb_per_launch"]), 1)
+        except Exception:
+            traffic = None
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None, "avg_launch_us": round(avg_us, 3),
+                "traffic": traffic, "avg_launch_us": round(avg_us, 3),
                 "alg_bytes_per_launch": round(bytes_per_launch, 1),
                 "launches_timed": int(g_launch)}
         if persistent:

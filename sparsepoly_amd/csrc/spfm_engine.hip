@@ -165,7 +165,7 @@ struct spfm_engine {
     int64_t sched_version = 0;
 
     // work
-    DevBuf part, delta, pold, viol_col, scalar, ctl, comp_order, pred_tmp, partial;
+    DevBuf part, delta, pold, viol_col, scalar, ctl, comp_order, pred_tmp, partial, pb_scal;
     double* h_scalar = nullptr;  // pinned
 
     // graphs
@@ -537,11 +537,12 @@ struct spfm_engine {
 
     int alloc_work() {
         if (!configured || !have_schedule) return SPFM_OK;
-        const size_t per_part = (solver == SPFM_SOLVER_PBCD) ? (size_t)k + 1 : 2;
+        const size_t per_part = (solver == SPFM_SOLVER_PBCD) ? ((size_t)k + 1) * kPbW : 2;
         const size_t per_delta = (solver == SPFM_SOLVER_PBCD) ? (size_t)k : 1;
         HIPC(part.alloc(sizeof(double) * per_part * (size_t)max_batch_cols));
         HIPC(delta.alloc(sizeof(double) * per_delta * (size_t)max_batch_cols));
         HIPC(pold.alloc(sizeof(double) * per_delta * (size_t)max_batch_cols));
+        HIPC(pb_scal.alloc(sizeof(double) * 4 * (size_t)max_batch_cols));
         return SPFM_OK;
     }
 
@@ -1079,12 +1080,13 @@ struct spfm_engine {
         const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
         double* Po = Pt.as<double>() + (size_t)order_idx * k * d;  // (d,k)
         RegState rs = regstate();
-        constexpr int CW = (L == 64) ? C : 1;  // chain kernel: lanes = 64
+        constexpr int CW = (L == 64) ? C : 1;  // wave-per-column kernels: lanes = 64
         if (n > 0)
             hipLaunchKernelGGL((pbcd_precompute_kernel<T, M>), dim3(cdiv(n * k, kBlock)),
                                dim3(kBlock), 0, stream, n, k, rptr.as<int64_t>(),
                                ridx.as<int32_t>(), rval.as<T>(), Po, A.as<T>());
-        if (reg == SPFM_REG_SQUAREDL21 || reg == SPFM_REG_OMEGACS) {
+        const bool chained = (reg == SPFM_REG_SQUAREDL21 || reg == SPFM_REG_OMEGACS);
+        if (chained) {
             hipLaunchKernelGGL(pbcd_norms_kernel, dim3(cdiv((int64_t)d * 64, kBlock)),
                                dim3(kBlock), 0, stream, d, k, Po, rs.norms);
             hipLaunchKernelGGL((pbcd_compute_cache_kernel<M>), dim3(1), dim3(kBlock), 0, stream, d,
@@ -1095,25 +1097,26 @@ struct spfm_engine {
         for (int b = 0; b < nb; ++b) {
             const int c0 = batch_ptr[b], nc = batch_ptr[b + 1] - c0;
             if (nc == 0) continue;
-            const int32_t* cols = d_order.as<int32_t>() + c0;
+            const ColDesc* desc = d_desc.as<ColDesc>() + c0;
             const int64_t bn = prof_on ? batch_nnz(b) : 0;
             prof_begin(2, bn);
-            hipLaunchKernelGGL((pbcd_grad_kernel<T, M, L, C>), dim3(nc), dim3(kBlock), shm, stream,
-                               cols, cptr.as<int64_t>(), cidx.as<int32_t>(), cval.as<T>(),
-                               A.as<T>(), yy.as<typename Vec2<T>::type>(), Po, k, loss,
-                               part.as<double>());
+            hipLaunchKernelGGL((pbcd_grad_kernel<T, M, L, C>), dim3(nc * kPbW), dim3(kBlock), shm,
+                               stream, desc, cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
+                               yy.as<typename Vec2<T>::type>(), Po, k, loss, part.as<double>());
             prof_end(2);
-            int rc = allreduce(part.as<double>(), (size_t)nc * (k + 1));
+            int rc = allreduce(part.as<double>(), (size_t)nc * kPbW * (k + 1));
             if (rc) return rc;
-            hipLaunchKernelGGL((pbcd_chain_kernel<M, CW>), dim3(1), dim3(kWave), 0, stream, cols,
-                               nc, Po, k, d, part.as<double>(), lams.as<double>(), reg, rs,
-                               top_degree + 1, mu, beta, gamma, eta, delta.as<double>(),
-                               pold.as<double>(), viol_col.as<double>());
+            hipLaunchKernelGGL((pbcd_prep_kernel<CW>), dim3(nc), dim3(kWave), 0, stream, desc, Po,
+                               k, part.as<double>(), lams.as<double>(), reg, mu, beta, gamma, eta,
+                               delta.as<double>(), pold.as<double>(), pb_scal.as<double>());
+            if (chained)
+                hipLaunchKernelGGL((pbcd_chain_kernel<M>), dim3(1), dim3(kWave), 0, stream, desc,
+                                   nc, d, reg, rs, top_degree + 1, pb_scal.as<double>());
             prof_begin(3, bn);
-            hipLaunchKernelGGL((pbcd_sync_kernel<T, M, L, C>), dim3(nc), dim3(kBlock), 0, stream,
-                               cols, cptr.as<int64_t>(), cidx.as<int32_t>(), cval.as<T>(),
-                               A.as<T>(), yy.as<T>(), lams.as<double>(), k, delta.as<double>(),
-                               pold.as<double>());
+            hipLaunchKernelGGL((pbcd_sync_kernel<T, M, L, C>), dim3(nc * kPbW), dim3(kBlock), 0,
+                               stream, desc, cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
+                               yy.as<T>(), lams.as<double>(), k, Po, delta.as<double>(),
+                               pold.as<double>(), pb_scal.as<double>(), viol_col.as<double>());
             prof_end(3);
         }
         HIPC(hipGetLastError());

@@ -1254,47 +1254,86 @@ __global__ __launch_bounds__(kBlock) void pbcd_compute_cache_kernel(int d, int r
     }
 }
 
-// First pass of pbcd._update (optimizer/pbcd.py:56-67): part[q*(k+1) + s] =
-// sum_i dloss_i * dA[i, M-1, s]; part[q*(k+1) + k] = sum_s sum_i dA[i, M-1, s]^2.
+// One pbcd step = four launches:
+//   pbcd_grad_kernel   kPbW workgroups per column: partial sums of the first pass of
+//                      pbcd._update (optimizer/pbcd.py:56-67)
+//   pbcd_prep_kernel   one wave per column, lanes over components: step size, gradient
+//                      step (pbcd.py:68-78) and everything of prox_bcd that does not depend
+//                      on the regularizer's running cache (block norm, L1 / L21 prox)
+//   pbcd_chain_kernel  one wave, lanes over columns: the scalar cache recurrences of
+//                      SquaredL21 / OmegaCS in batch order (squaredl21.py:40-55,
+//                      omegacs.py:68-106) -> one shrink factor per column
+//   pbcd_sync_kernel   kPbW workgroups per column: p_j = f * p_j', P[j] write-back and
+//                      "synchronize predictions and caches" (pbcd.py:135-144)
+// Rounding note: update_cache_pbcd's l2 = ||P[j]|| after the prox is taken as f * ||p_j'||
+// (equal up to ~2 ulp) so that the chain needs no vector work.
+constexpr int kPbW = 4;  // workgroups per column in the gather / scatter kernels
+
 template <typename T, int M, int L, int C>
 __global__ __launch_bounds__(kBlock) void pbcd_grad_kernel(
-    const int32_t* __restrict__ cols, const int64_t* __restrict__ cptr,
-    const int32_t* __restrict__ cidx, const T* __restrict__ cval, const T* __restrict__ A,
+    const ColDesc* __restrict__ desc, const int32_t* __restrict__ cidx,
+    const T* __restrict__ cval, const T* __restrict__ A,
     const typename Vec2<T>::type* __restrict__ yy, const double* __restrict__ P /* (d,k) */,
-    int k, int loss, double* __restrict__ part) {
+    int k, int loss, double* __restrict__ part /* [ncols][kPbW][k+1] */) {
     constexpr int G = kBlock / L;  // entry groups per workgroup
+    constexpr int U = 2;           // entries per group in flight
     extern __shared__ double shm[];  // G * k + 16
     double* red = shm + (size_t)G * k;
-    const int q = blockIdx.x;
-    const int j = cols[q];
+    const int q = blockIdx.x / kPbW, w = blockIdx.x % kPbW;
+    const ColDesc cd = desc[q];
     const int grp = threadIdx.x / L, lane = threadIdx.x % L;
     double p[C], grad[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int s = lane + c * L;
-        p[c] = (s < k) ? P[(size_t)j * k + s] : 0.0;
+        p[c] = (s < k) ? P[(size_t)cd.j * k + s] : 0.0;
         grad[c] = 0.0;
     }
     double hs = 0.0, dummy = 0.0;
-    const int64_t b = cptr[j], e = cptr[j + 1];
+    const int64_t e = cd.start + cd.len;
     const size_t slab = (size_t)(M - 1) * k;
-    for (int64_t ii = b + grp; ii < e; ii += G) {
-        const int i = cidx[ii];
-        const double x = (double)cval[ii];
-        const typename Vec2<T>::type yv = yy[i];
-        const double dl = dloss_dev(loss, (double)yv.x, (double)yv.y);
+    for (int64_t ii0 = cd.start + (int64_t)w * G + grp; ii0 < e; ii0 += (int64_t)U * G * kPbW) {
+        int iu[U];
+        double xu[U], dlu[U];
+        double au[U][C][M > 1 ? M - 1 : 1];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int s = lane + c * L;
-            if (s < k) {
-                double dprev = x;
+        for (int u = 0; u < U; ++u) {  // all loads of U entries in flight together
+            const int64_t ii = ii0 + (int64_t)u * G * kPbW;
+            const bool v = ii < e;
+            iu[u] = v ? cidx[ii] : -1;
+            xu[u] = v ? (double)cval[ii] : 0.0;
+        }
 #pragma unroll
-                for (int t = 1; t < M; ++t) {
-                    const double a = (double)A[(size_t)i * slab + (size_t)(t - 1) * k + s];
-                    dprev = x * (a - p[c] * dprev);
+        for (int u = 0; u < U; ++u) {
+            if (iu[u] >= 0) {
+                const typename Vec2<T>::type yv = yy[iu[u]];
+                dlu[u] = dloss_dev(loss, (double)yv.x, (double)yv.y);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int s = lane + c * L;
+#pragma unroll
+                    for (int t = 1; t < M; ++t)
+                        au[u][c][t - 1] =
+                            (s < k) ? (double)A[(size_t)iu[u] * slab + (size_t)(t - 1) * k + s]
+                                    : 0.0;
                 }
-                grad[c] += dl * dprev;
-                hs += dprev * dprev;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (iu[u] >= 0) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int s = lane + c * L;
+                    if (s < k) {
+                        double dprev = xu[u];
+#pragma unroll
+                        for (int t = 1; t < M; ++t)
+                            dprev = xu[u] * (au[u][c][t - 1] - p[c] * dprev);
+                        grad[c] += dlu[u] * dprev;
+                        hs += dprev * dprev;
+                    }
+                }
             }
         }
     }
@@ -1304,90 +1343,121 @@ __global__ __launch_bounds__(kBlock) void pbcd_grad_kernel(
         if (s < k) shm[(size_t)grp * k + s] = grad[c];
     }
     block_sum2(hs, dummy, red);  // contains the __syncthreads that publishes shm
+    double* out = part + ((size_t)q * kPbW + w) * (k + 1);
     for (int s = threadIdx.x; s < k; s += kBlock) {
         double acc = 0.0;
         for (int g2 = 0; g2 < G; ++g2) acc += shm[(size_t)g2 * k + s];
-        part[(size_t)q * (k + 1) + s] = acc;
+        out[s] = acc;
     }
-    if (threadIdx.x == 0) part[(size_t)q * (k + 1) + k] = hs;
+    if (threadIdx.x == 0) out[k] = hs;
 }
 
-// Second half of pbcd._update (optimizer/pbcd.py:68-79), P[j] write-back,
-// sum_viol (pbcd.py:146) and regularizer.update_cache_pbcd (pbcd.py:145) for all
-// columns of a batch in batch order; one wavefront, lanes over components.
-// prox_bcd: l1.py:44-45, l21.py:33-38, squaredl21.py:45-55, omegacs.py:78-106;
-// update_cache_pbcd: squaredl21.py:40-43, omegacs.py:68-76.
-template <int M, int C>
-__global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
-    const int32_t* __restrict__ cols, int ncols, double* __restrict__ P /* (d,k) */, int k, int d,
-    const double* __restrict__ part, const double* __restrict__ lams, int reg, RegState rs,
-    int top_ncache, double mu, double beta, double gamma, double eta, double* __restrict__ delta,
-    double* __restrict__ pold, double* __restrict__ viol_col) {
-    const int lane = threadIdx.x;
-    double lam[C];
+// per column: scal[q] = {l2 of p_j', st0 = eta*gamma/inv, f (L1/L21: final), unused}
+template <int C>
+__global__ __launch_bounds__(kWave) void pbcd_prep_kernel(
+    const ColDesc* __restrict__ desc, const double* __restrict__ P /* (d,k) */, int k,
+    const double* __restrict__ part, const double* __restrict__ lams, int reg, double mu,
+    double beta, double gamma, double eta, double* __restrict__ pin /* [ncols][k] p_j' */,
+    double* __restrict__ pold /* [ncols][k] */, double* __restrict__ scal /* [ncols][4] */) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int j = desc[q].j;
+    const double* pq = part + (size_t)q * kPbW * (k + 1);
+    double inv = 0.0;
+#pragma unroll
+    for (int w = 0; w < kPbW; ++w) inv += pq[(size_t)w * (k + 1) + k];
+    inv *= mu;
+    inv += beta;
+    const double st0 = eta * gamma / inv;
+    double p[C];
+    double sq = 0.0;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int s = lane + c * kWave;
-        lam[c] = (s < k) ? lams[s] : 0.0;
+        p[c] = 0.0;
+        if (s < k) {
+            const double po = P[(size_t)j * k + s];
+            double g = 0.0;
+#pragma unroll
+            for (int w = 0; w < kPbW; ++w) g += pq[(size_t)w * (k + 1) + s];
+            g *= lams[s];
+            g += beta * po;
+            g /= inv;
+            double v = po - eta * g;
+            if (reg == REG_L1) {  // l1.py:44-45, element-wise
+                const double sg = (v > 0) ? 1.0 : ((v < 0) ? -1.0 : 0.0);
+                const double m = fabs(v) - st0;
+                v = sg * (m > 0.0 ? m : 0.0);
+            } else if (reg == REG_SQL21) {
+                v /= 1 + 2 * st0;  // squaredl21.py:46
+            }
+            p[c] = v;
+            pold[(size_t)q * k + s] = po;
+            pin[(size_t)q * k + s] = v;
+            sq += v * v;
+        }
     }
-    // regularizer scalars, uniform across lanes
+    const double l2 = sqrt(wave_sum(sq));
+    if (lane == 0) {
+        double f = 1.0;
+        if (reg == REG_L21) f = (l2 > st0) ? (1.0 - st0 / l2) : 0.0;  // l21.py:33-38
+        scal[4 * q + 0] = l2;
+        scal[4 * q + 1] = st0;
+        scal[4 * q + 2] = f;
+        scal[4 * q + 3] = 0.0;
+    }
+}
+
+// Scalar chain for SquaredL21 / OmegaCS: lanes = columns (64 at a time), wave-uniform
+// serial loop; writes the shrink factor f into scal[q][2] and the new block norm into
+// norms[j].  Fallback branches ("numerical error": squaredl21.py:48-49,
+// omegacs.py:75-76,90-96) recompute from all d norms with the whole wave.
+template <int M>
+__global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
+    const ColDesc* __restrict__ desc, int ncols, int d, int reg, RegState rs, int top_ncache,
+    double* __restrict__ scal) {
+    const int lane = threadIdx.x;
     double cache[kMaxDegree + 2], dcache[kMaxDegree + 2];
 #pragma unroll
     for (int t = 0; t < kMaxDegree + 2; ++t) {
         cache[t] = (t < top_ncache) ? rs.cache[t] : 0.0;
         dcache[t] = (t < top_ncache) ? rs.dcache[t] : 0.0;
     }
-    for (int q = 0; q < ncols; ++q) {
-        const int j = cols[q];
-        double p[C], po[C];
-        double inv = part[(size_t)q * (k + 1) + k];
-        inv *= mu;
-        inv += beta;
-        const double st0 = eta * gamma / inv;
-        double sq = 0.0;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int s = lane + c * kWave;
-            if (s < k) {
-                po[c] = P[(size_t)j * k + s];
-                double g = part[(size_t)q * (k + 1) + s];
-                g *= lam[c];
-                g += beta * po[c];
-                g /= inv;
-                p[c] = po[c] - eta * g;
-            } else {
-                po[c] = 0.0;
-                p[c] = 0.0;
-            }
+    for (int base = 0; base < ncols; base += kWave) {
+        const int q = base + lane;
+        const bool valid = q < ncols;
+        const int cnt = min(kWave, ncols - base);
+        int j = 0;
+        double l2 = 0.0, st0 = 0.0, njl = 0.0;
+        if (valid) {
+            j = desc[q].j;
+            l2 = scal[4 * q + 0];
+            st0 = scal[4 * q + 1];
+            njl = rs.norms[j];
         }
-        if (reg == REG_L1) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const double v = p[c];
-                const double sg = (v > 0) ? 1.0 : ((v < 0) ? -1.0 : 0.0);
-                const double m = fabs(v) - st0;
-                p[c] = sg * (m > 0.0 ? m : 0.0);
-            }
-        } else {
-            double strength = st0;
+        double f_mine = 0.0, l2n_mine = 0.0;
+// rare fallback paths re-read all d norms from memory: first store the norms of the
+// columns of this chunk that were already processed (they live in registers)
+#define PBCD_FLUSH_NORMS                                            \
+    {                                                               \
+        if (valid && lane < i) rs.norms[j] = l2n_mine;              \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      \
+    }
+        for (int i = 0; i < cnt; ++i) {
+            const double l2i = readlane_d(l2, i), si = readlane_d(st0, i);
+            double nj = readlane_d(njl, i);
+            const int ji = __builtin_amdgcn_readlane(j, i);
+            double strength;
             if (reg == REG_SQL21) {
-                const double den = 1 + 2 * st0;
-#pragma unroll
-                for (int c = 0; c < C; ++c) p[c] /= den;
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) sq += p[c] * p[c];
-            const double l2 = sqrt(wave_sum(sq));
-            const double nj = (reg == REG_L21) ? 0.0 : rs.norms[j];
-            if (reg == REG_SQL21) {
-                if (cache[0] < nj) {  // squaredl21.py:48-49 "to avoid numerical error"
+                if (cache[0] < nj) {  // squaredl21.py:48-49
+                    PBCD_FLUSH_NORMS
                     double a = 0.0;
                     for (int jj = lane; jj < d; jj += kWave) a += rs.norms[jj];
                     cache[0] = wave_sum(a);
                 }
                 const double dc = cache[0] - nj;
-                strength = 2 * dc * st0 / (1.0 + 2 * st0);
-            } else if (reg == REG_OMEGACS) {
+                strength = 2 * dc * si / (1.0 + 2 * si);
+            } else {  // REG_OMEGACS
 #pragma unroll
                 for (int deg = 2; deg <= M; ++deg) {
                     dcache[deg] = cache[deg - 1];
@@ -1397,16 +1467,13 @@ __global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
 #pragma unroll
                 for (int t = 1; t < kMaxDegree + 2; ++t)
                     if (t < top_ncache && dcache[t] < mn) mn = dcache[t];
-                if (mn < 0) {  // omegacs.py:90-96 fallback
-                    if (lane == 0) rs.norms[j] = 0.0;
-                    __threadfence_block();
-                    // __recompute_cache_bcd(degree - 1): serial in the reference; here
-                    // lane-strided DP + product across lanes via shuffles
+                if (mn < 0) {  // omegacs.py:90-96
+                    PBCD_FLUSH_NORMS
                     double cc[kMaxDegree + 2];
 #pragma unroll
                     for (int t = 0; t < kMaxDegree + 2; ++t) cc[t] = (t == 0) ? 1.0 : 0.0;
                     for (int jj = lane; jj < d; jj += kWave) {
-                        const double v = (jj == j) ? 0.0 : rs.norms[jj];
+                        const double v = (jj == ji) ? 0.0 : rs.norms[jj];
 #pragma unroll
                         for (int t = M - 1; t >= 1; --t) cc[t] += cc[t - 1] * v;
                     }
@@ -1424,68 +1491,39 @@ __global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
 #pragma unroll
                         for (int t = 0; t < M; ++t) cc[t] = o[t];
                     }
-                    // cache[1:] = 0 then DP up to degree-1 (omegacs.py:54-59)
 #pragma unroll
-                    for (int t = 0; t < kMaxDegree + 2; ++t)
-                        cache[t] = (t < M) ? cc[t] : 0.0;
+                    for (int t = 0; t < kMaxDegree + 2; ++t) cache[t] = (t < M) ? cc[t] : 0.0;
                     dcache[0] = 0.0;
                     dcache[1] = 1.0;
 #pragma unroll
                     for (int deg = 2; deg <= M; ++deg) dcache[deg] = cache[M - 1];
+                    nj = 0.0;  // self._norms[j] = 0.0
                 }
-                strength = st0 * dcache[M];
+                strength = si * dcache[M];
             }
-            if (l2 > strength) {
-                const double f = 1.0 - strength / l2;
-#pragma unroll
-                for (int c = 0; c < C; ++c) p[c] *= f;
-            } else {
-#pragma unroll
-                for (int c = 0; c < C; ++c) p[c] = 0.0;
-            }
-        }
-        // write back, violation, cache update
-        double va = 0.0, sq2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int s = lane + c * kWave;
-            if (s < k) {
-                const double dl = po[c] - p[c];
-                P[(size_t)j * k + s] = p[c];
-                delta[(size_t)q * k + s] = dl;
-                pold[(size_t)q * k + s] = po[c];
-                va += fabs(dl);
-                sq2 += p[c] * p[c];
-            }
-        }
-        va = wave_sum(va);
-        if (lane == 0) viol_col[j] += va;
-        if (reg == REG_SQL21 || reg == REG_OMEGACS) {
-            const double l2n = sqrt(wave_sum(sq2));
-            const double nj = rs.norms[j];
-            if (reg == REG_SQL21) {
+            const double f = (l2i > strength) ? (1.0 - strength / l2i) : 0.0;
+            const double l2n = f * l2i;
+            if (reg == REG_SQL21) {  // squaredl21.py:40-43
                 cache[0] -= nj;
                 cache[0] += l2n;
-            } else {
+            } else {  // omegacs.py:68-76
 #pragma unroll
                 for (int deg = 1; deg <= M; ++deg) {
                     cache[deg] += dcache[deg] * l2n;
                     cache[deg] -= dcache[deg] * nj;
                 }
-            }
-            if (lane == 0) rs.norms[j] = l2n;
-            __threadfence_block();
-            if (reg == REG_OMEGACS) {
                 double mn = cache[0];
 #pragma unroll
                 for (int t = 1; t < kMaxDegree + 2; ++t)
                     if (t < top_ncache && cache[t] < mn) mn = cache[t];
-                if (mn < 0) {  // omegacs.py:75-76: __recompute_cache_bcd(degree)
+                if (mn < 0) {  // __recompute_cache_bcd(degree)
+                    PBCD_FLUSH_NORMS
                     double cc[kMaxDegree + 2];
 #pragma unroll
                     for (int t = 0; t < kMaxDegree + 2; ++t) cc[t] = (t == 0) ? 1.0 : 0.0;
                     for (int jj = lane; jj < d; jj += kWave) {
-                        const double v = (jj == j) ? l2n : rs.norms[jj];
+                        double v = rs.norms[jj];
+                        if (jj == ji) v = l2n;
 #pragma unroll
                         for (int t = M; t >= 1; --t) cc[t] += cc[t - 1] * v;
                     }
@@ -1504,13 +1542,24 @@ __global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
                         for (int t = 0; t <= M; ++t) cc[t] = o[t];
                     }
 #pragma unroll
-                    for (int t = 0; t < kMaxDegree + 2; ++t)
-                        cache[t] = (t <= M) ? cc[t] : 0.0;
+                    for (int t = 0; t < kMaxDegree + 2; ++t) cache[t] = (t <= M) ? cc[t] : 0.0;
                 }
             }
+            if (lane == i) {
+                f_mine = f;
+                l2n_mine = l2n;
+            }
         }
+        if (valid) {
+            scal[4 * q + 2] = f_mine;
+            rs.norms[j] = l2n_mine;
+        }
+        // the next chunk (and its fallback paths) read rs.norms of this chunk's columns
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    if (lane == 0 && (reg == REG_SQL21 || reg == REG_OMEGACS)) {
+#undef PBCD_FLUSH_NORMS
+    if (lane == 0) {
 #pragma unroll
         for (int t = 0; t < kMaxDegree + 2; ++t)
             if (t < top_ncache) {
@@ -1520,31 +1569,49 @@ __global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
     }
 }
 
+// p_j = f * p_j' (prox_bcd's shrink), P[j] write-back, sum_viol (pbcd.py:146) and
 // "synchronize predictions and caches" (optimizer/pbcd.py:135-144)
 template <typename T, int M, int L, int C>
 __global__ __launch_bounds__(kBlock) void pbcd_sync_kernel(
-    const int32_t* __restrict__ cols, const int64_t* __restrict__ cptr,
-    const int32_t* __restrict__ cidx, const T* __restrict__ cval, T* __restrict__ A,
-    T* __restrict__ yy, const double* __restrict__ lams, int k,
-    const double* __restrict__ delta, const double* __restrict__ pold) {
+    const ColDesc* __restrict__ desc, const int32_t* __restrict__ cidx,
+    const T* __restrict__ cval, T* __restrict__ A, T* __restrict__ yy,
+    const double* __restrict__ lams, int k, double* __restrict__ P /* (d,k) */,
+    const double* __restrict__ pin, const double* __restrict__ pold,
+    const double* __restrict__ scal, double* __restrict__ viol_col) {
     constexpr int G = kBlock / L;
-    const int q = blockIdx.x;
-    const int j = cols[q];
+    const int q = blockIdx.x / kPbW, w = blockIdx.x % kPbW;
+    const ColDesc cd = desc[q];
     const int grp = threadIdx.x / L, lane = threadIdx.x % L;
+    const double f = scal[4 * q + 2];
     double po[C], up[C], lu[C];
     bool any = false;
+    double va = 0.0;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int s = lane + c * L;
-        po[c] = (s < k) ? pold[(size_t)q * k + s] : 0.0;
-        up[c] = (s < k) ? delta[(size_t)q * k + s] : 0.0;
-        lu[c] = (s < k) ? lams[s] * up[c] : 0.0;
-        any |= (up[c] != 0.0);
+        po[c] = 0.0;
+        up[c] = 0.0;
+        lu[c] = 0.0;
+        if (s < k) {
+            po[c] = pold[(size_t)q * k + s];
+            const double pn = pin[(size_t)q * k + s] * f;
+            up[c] = po[c] - pn;
+            lu[c] = lams[s] * up[c];
+            any |= (up[c] != 0.0);
+            if (w == 0 && grp == 0) {
+                P[(size_t)cd.j * k + s] = pn;
+                va += fabs(up[c]);
+            }
+        }
+    }
+    if (w == 0 && grp == 0) {
+        va = group_sum(va, L);
+        if (lane == 0) viol_col[cd.j] += va;
     }
     if (!__syncthreads_or(any ? 1 : 0)) return;  // block did not move: exact no-op
-    const int64_t b = cptr[j], e = cptr[j + 1];
+    const int64_t e = cd.start + cd.len;
     const size_t slab = (size_t)(M - 1) * k;
-    for (int64_t ii = b + grp; ii < e; ii += G) {
+    for (int64_t ii = cd.start + (int64_t)w * G + grp; ii < e; ii += (int64_t)G * kPbW) {
         const size_t i = (size_t)cidx[ii];
         const double x = (double)cval[ii];
         double acc = 0.0;

@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(kBlock) void pbcd_compute_cache_kernel(int d, int r
 //                      "synchronize predictions and caches" (pbcd.py:135-144)
 // Rounding note: update_cache_pbcd's l2 = ||P[j]|| after the prox is taken as f * ||p_j'||
 // (equal up to ~2 ulp) so that the chain needs no vector work.
-constexpr int kPbW = 4;  // workgroups per column in the gather / scatter kernels
+constexpr int kPbW = 8;  // workgroups per column in the gather / scatter kernels
 
 template <typename T, int M, int L, int C>
 __global__ __launch_bounds__(kBlock) void pbcd_grad_kernel(
@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(kBlock) void pbcd_grad_kernel(
     const typename Vec2<T>::type* __restrict__ yy, const double* __restrict__ P /* (d,k) */,
     int k, int loss, double* __restrict__ part /* [ncols][kPbW][k+1] */) {
     constexpr int G = kBlock / L;  // entry groups per workgroup
-    constexpr int U = 2;           // entries per group in flight
+    constexpr int U = 4;           // entries per group in flight
     extern __shared__ double shm[];  // G * k + 16
     double* red = shm + (size_t)G * k;
     const int q = blockIdx.x / kPbW, w = blockIdx.x % kPbW;
@@ -1417,10 +1417,14 @@ __global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
     double* __restrict__ scal) {
     const int lane = threadIdx.x;
     double cache[kMaxDegree + 2], dcache[kMaxDegree + 2];
+    {   // one vector load each, then broadcast (the state is wave-uniform)
+        const double cv = (lane < top_ncache) ? rs.cache[lane] : 0.0;
+        const double dv = (lane < top_ncache) ? rs.dcache[lane] : 0.0;
 #pragma unroll
-    for (int t = 0; t < kMaxDegree + 2; ++t) {
-        cache[t] = (t < top_ncache) ? rs.cache[t] : 0.0;
-        dcache[t] = (t < top_ncache) ? rs.dcache[t] : 0.0;
+        for (int t = 0; t < kMaxDegree + 2; ++t) {
+            cache[t] = readlane_d(cv, t);
+            dcache[t] = readlane_d(dv, t);
+        }
     }
     for (int base = 0; base < ncols; base += kWave) {
         const int q = base + lane;
@@ -1433,6 +1437,60 @@ __global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
             l2 = scal[4 * q + 0];
             st0 = scal[4 * q + 1];
             njl = rs.norms[j];
+        }
+        if (M == 2) {
+            // Degree 2: the cache is one scalar c (= sum of block norms) and column i maps it
+            // through c' = (c - n_i) + max(l2_i - t_i (c - n_i), 0), t_i = st0 (omegacs) or
+            // 2 st0 / (1 + 2 st0) (squaredl21): the same piecewise-affine recurrence as
+            // pcd's squaredl12, solved by the speculative affine scan.  If any column would
+            // take one of the reference's "numerical error" branches the chunk is redone by
+            // the serial loop below, which restates them.
+            const double c0 = (reg == REG_SQL21) ? cache[0] : cache[1];
+            const double tt = (reg == REG_SQL21) ? (2 * st0 / (1.0 + 2 * st0)) : st0;
+            bool nz = valid && (l2 - tt * (c0 - njl)) > 0;
+            double cb = c0, m = 0.0, al = 1.0, be = 0.0;
+            for (int round = 0; round <= kWave; ++round) {
+                al = valid ? (nz ? (1.0 - tt) : 1.0) : 1.0;
+                be = valid ? (nz ? (l2 - (1.0 - tt) * njl) : -njl) : 0.0;
+                affine_scan_inclusive(al, be, lane);
+                cb = affine_before(al, be, c0, lane);
+                m = l2 - tt * (cb - njl);
+                const bool nz2 = m > 0;
+                const unsigned long long bad = __ballot(valid && (nz2 != nz));
+                nz = nz2;
+                if (bad == 0ull) break;
+            }
+            const double l2n = (valid && nz) ? m : 0.0;
+            const double dc2 = cb - njl;  // dcache[2] (omegacs) / dcache (squaredl21)
+            // cache[2] += dcache[2] * l2n - dcache[2] * n_j per column (omegacs.py:71-73)
+            double c2term = (valid && reg == REG_OMEGACS) ? (dc2 * l2n - dc2 * njl) : 0.0;
+            double c2pre = c2term;  // inclusive prefix sum
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const double v = __shfl_up(c2pre, o, kWave);
+                if (lane >= o) c2pre += v;
+            }
+            const double c_after = al * c0 + be;  // cache after this column
+            const bool trouble = valid && ((dc2 < 0) || (c_after < 0) ||
+                                           (reg == REG_OMEGACS && cache[2] + c2pre < 0));
+            if (__ballot(trouble) == 0ull) {
+                const double f = (valid && nz) ? (1.0 - (tt * dc2) / l2) : 0.0;
+                if (valid) {
+                    scal[4 * q + 2] = f;
+                    rs.norms[j] = l2n;  // = l2 - strength, the value the scan propagated
+                }
+                const double c_end = readlane_d(c_after, cnt - 1);
+                if (reg == REG_SQL21) {
+                    cache[0] = c_end;
+                } else {
+                    cache[1] = c_end;
+                    cache[2] += readlane_d(c2pre, cnt - 1);
+                    dcache[2] = readlane_d(dc2, cnt - 1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                continue;
+            }
         }
         double f_mine = 0.0, l2n_mine = 0.0;
 // rare fallback paths re-read all d norms from memory: first store the norms of the
@@ -1611,28 +1669,56 @@ __global__ __launch_bounds__(kBlock) void pbcd_sync_kernel(
     if (!__syncthreads_or(any ? 1 : 0)) return;  // block did not move: exact no-op
     const int64_t e = cd.start + cd.len;
     const size_t slab = (size_t)(M - 1) * k;
-    for (int64_t ii = cd.start + (int64_t)w * G + grp; ii < e; ii += (int64_t)G * kPbW) {
-        const size_t i = (size_t)cidx[ii];
-        const double x = (double)cval[ii];
-        double acc = 0.0;
+    constexpr int U = 4;  // entries per group in flight
+    for (int64_t ii0 = cd.start + (int64_t)w * G + grp; ii0 < e; ii0 += (int64_t)U * G * kPbW) {
+        int iu[U];
+        double xu[U];
+        double au[U][C][M > 1 ? M - 1 : 1];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int s = lane + c * L;
-            if (s < k) {
-                double dprev = x;
+        for (int u = 0; u < U; ++u) {
+            const int64_t ii = ii0 + (int64_t)u * G * kPbW;
+            const bool v = ii < e;
+            iu[u] = v ? cidx[ii] : -1;
+            xu[u] = v ? (double)cval[ii] : 0.0;
+        }
 #pragma unroll
-                for (int t = 1; t < M; ++t) {
-                    const size_t at = i * slab + (size_t)(t - 1) * k + s;
-                    const double a = (double)A[at];
-                    const double dcur = x * (a - po[c] * dprev);
-                    A[at] = (T)(a - up[c] * dprev);
-                    dprev = dcur;
+        for (int u = 0; u < U; ++u) {
+            if (iu[u] >= 0) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int s = lane + c * L;
+#pragma unroll
+                    for (int t = 1; t < M; ++t)
+                        au[u][c][t - 1] =
+                            (s < k) ? (double)A[(size_t)iu[u] * slab + (size_t)(t - 1) * k + s]
+                                    : 0.0;
                 }
-                acc += lu[c] * dprev;
             }
         }
-        acc = group_sum(acc, L);
-        if (lane == 0) yy[2 * i] = (T)((double)yy[2 * i] - acc);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (iu[u] >= 0) {
+                const size_t i = (size_t)iu[u];
+                double acc = 0.0;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int s = lane + c * L;
+                    if (s < k) {
+                        double dprev = xu[u];
+#pragma unroll
+                        for (int t = 1; t < M; ++t) {
+                            const double a = au[u][c][t - 1];
+                            const double dcur = xu[u] * (a - po[c] * dprev);
+                            A[i * slab + (size_t)(t - 1) * k + s] = (T)(a - up[c] * dprev);
+                            dprev = dcur;
+                        }
+                        acc += lu[c] * dprev;
+                    }
+                }
+                acc = group_sum(acc, L);
+                if (lane == 0) yy[2 * i] = (T)((double)yy[2 * i] - acc);
+            }
+        }
     }
 }
 

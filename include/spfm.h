@@ -182,7 +182,8 @@ int spfm_set_option(spfm_handle h, const char* key, int value);
 int spfm_get_option(spfm_handle h, const char* key, int* value);
 
 /* diagnostic ("prb_stamps" option): accumulated shader cycles per phase of the last
- * persistent pass, 8 values per workgroup; returns the number of values written. */
+ * persistent pass, 16 values per workgroup (8 control-wave, 8 worker-wave phases);
+ * returns the number of values written. */
 int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap);
 
 #ifdef __cplusplus

@@ -780,8 +780,8 @@ struct spfm_engine {
             const int32_t* cols = d_order.as<int32_t>() + c0;
             prof_begin(4, prof_on ? batch_nnz(b) : 0);
             if (!comm) {
-                hipLaunchKernelGGL((lin_fused_kernel<T>), dim3(nc), dim3(kBlock), 0, stream, cols,
-                                   cptr.as<int64_t>(), cidx.as<int32_t>(), cval.as<T>(),
+                hipLaunchKernelGGL((lin_fused_kernel<T>), dim3(nc), dim3(kBlock), 0, stream,
+                                   d_desc.as<ColDesc>() + c0, cidx.as<int32_t>(), cval.as<T>(),
                                    yy.as<T>(), loss, w.as<double>(), col_norm.as<double>(), alpha,
                                    mu, viol_col.as<double>());
             } else {
@@ -889,7 +889,7 @@ struct spfm_engine {
         HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
         HIPC(prow_old.alloc(sizeof(double) * (size_t)d));
         HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
-        HIPC(prb_stamps.alloc(sizeof(long long) * 8 * (size_t)prb_G));
+        HIPC(prb_stamps.alloc(sizeof(long long) * 16 * (size_t)prb_G));
         HIPC(hipMemsetAsync(prb_stamps.p, 0, prb_stamps.bytes, stream));
         HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
         HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));
@@ -1450,7 +1450,7 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
 int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap) {
     GUARD(h);
     if (!h->prb_ready || !out) return SPFM_ERR_INVALID;
-    const int nval = 8 * h->prb_G;
+    const int nval = 16 * h->prb_G;
     if (cap < nval) return SPFM_ERR_INVALID;
     if (hipMemcpy(out, h->prb_stamps.p, sizeof(long long) * (size_t)nval, hipMemcpyDeviceToHost) !=
         hipSuccess)

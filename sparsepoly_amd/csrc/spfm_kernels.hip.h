@@ -691,7 +691,8 @@ struct PrbArgs {
     double* slab;          // [2][G][64][2]
     unsigned* cnt;         // [nb] arrival counters (zeroed before the launch)
     unsigned* abort_flag;  // [1]
-    long long* stamps;     // diagnostic: [G][8] accumulated cycles per phase, or nullptr
+    long long* stamps;     // diagnostic: [G][16] accumulated cycles per phase (8 control-wave,
+                           // 8 worker-wave values), or nullptr
 };
 
 __device__ __forceinline__ void st_agent(double* p, double v) {
@@ -874,6 +875,12 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         acc[k] += tn - tprev;               \
         tprev = tn;                         \
     }
+#define PRB_WSTAMP(k)                       \
+    if (stamp && tid == 64) {               \
+        const long long tn = clock64();     \
+        acc[k] += tn - tprev;               \
+        tprev = tn;                         \
+    }
 
     for (int b = 0; b < a.nb; ++b) {
         const int ncols = c1 - c0;
@@ -929,6 +936,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             ah += __shfl_xor(ah, 1, kWave);
             ag += __shfl_xor(ag, 2, kWave);
             ah += __shfl_xor(ah, 2, kWave);
+            PRB_WSTAMP(0)  // gather + partial sums
             // publish this row block's partial sums of the slot (tagged granules).  Slots
             // beyond the batch are published too (as zeros): every word of a slab is then
             // rewritten at every use of the buffer, so a reader can never meet a stale
@@ -944,8 +952,10 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         double p_next = 0.0;
         int n2e0 = 0, n2e1 = 0;
         if (!control) {
+            PRB_WSTAMP(1)  // publish issue
             const bool ok = prb_collect_quarter<2>(a, b, wave - 1, lane, ncols, sh_quart);
             if (!ok) *sh_ok = 0;
+            PRB_WSTAMP(2)  // granule sweep until every workgroup's partials are in
             if (b + 1 < a.nb) {
                 // prefetch (after the exchange: vmcnt retires in order, so streaming loads
                 // issued earlier would delay every granule check): entries of step b+1
@@ -958,8 +968,10 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         // B3: quarter sums in LDS.  Raw barrier: only LDS traffic must have landed; the
         // prefetch loads just issued stay in flight across it (a __syncthreads() would
         // add s_waitcnt vmcnt(0) and expose their HBM latency on every step).
+        PRB_WSTAMP(3)  // prefetch issue
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         PRB_STAMP(3)
+        PRB_WSTAMP(4)  // B3
         if (!*sh_ok) break;
         if (control) {
             double tot[2];
@@ -982,6 +994,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B4: deltas in LDS
         PRB_STAMP(5)
+        PRB_WSTAMP(5)  // waiting for the control wave's chain
         // ---- phase 3 (workers): scatter-update of the own rows (pcd.py:124-133)
         if (slot < ncols) {
             const double upd = sh_delta[slot];
@@ -1016,13 +1029,16 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         c1 = c2;
         c2 = c3;
         c3 = c4;
+        PRB_WSTAMP(6)  // scatter issue
         __syncthreads();  // B5: rows move between slots from step to step
         PRB_STAMP(6)
+        PRB_WSTAMP(7)  // B5 (stores acknowledged)
     }
 #undef PRB_STAMP
-    if (stamp && tid == 0) {
+#undef PRB_WSTAMP
+    if (stamp && (tid == 0 || tid == 64)) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a.stamps[(size_t)g * 8 + q] = acc[q];
+        for (int q = 0; q < 8; ++q) a.stamps[(size_t)g * 16 + (tid == 64 ? 8 : 0) + q] = acc[q];
     }
 }
 
@@ -1106,38 +1122,58 @@ __global__ __launch_bounds__(kBlock) void lin_sync_kernel(
     }
 }
 
-// Single-GPU fused form of the two kernels above (no exchange between the
-// gradient and the update): one launch per step.
+// Single-GPU fused form of the two kernels above (no exchange between the gradient
+// and the update): one launch per step, column found through its descriptor, the
+// first two entries per thread stay in registers between the two halves.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void lin_fused_kernel(
-    const int32_t* __restrict__ cols, const int64_t* __restrict__ cptr,
-    const int32_t* __restrict__ cidx, const T* __restrict__ cval, T* __restrict__ yy, int loss,
-    double* __restrict__ w, const double* __restrict__ col_norm_sq, double alpha, double mu,
+    const ColDesc* __restrict__ desc, const int32_t* __restrict__ cidx,
+    const T* __restrict__ cval, T* __restrict__ yy, int loss, double* __restrict__ w,
+    const double* __restrict__ col_norm_sq, double alpha, double mu,
     double* __restrict__ viol_col) {
     __shared__ double red[16];
-    const int q = blockIdx.x;
-    const int j = cols[q];
-    const int64_t b = cptr[j], e = cptr[j + 1];
+    constexpr int PF = 2;
+    const ColDesc cd = desc[blockIdx.x];
+    const int j = cd.j;
+    const int tid = threadIdx.x;
     const typename Vec2<T>::type* yy2 = reinterpret_cast<const typename Vec2<T>::type*>(yy);
+    const double wj = w[j];
+    const double cn = col_norm_sq[j];
+    int ri[PF];
+    double rx[PF], ryh[PF];
+    bool rv[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int off = tid + u * kBlock;
+        rv[u] = off < cd.len;
+        ri[u] = rv[u] ? cidx[cd.start + off] : 0;
+        rx[u] = rv[u] ? (double)cval[cd.start + off] : 0.0;
+    }
     double g = 0.0, h = 0.0;
-    for (int64_t ii = b + threadIdx.x; ii < e; ii += kBlock) {
-        const int i = cidx[ii];
-        const typename Vec2<T>::type yv = yy2[i];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const typename Vec2<T>::type yv = yy2[ri[u]];
+        ryh[u] = (double)yv.x;
+        g += rv[u] ? dloss_dev(loss, (double)yv.x, (double)yv.y) * rx[u] : 0.0;
+    }
+    for (int64_t ii = cd.start + tid + PF * kBlock; ii < cd.start + cd.len; ii += kBlock) {
+        const typename Vec2<T>::type yv = yy2[cidx[ii]];
         g += dloss_dev(loss, (double)yv.x, (double)yv.y) * (double)cval[ii];
     }
     block_sum2(g, h, red);
-    const double wj = w[j];
     double upd = g;
     upd += alpha * wj;
-    const double inv = mu * col_norm_sq[j] + alpha;
+    const double inv = mu * cn + alpha;
     upd /= inv;
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         w[j] = wj - upd;
         viol_col[j] += fabs(upd);
     }
     if (upd == 0.0) return;
-    for (int64_t ii = b + threadIdx.x; ii < e; ii += kBlock) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (rv[u]) yy[2 * (size_t)ri[u]] = (T)(ryh[u] - upd * rx[u]);
+    for (int64_t ii = cd.start + tid + PF * kBlock; ii < cd.start + cd.len; ii += kBlock) {
         const size_t i = (size_t)cidx[ii];
         yy[2 * i] = (T)((double)yy[2 * i] - upd * (double)cval[ii]);
     }

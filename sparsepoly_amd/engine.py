@@ -230,11 +230,11 @@ class HipEngine(object):
         self._check(self._lib.spfm_set_use_graph(self._h, int(bool(on))))
 
     def debug_prb_stamps(self):
-        buf = np.zeros(8 * 256, dtype=np.int64)
+        buf = np.zeros(16 * 256, dtype=np.int64)
         nv = self._lib.spfm_debug_prb_stamps(self._h, buf.ctypes.data_as(_capi._lp), buf.size)
         if nv < 0:
             self._check(nv)
-        return buf[:nv].reshape(-1, 8)
+        return buf[:nv].reshape(-1, 16)
 
     def get_option(self, key):
         v = C.c_int()

@@ -1,5 +1,5 @@
 import os, sys, time, numpy as np
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparsepoly_amd.engine import HipEngine
 from sparsepoly_amd.synth import make_problem
 n, d = int(os.environ.get("N", 1000000)), int(os.environ.get("D", 100000))
@@ -13,9 +13,11 @@ for G in [int(g) for g in os.environ.get("GS", "16,32").split(",")]:
     eng.pcd_epoch(0, 2, 10.0, 1.0, 1.0, ic[:2])
     t=time.time(); eng.pcd_epoch(0, 2, 10.0, 1.0, 1.0, ic[:4]); dt=(time.time()-t)/4
     st = eng.debug_prb_stamps().astype(float)
-    names = ["ctl-pre", "-", "-", "ph1+exch+B3", "sum+chain", "B4", "phase3+B5", "-"]
+    names = ["c:pre", "c:-", "c:-", "c:waitB3", "c:sum+chain", "c:B4", "c:ph3+B5", "c:-",
+             "w:gather+sum", "w:publish", "w:sweep", "w:prefetch", "w:B3", "w:waitB4", "w:scatter",
+             "w:B5"]
     print("G=%d pass %.2f ms, %.2f us/step; cycles/step (WG0 | mean over WGs | max):" % (G, dt*1e3, dt*1e6/nb))
-    for k in range(7):
+    for k in range(16):
         print("   %-10s %8.0f %8.0f %8.0f" % (names[k], st[0,k]/nb, st[:,k].mean()/nb, st[:,k].max()/nb))
-    print("   total cycles/step WG0: %.0f" % (st[0].sum()/nb))
+    print("   total cycles/step WG0: control %.0f worker %.0f" % (st[0,:8].sum()/nb, st[0,8:].sum()/nb))
     eng.close()

@@ -745,13 +745,14 @@ __device__ __forceinline__ bool prb_collect_quarter(const PrbArgs& a, int b, int
     bool ok = true;
     if (lane < ncols) {
         const double* sl = slab + (size_t)lane * 2;
-        for (int gg = g0; gg < g1; gg += 8) {
-            unsigned long long t[8][NV];
+        constexpr int GU = 8;  // granule pairs polled together per lane
+        for (int gg = g0; gg < g1; gg += GU) {
+            unsigned long long t[GU][NV];
             unsigned spins = 0;
             for (;;) {
                 bool all = true;
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < GU; ++u)
 #pragma unroll
                     for (int v = 0; v < NV; ++v) {
                         const bool in = gg + u < g1;
@@ -772,7 +773,7 @@ __device__ __forceinline__ bool prb_collect_quarter(const PrbArgs& a, int b, int
             }
             if (!ok) break;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < GU; ++u)
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
                     if (gg + u < g1) tot[v] += __longlong_as_double((long long)(t[u][v] & ~3ull));

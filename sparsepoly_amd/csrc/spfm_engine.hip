@@ -178,7 +178,7 @@ struct spfm_engine {
     int prb_G = 64;
     bool prb_ready = false;
     DevBuf prb_sp, prb_erow, prb_eval, prb_slab, prb_cnt, prb_abort, prow_old, d_bptr, prb_stamps,
-        prb_viol;
+        prb_viol, prb_cn;
     bool prb_stamp_on = false;
     static constexpr size_t kPrbLds = 84 * 1024;  // > half of the CU's 160 KiB: 1 WG per CU
     std::map<std::string, hipGraphExec_t> graphs;
@@ -801,9 +801,45 @@ struct spfm_engine {
         return SPFM_OK;
     }
 
+    template <typename T, int LOSS>
+    int lin_prb(double alpha) {
+        const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
+        int rc = ensure_prb<T>();
+        if (rc) return rc;
+        HIPC(hipFuncSetAttribute((const void*)lin_prb_kernel<T, LOSS>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrbLds));
+        hipLaunchKernelGGL(gather_sched_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
+                           d_desc.as<ColDesc>(), w.as<double>(), prow_old.as<double>());
+        HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));
+        prof_begin(4, nnz);
+        hipLaunchKernelGGL((lin_prb_kernel<T, LOSS>), dim3(prb_G), dim3(kPrbThreads), kPrbLds,
+                           stream, prb_args(), prb_eval.as<T>(), yy.as<T>(), prow_old.as<double>(),
+                           prb_cn.as<double>(), w.as<double>(), alpha, mu, prb_viol.as<double>());
+        prof_end(4);
+        hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
+                           d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+    template <typename T>
+    int lin_prb_loss(double alpha) {
+        switch (loss) {
+            case SPFM_LOSS_SQUARED: return lin_prb<T, LOSS_SQUARED>(alpha);
+            case SPFM_LOSS_SQUARED_HINGE: return lin_prb<T, LOSS_SQUARED_HINGE>(alpha);
+            default: return lin_prb<T, LOSS_LOGISTIC>(alpha);
+        }
+    }
+
     int cd_linear_epoch(double alpha, double* viol) {
         int rc = epoch_prologue();
         if (rc) return rc;
+        if (prb_usable()) {
+            rc = dtype == SPFM_F32 ? lin_prb_loss<float>(alpha) : lin_prb_loss<double>(alpha);
+            if (rc) return rc;
+            rc = epoch_epilogue(viol);
+            if (rc) return rc;
+            return prb_check_abort();
+        }
         const std::string key = fkey("lin", {alpha}, {loss, sched_version});
         rc = run_cached(key, [&]() {
             return dtype == SPFM_F32 ? lin_body<float>(alpha) : lin_body<double>(alpha);
@@ -889,6 +925,7 @@ struct spfm_engine {
         HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
         HIPC(prow_old.alloc(sizeof(double) * (size_t)d));
         HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
+        HIPC(prb_cn.alloc(sizeof(double) * (size_t)d));
         HIPC(prb_stamps.alloc(sizeof(long long) * 16 * (size_t)prb_G));
         HIPC(hipMemsetAsync(prb_stamps.p, 0, prb_stamps.bytes, stream));
         HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
@@ -903,6 +940,9 @@ struct spfm_engine {
                                prb_erow.as<int32_t>(), prb_eval.as<T>());
             HIPC(hipGetLastError());
         }
+        hipLaunchKernelGGL(gather_sched_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
+                           d_desc.as<ColDesc>(), col_norm.as<double>(), prb_cn.as<double>());
+        HIPC(hipGetLastError());
         HIPC(hipStreamSynchronize(stream));
         prb_ready = true;
         return SPFM_OK;

@@ -1043,6 +1043,132 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     }
 }
 
+// cd_linear._cd_linear_epoch (optimizer/cd_linear.py:8-33) as one persistent launch:
+// same row-block ownership, entry stream and tagged-granule exchange as pcd_prb_kernel,
+// one value per slot; the update has no regularizer, so the control wave's "chain" is
+// lane-parallel.  w_sched / cn_sched are w and col_norm_sq in visiting order (w as of the
+// epoch start: workgroup 0 writes the new w[j] while others may still read the old one).
+template <typename T, int LOSS>
+__global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
+    PrbArgs a, const T* __restrict__ eval, T* __restrict__ yy,
+    const double* __restrict__ w_sched, const double* __restrict__ cn_sched,
+    double* __restrict__ w, double alpha, double mu, double* __restrict__ viol_pos) {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    double* sh_delta = dyn_lds + 128;  // [64]
+    double* sh_quart = dyn_lds + 256;  // [4][64][2]
+    int* sh_ok = reinterpret_cast<int*>(dyn_lds + 768);
+    const typename Vec2<T>::type* yy2 = reinterpret_cast<const typename Vec2<T>::type*>(yy);
+    const int g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool control = wave == 0;
+    const int wt = tid - 64;
+    const int slot = control ? 64 : (wt >> 2), sub = wt & 3;
+    PrbEntries<T> cur, nxt;
+    int c0 = a.bptr[0], c1 = a.bptr[1];
+    int c2 = (a.nb > 1) ? a.bptr[2] : c1;
+    int c3 = (a.nb > 2) ? a.bptr[3] : c2;
+    {
+        int e0, e1;
+        prb_load_sp(a, g, 0, slot, c1 - c0, e0, e1);
+        prb_load_entries<T>(a, eval, e0, e1, sub, cur);
+    }
+    int ne0 = 0, ne1 = 0;
+    if (a.nb > 1) prb_load_sp(a, g, 1, slot, c2 - c1, ne0, ne1);
+    if (tid == 0) *sh_ok = 1;
+    for (int b = 0; b < a.nb; ++b) {
+        const int ncols = c1 - c0;
+        const int c4 = (b + 4 <= a.nb) ? a.bptr[b + 4] : c3;
+        double yh[PRB_PF];
+        double wl = 0.0, cnl = 0.0;
+        int jl = 0;
+        if (control) {
+            if (lane < ncols) {
+                wl = w_sched[c0 + lane];
+                cnl = cn_sched[c0 + lane];
+                if (g == 0) jl = a.desc[c0 + lane].j;
+            }
+        } else {
+            double yt[PRB_PF];
+#pragma unroll
+            for (int u = 0; u < PRB_PF; ++u) {
+                const typename Vec2<T>::type yv = yy2[(size_t)cur.row[u]];
+                yh[u] = (double)yv.x;
+                yt[u] = (double)yv.y;
+            }
+            double ag = 0.0;
+#pragma unroll
+            for (int u = 0; u < PRB_PF; ++u) {
+                const bool v = cur.e0 + sub + 4 * u < cur.e1;
+                ag += v ? dloss_dev(LOSS, yh[u], yt[u]) * (double)cur.x[u] : 0.0;
+            }
+            for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {
+                const typename Vec2<T>::type yv = yy2[(size_t)a.erow[e]];
+                ag += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * (double)eval[e];
+            }
+            ag += __shfl_xor(ag, 1, kWave);
+            ag += __shfl_xor(ag, 2, kWave);
+            if (sub == 0) {
+                double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + slot) * 2;
+                prb_store_granule(sl, ag, prb_tag(b));
+            }
+            const bool ok = prb_collect_quarter<1>(a, b, wave - 1, lane, ncols, sh_quart);
+            if (!ok) *sh_ok = 0;
+            if (b + 1 < a.nb) {
+                prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt);
+            }
+        }
+        int n2e0 = 0, n2e1 = 0;
+        if (!control && b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // quarter sums in LDS
+        if (!*sh_ok) break;
+        if (control) {
+            const double tot = ((sh_quart[(0 * 64 + lane) * 2] + sh_quart[(1 * 64 + lane) * 2]) +
+                                sh_quart[(2 * 64 + lane) * 2]) +
+                               sh_quart[(3 * 64 + lane) * 2];
+            const bool valid = lane < ncols;
+            double upd = tot;           // cd_linear.py:19-24
+            upd += alpha * wl;
+            const double inv = mu * cnl + alpha;
+            upd /= inv;
+            if (!valid) upd = 0.0;
+            sh_delta[lane] = upd;
+            if (g == 0 && valid) {
+                w[jl] = wl - upd;
+                viol_pos[c0 + lane] = fabs(upd);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // updates in LDS
+        if (slot < ncols) {
+            const double upd = sh_delta[slot];
+            if (upd != 0.0) {
+#pragma unroll
+                for (int u = 0; u < PRB_PF; ++u)
+                    if (cur.e0 + sub + 4 * u < cur.e1)
+                        yy[2 * (size_t)cur.row[u]] = (T)(yh[u] - upd * (double)cur.x[u]);
+                for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {
+                    const size_t i = (size_t)a.erow[e];
+                    yy[2 * i] = (T)((double)yy[2 * i] - upd * (double)eval[e]);
+                }
+            }
+        }
+        cur = nxt;
+        ne0 = n2e0;
+        ne1 = n2e1;
+        c0 = c1;
+        c1 = c2;
+        c2 = c3;
+        c3 = c4;
+        __syncthreads();
+    }
+}
+
+// out[pos] = v[desc[pos].j]
+__global__ void gather_sched_kernel(int d, const ColDesc* __restrict__ desc,
+                                    const double* __restrict__ v, double* __restrict__ out) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < d) out[pos] = v[desc[pos].j];
+}
+
 // viol_col[desc[pos].j] += viol_pos[pos]   (sum_viol bookkeeping of the persistent pass)
 __global__ void fold_viol_kernel(int d, const ColDesc* __restrict__ desc,
                                  const double* __restrict__ viol_pos,

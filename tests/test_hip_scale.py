@@ -1,0 +1,172 @@
+"""Parity at realistic column density and size-independent invariants at the full
+BASELINE config-2 size (1M x 100k, ~50 nnz/row).  Needs a real MI355X: ``pytest -m gpu``."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(Xc, y, k, degree, solver, reg, precision, schedule, P0=None, options=None):
+    from sparsepoly_amd.engine import HipEngine
+
+    d = Xc.shape[1]
+    eng = HipEngine(0, precision)
+    for key, val in (options or {}).items():
+        eng.set_option(key, val)
+    eng.set_data(Xc, y)
+    if P0 is None:
+        P0 = 0.01 * np.random.RandomState(0).randn(degree - 1, k, d)
+    eng.set_params(P0, np.zeros(d), np.ones(k))
+    eng.configure(solver, "squared", reg, degree)
+    eng.init_pred(degree, True, degree == 3)
+    order = eng.set_schedule(schedule, np.arange(d, dtype=np.int32))
+    return eng, order, P0
+
+
+@pytest.mark.parametrize("solver,reg,degree,k,beta,gamma",
+                         [("pcd", "squaredl12", 2, 30, 10.0, 1e-3),
+                          ("pcd", "omegati", 3, 8, 10.0, 1e-4),
+                          ("pbcd", "omegacs", 2, 30, 1.0, 1e-2)])
+def test_midsize_f32_trajectory_vs_oracle(oracle, solver, reg, degree, k, beta, gamma):
+    """1/10-scale config 2/3/4 (100k x 10k, same 500 nnz per column): the f32 engine in the
+    coloured order vs the f64 oracle replaying that order -- the north_star tolerance:
+    viol / sum-loss within 1e-5 relative, parameters within 1e-4.  gamma is chosen so that P
+    stays substantially non-zero (with gamma = 1 every coordinate is thresholded to 0 in the
+    first epoch and nothing is pinned) and the iteration is well conditioned (oracle: a 1e-7
+    perturbation of P_0 moves viol by <= 3e-8 relative over these 3 epochs)."""
+    from sparsepoly_amd.synth import make_problem
+
+    X, y = make_problem(100_000, 10_000, 50, seed=1)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    eng, order, P0 = _engine(Xc, y, k, degree, solver, reg, "f32", "colored")
+    ic = np.arange(k, dtype=np.int32)
+    viol, loss = [], []
+    for it in range(3):
+        v = eng.cd_linear_epoch(1.0)
+        for deg in list(range(2, degree)) + [degree]:
+            o = degree - deg if deg != degree else 0
+            if solver == "pcd":
+                v += eng.pcd_epoch(o, deg, beta, gamma, 1.0, ic)
+            else:
+                v += eng.pbcd_epoch(o, deg, beta, gamma, 1.0)
+        viol.append(v)
+        loss.append(eng.loss_sum())
+    P, w = eng.get_params()
+    eng.close()
+    fm = oracle.OracleFM(degree=degree, n_components=k, solver=solver, regularizer=reg, alpha=1.0,
+                         beta=beta, gamma=gamma, tol=0, max_iter=3, feature_order=order)
+    fm.fit(X, y, P_init=P0, lams_init=np.ones(k))
+    assert 0.05 < (fm.P_[0] != 0).mean()  # the model did not collapse
+    np.testing.assert_allclose(viol, [h[0] for h in fm.history], rtol=1e-5)
+    np.testing.assert_allclose(loss, [h[1] for h in fm.history], rtol=1e-5)
+    np.testing.assert_allclose(P, fm.P_, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(w, fm.w_, rtol=0, atol=1e-4)
+
+
+def test_midsize_exact_schedule_many_small_steps(oracle):
+    """schedule='exact' (natural order, runs of ~2-3 disjoint columns) through the
+    persistent pass: thousands of tiny steps, f64 engine vs oracle in natural order."""
+    from sparsepoly_amd.synth import make_problem
+
+    X, y = make_problem(20_000, 2_000, 50, seed=2)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    eng, order, P0 = _engine(Xc, y, 4, 2, "pcd", "squaredl12", "f64", "exact")
+    np.testing.assert_array_equal(order, np.arange(2000))
+    assert eng.n_batches > 500
+    ic = np.arange(4, dtype=np.int32)
+    v = eng.cd_linear_epoch(1.0) + eng.pcd_epoch(0, 2, 10.0, 1e-3, 1.0, ic)
+    P, w = eng.get_params()
+    eng.close()
+    fm = oracle.OracleFM(degree=2, n_components=4, solver="pcd", regularizer="squaredl12",
+                         alpha=1.0, beta=10.0, gamma=1e-3, tol=0, max_iter=1)
+    fm.fit(X, y, P_init=P0, lams_init=np.ones(4))
+    np.testing.assert_allclose(v, fm.history[0][0], rtol=1e-9)
+    np.testing.assert_allclose(P, fm.P_, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(w, fm.w_, rtol=0, atol=1e-9)
+
+
+@pytest.fixture(scope="module")
+def config2_matrix():
+    from sparsepoly_amd.synth import make_problem
+
+    X, y = make_problem(1_000_000, 100_000, 50, seed=0)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    return Xc, y
+
+
+@pytest.mark.parametrize("solver,reg", [("pcd", "squaredl12"), ("pbcd", "omegacs")])
+def test_fullsize_incremental_state_equals_recompute(config2_matrix, solver, reg):
+    """Full BASELINE config-2 size.  Invariant of the whole sweep (pcd.py:124-133,
+    pbcd.py:135-144, cd_linear.py:28-31): the incrementally maintained y_pred must equal
+    _get_output recomputed from the final (P, w); every coordinate is visited exactly once
+    (violation sum finite, schedule a permutation), and a second engine with precision f64
+    gives the same violation sum to f32-storage accuracy."""
+    Xc, y = config2_matrix
+    k = 30
+    out = {}
+    for precision in ("f32", "f64"):
+        eng, order, P0 = _engine(Xc, y, k, 2, solver, reg, precision, "colored")
+        assert np.array_equal(np.sort(order), np.arange(Xc.shape[1]))
+        ic = np.arange(3, dtype=np.int32)  # 3 of the 30 component passes: bounded run time
+        v = eng.cd_linear_epoch(1.0)
+        if solver == "pcd":
+            v += eng.pcd_epoch(0, 2, 10.0, 1e-4, 1.0, ic)
+        else:
+            v += eng.pbcd_epoch(0, 2, 1.0, 1e-3, 1.0)
+        y_inc = eng.get_y_pred()
+        loss_inc = eng.loss_sum()
+        eng.init_pred(2, True, False)  # from scratch with the trained parameters
+        y_new = eng.get_y_pred()
+        eng.close()
+        assert np.isfinite(v) and v > 0
+        tol = 2e-4 if precision == "f32" else 1e-9
+        np.testing.assert_allclose(y_inc, y_new, rtol=0, atol=tol * max(1.0, np.abs(y_new).max()))
+        out[precision] = (v, loss_inc)
+    np.testing.assert_allclose(out["f32"][0], out["f64"][0], rtol=2e-5)
+    np.testing.assert_allclose(out["f32"][1], out["f64"][1], rtol=2e-5)
+
+
+def test_estimator_augment_and_warm_start(oracle):
+    """fit_lower='augment' (dummy columns, sparse_factorization_machines.py:86-92) and
+    warm_start=True (P_, w_, lams_ reused, y_pred recomputed: :380-391,408)."""
+    from sklearn.preprocessing import add_dummy_feature
+
+    from sparsepoly_amd import SparseFactorizationMachineRegressor
+
+    rng = np.random.RandomState(5)
+    X = sp.random(300, 30, density=0.15, random_state=rng, data_rvs=rng.randn, format="csr")
+    y = rng.randn(300)
+    kw = dict(degree=3, n_components=4, solver="pcd", regularizer="omegati", alpha=0.1, beta=10.0,
+              gamma=0.05, tol=0, random_state=0, precision="f64")
+    est = SparseFactorizationMachineRegressor(fit_lower="augment", max_iter=3, **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        est.fit(X, y)
+    Xa = add_dummy_feature(X, value=1)  # degree 3, fit_linear=True: one dummy column
+    assert est.P_.shape == (1, 4, 31) and est.w_.shape == (31,)
+    fm = oracle.OracleFM(degree=3, n_components=4, solver="pcd", regularizer="omegati",
+                         alpha=0.1, beta=10.0, gamma=0.05, tol=0, max_iter=3, random_state=0,
+                         fit_lower="augment")
+    fm.fit(sp.csr_matrix(Xa), y)
+    np.testing.assert_allclose(est.P_, fm.P_, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(est.w_, fm.w_, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(est.predict(X), fm.predict(sp.csr_matrix(Xa)), rtol=0, atol=1e-8)
+    # warm start: 2 + 2 iterations == oracle continuing from the same state
+    est = SparseFactorizationMachineRegressor(fit_lower="explicit", max_iter=2, warm_start=True,
+                                              **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        est.fit(X, y)
+        P_mid, w_mid = est.P_.copy(), est.w_.copy()
+        est.fit(X, y)
+    fm = oracle.OracleFM(degree=3, n_components=4, solver="pcd", regularizer="omegati",
+                         alpha=0.1, beta=10.0, gamma=0.05, tol=0, max_iter=2, random_state=0)
+    fm.fit(X, y, P_init=P_mid, w_init=w_mid, lams_init=np.ones(4))
+    np.testing.assert_allclose(est.P_, fm.P_, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(est.w_, fm.w_, rtol=0, atol=1e-9)

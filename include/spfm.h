@@ -162,9 +162,12 @@ int spfm_comm_init(spfm_handle h, const char* id128, int n_ranks, int rank);
 
 /* -- instrumentation ----------------------------------------------------------
  * Device time (ms, HIP events on the handle's stream) and launch count of the
- * dominant kernel family since the last reset: which = 0 pcd gradient gather,
- * 1 pcd sync scatter, 2 pbcd gradient, 3 pbcd sync, 4 cd_linear step.
- * Timing is only collected when enabled (it serialises the stream). */
+ * dominant kernel family since the last reset: which = 0 pcd gather (persistent
+ * engine: the whole-pass kernel pcd_prb_kernel; multi-kernel engine: pcd_grad_kernel),
+ * 1 pcd chain+scatter (multi-kernel engine), 2 pbcd gradient, 3 pbcd sync,
+ * 4 cd_linear (lin_prb_kernel or the per-step kernels).  nnz = column entries the
+ * timed launches processed.  Timing is only collected when enabled (one event pair
+ * per launch; the multi-kernel engine then launches eagerly instead of replaying). */
 int spfm_profile_enable(spfm_handle h, int on);
 int spfm_profile_get(spfm_handle h, int which, double* ms, int64_t* launches, int64_t* nnz);
 int spfm_profile_reset(spfm_handle h);

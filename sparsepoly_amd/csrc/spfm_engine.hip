@@ -155,7 +155,7 @@ struct spfm_engine {
     // config
     int solver = -1, loss = 0, reg = 0, top_degree = 0;
     bool configured = false;
-    DevBuf abs_p, norms, cache, dcache;
+    DevBuf norms, cache, dcache;
 
     // schedule
     std::vector<int32_t> order, batch_ptr;
@@ -177,7 +177,7 @@ struct spfm_engine {
     bool persistent = true;
     int prb_G = 64;
     bool prb_ready = false;
-    DevBuf prb_sp, prb_erow, prb_eval, prb_slab, prb_cnt, prb_abort, prow_old, d_bptr, prb_stamps,
+    DevBuf prb_sp, prb_erow, prb_eval, prb_slab, prb_abort, prow_old, d_bptr, prb_stamps,
         prb_viol, prb_cn;
     bool prb_stamp_on = false;
     static constexpr size_t kPrbLds = 84 * 1024;  // > half of the CU's 160 KiB: 1 WG per CU
@@ -207,7 +207,6 @@ struct spfm_engine {
 
     RegState regstate() {
         RegState rs;
-        rs.abs_p = abs_p.as<double>();
         rs.norms = norms.as<double>();
         rs.cache = cache.as<double>();
         rs.dcache = dcache.as<double>();
@@ -511,11 +510,9 @@ struct spfm_engine {
         top_degree = top_degree_;
         clear_graphs();
         const size_t ncache = kMaxDegree + 2;
-        HIPC(abs_p.alloc(sizeof(double) * (size_t)d));
         HIPC(norms.alloc(sizeof(double) * (size_t)d));
         HIPC(cache.alloc(sizeof(double) * ncache * 2));  // pcd: double-buffered per batch
         HIPC(dcache.alloc(sizeof(double) * ncache));
-        HIPC(hipMemsetAsync(abs_p.p, 0, sizeof(double) * (size_t)d, stream));
         HIPC(hipMemsetAsync(norms.p, 0, sizeof(double) * (size_t)d, stream));
         HIPC(hipMemsetAsync(cache.p, 0, sizeof(double) * ncache * 2, stream));
         double hd[kMaxDegree + 2] = {0};
@@ -921,7 +918,6 @@ struct spfm_engine {
         HIPC(prb_erow.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
         HIPC(prb_eval.alloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1)));
         HIPC(prb_slab.alloc(sizeof(double) * 2 * (size_t)prb_G * 64 * 2));
-        HIPC(prb_cnt.alloc(sizeof(unsigned) * (size_t)n_batches()));
         HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
         HIPC(prow_old.alloc(sizeof(double) * (size_t)d));
         HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
@@ -957,7 +953,6 @@ struct spfm_engine {
         a.sp = prb_sp.as<int32_t>();
         a.erow = prb_erow.as<int32_t>();
         a.slab = prb_slab.as<double>();
-        a.cnt = prb_cnt.as<unsigned>();
         a.abort_flag = prb_abort.as<unsigned>();
         a.stamps = prb_stamp_on ? prb_stamps.as<long long>() : nullptr;
         return a;

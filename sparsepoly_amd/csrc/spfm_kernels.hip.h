@@ -1,14 +1,14 @@
 // spfm_kernels.hip.h -- gfx950 device code of the sparse-FM proximal CD core.
 //
 // Execution model: the coordinate order is partitioned into
-// batches of columns that share no row.  One batch = one dependent step =
-//   grad kernel   (one 256-thread workgroup per column: gather A[i], (yhat,y)[i]
-//                  over the column's rows, f64 wave-shuffle + LDS reduction)
-//   chain kernel  (one wavefront: step size, gradient step, prox and the
-//                  regularizer's cache recurrence, serial in batch order)
-//   sync kernel   (one workgroup per column: scatter-update of A[i], yhat[i])
-// Kernel boundaries on one stream are the only inter-workgroup synchronisation
-// (cheaper on MI355X than an in-kernel grid barrier, MI355X_MICROARCH price list).
+// batches of columns that share no row; one batch = one dependent step.  Two engines:
+//   persistent row-block pass (pcd_prb_kernel / lin_prb_kernel): one launch per
+//     component pass, each workgroup owns a block of rows, the per-step column partial
+//     sums are exchanged as tagged 8-byte granules (agent-scope stores / loads);
+//   multi-kernel (multi-GPU, pbcd): per step a gather kernel (workgroup per column, f64
+//     wave-shuffle + LDS reduction), [RCCL all-reduce], and a fused chain + scatter
+//     kernel; kernel boundaries on one stream are the only inter-workgroup
+//     synchronisation and the launch sequence is replayed from a hipGraph.
 //
 // Storage type T (float|double): X values, A caches, (yhat,y).  Everything that
 // is reduced or fed to the prox is float64.
@@ -44,7 +44,6 @@ struct ColDesc {
 
 // Regularizer state on the device (regularizer/*.py jitclass members)
 struct RegState {
-    double* abs_p;   // (d)      SquaredL12/OmegaTI _abs_p
     double* norms;   // (d)      SquaredL21/OmegaCS _norms
     double* cache;   // (kMaxDegree+2) _cache ; SquaredL12/SquaredL21: cache[0]
     double* dcache;  // (kMaxDegree+2) OmegaCS _dcache (persists between calls)
@@ -153,33 +152,10 @@ __global__ __launch_bounds__(kBlock) void reduce_sum_kernel(const double* __rest
 
 // ---------------------------------------------------------- pcd: precompute
 
-// pcd._precompute_A_all_degree (optimizer/pcd.py:15-30) for component ctl->s,
-// row-parallel over the CSR image (the reference sweeps columns; the per-row
-// recurrence visits the row's entries in the same ascending-column order).
-// A[i, M] is never read during training (pcd.py:11-12) and is not stored.
-template <typename T, int M>
-__global__ __launch_bounds__(kBlock) void pcd_precompute_kernel(
-    const Ctl* __restrict__ ctl, int64_t n, const int64_t* __restrict__ rptr,
-    const int32_t* __restrict__ ridx, const T* __restrict__ rval, const double* __restrict__ P,
-    int d, T* __restrict__ A) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const double* ps = P + (size_t)ctl->s * d;
-    double a[M];  // a[0] = 1 implicit at index 0
-    a[0] = 1.0;
-#pragma unroll
-    for (int t = 1; t < M; ++t) a[t] = 0.0;
-    const int64_t b = rptr[i], e = rptr[i + 1];
-    for (int64_t ii = b; ii < e; ++ii) {
-        const double p = ps[ridx[ii]];
-        const double x = (double)rval[ii];
-#pragma unroll
-        for (int t = M - 1; t >= 1; --t) a[t] += a[t - 1] * p * x;
-    }
-#pragma unroll
-    for (int t = 1; t < M; ++t) A[(size_t)i * (M - 1) + (t - 1)] = (T)a[t];
-}
-
+// pcd._precompute_A_all_degree (optimizer/pcd.py:15-30): per row the reference's column
+// sweep visits the row's entries in ascending column order; the kernel below keeps that
+// order inside every row.  A[i, M] is never read during training (pcd.py:11-12) and is
+// not stored.
 // All components in one pass over the CSR image (the "one precompute pass for all s"
 // of the roofline model): A_all[s][i][t-1] = A^{(s)}[i, t].  Valid because
 // P[s,:] changes only during pass s, so A^{(s)} computed from the epoch-start P equals
@@ -689,7 +665,6 @@ struct PrbArgs {
     const int32_t* sp;     // [G][nb][65] slot boundaries into erow/eval
     const int32_t* erow;   // entry row ids, sorted by (workgroup, batch, slot, row)
     double* slab;          // [2][G][64][2]
-    unsigned* cnt;         // [nb] arrival counters (zeroed before the launch)
     unsigned* abort_flag;  // [1]
     long long* stamps;     // diagnostic: [G][16] accumulated cycles per phase (8 control-wave,
                            // 8 worker-wave values), or nullptr

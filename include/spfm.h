@@ -130,6 +130,20 @@ int spfm_set_schedule(spfm_handle h, int mode, const int32_t* indices_feature,
                       const int64_t* conflict_indptr, const int32_t* conflict_indices,
                       int64_t conflict_n_rows, int32_t* order_out, int32_t* n_batches_out);
 
+/* Install a schedule computed earlier (spfm_schedule_build / a cached product of a
+ * previous fit on the same data): order[d] and batch_ptr[n_batches+1].  The library
+ * re-checks that `order` is a permutation and that every batch is row-disjoint on the
+ * structure it would have used to build it (conflict_* as in spfm_set_schedule, NULL =
+ * local data), because a batch that shares a row would race; SPFM_ERR_INVALID otherwise. */
+int spfm_set_schedule_raw(spfm_handle h, const int32_t* order, const int32_t* batch_ptr,
+                          int32_t n_batches, const int64_t* conflict_indptr,
+                          const int32_t* conflict_indices, int64_t conflict_n_rows);
+
+/* Read back the installed schedule: order_out[d], batch_ptr_out[n_batches+1] (either may
+ * be NULL); n_batches_out receives the number of batches. */
+int spfm_get_schedule(spfm_handle h, int32_t* order_out, int32_t* batch_ptr_out,
+                      int32_t* n_batches_out);
+
 /* Host-only form of the batch construction (no handle, no device): fills
  * order_out[d] and batch_ptr_out[<= d+1] (batch b = order_out[batch_ptr[b] ..
  * batch_ptr[b+1])) and returns the number of batches in n_batches_out.

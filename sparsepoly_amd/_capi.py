@@ -23,7 +23,8 @@ SCHEDULES = {"exact": 0, "colored": 1}
 SYMBOLS = [
     "spfm_create", "spfm_destroy", "spfm_last_error", "spfm_device_name", "spfm_set_data_csc",
     "spfm_set_params", "spfm_get_params", "spfm_configure", "spfm_init_pred", "spfm_get_y_pred",
-    "spfm_loss_sum", "spfm_predict_csr", "spfm_set_schedule", "spfm_schedule_build",
+    "spfm_loss_sum", "spfm_predict_csr", "spfm_set_schedule", "spfm_set_schedule_raw",
+    "spfm_get_schedule", "spfm_schedule_build",
     "spfm_cd_linear_epoch",
     "spfm_pcd_epoch", "spfm_pbcd_epoch", "spfm_comm_unique_id", "spfm_comm_init",
     "spfm_profile_enable", "spfm_profile_get", "spfm_profile_reset", "spfm_set_use_graph",
@@ -65,6 +66,8 @@ def load():
     L.spfm_loss_sum.argtypes = [_h, _dp]
     L.spfm_predict_csr.argtypes = [_h, C.c_int64, _lp, _ip, _dp, C.c_int, C.c_int, C.c_int, _dp]
     L.spfm_set_schedule.argtypes = [_h, C.c_int, _ip, _lp, _ip, C.c_int64, _ip, _ip]
+    L.spfm_set_schedule_raw.argtypes = [_h, _ip, _ip, C.c_int32, _lp, _ip, C.c_int64]
+    L.spfm_get_schedule.argtypes = [_h, _ip, _ip, _ip]
     L.spfm_schedule_build.argtypes = [C.c_int, C.c_int64, C.c_int32, _lp, _ip, _ip, C.c_int, _ip,
                                       _ip, _ip]
     L.spfm_cd_linear_epoch.argtypes = [_h, C.c_double, _dp]

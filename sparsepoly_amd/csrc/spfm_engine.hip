@@ -570,6 +570,15 @@ struct spfm_engine {
         } else {
             FAIL(SPFM_ERR_INVALID, "set_schedule: unknown mode");
         }
+        int rc = install_schedule();
+        if (rc) return rc;
+        if (order_out) std::memcpy(order_out, order.data(), sizeof(int32_t) * (size_t)d);
+        if (n_batches_out) *n_batches_out = (int32_t)batch_ptr.size() - 1;
+        return SPFM_OK;
+    }
+
+    // upload order / descriptors / batch boundaries of the schedule in `order`, `batch_ptr`
+    int install_schedule() {
         max_batch_cols = 1;
         for (size_t b = 0; b + 1 < batch_ptr.size(); ++b)
             max_batch_cols = std::max(max_batch_cols, batch_ptr[b + 1] - batch_ptr[b]);
@@ -586,7 +595,6 @@ struct spfm_engine {
                             hipMemcpyHostToDevice, stream));
         HIPC(hipMemcpyAsync(d_desc.p, hdesc.data(), sizeof(ColDesc) * (size_t)d,
                             hipMemcpyHostToDevice, stream));
-        HIPC(hipStreamSynchronize(stream));
         std::vector<int32_t> hb(batch_ptr.begin(), batch_ptr.end());
         HIPC(d_bptr.alloc(sizeof(int32_t) * hb.size()));
         HIPC(hipMemcpyAsync(d_bptr.p, hb.data(), sizeof(int32_t) * hb.size(),
@@ -596,9 +604,44 @@ struct spfm_engine {
         prb_ready = false;
         ++sched_version;
         clear_graphs();
-        if (order_out) std::memcpy(order_out, order.data(), sizeof(int32_t) * (size_t)d);
-        if (n_batches_out) *n_batches_out = (int32_t)batch_ptr.size() - 1;
         return alloc_work();
+    }
+
+    int set_schedule_raw(const int32_t* order_in, const int32_t* bptr_in, int32_t nb,
+                         const int64_t* cf_indptr, const int32_t* cf_indices, int64_t cf_rows) {
+        if (!have_data) FAIL(SPFM_ERR_INVALID, "set_schedule_raw: no data");
+        if (!order_in || !bptr_in || nb < 1) FAIL(SPFM_ERR_INVALID, "set_schedule_raw: bad arguments");
+        if (bptr_in[0] != 0 || bptr_in[nb] != d)
+            FAIL(SPFM_ERR_INVALID, "set_schedule_raw: batch_ptr must run from 0 to n_features");
+        std::vector<char> seen((size_t)d, 0);
+        for (int q = 0; q < d; ++q) {
+            const int j = order_in[q];
+            if (j < 0 || j >= d || seen[(size_t)j])
+                FAIL(SPFM_ERR_INVALID, "set_schedule_raw: order is not a permutation");
+            seen[(size_t)j] = 1;
+        }
+        const int64_t* cp = cf_indptr ? cf_indptr : h_cptr.data();
+        const int32_t* ci = cf_indptr ? cf_indices : h_cidx.data();
+        const int64_t rows = cf_indptr ? cf_rows : n;
+        if (cf_indptr && (!cf_indices || cf_rows <= 0))
+            FAIL(SPFM_ERR_INVALID, "set_schedule_raw: bad conflict structure");
+        std::vector<int32_t> stamp((size_t)rows, -1);
+        for (int b = 0; b < nb; ++b) {
+            if (bptr_in[b + 1] < bptr_in[b])
+                FAIL(SPFM_ERR_INVALID, "set_schedule_raw: batch_ptr is not monotone");
+            for (int q = bptr_in[b]; q < bptr_in[b + 1]; ++q) {
+                const int j = order_in[q];
+                for (int64_t ii = cp[j]; ii < cp[j + 1]; ++ii) {
+                    if (stamp[(size_t)ci[ii]] == b)
+                        FAIL(SPFM_ERR_INVALID,
+                             "set_schedule_raw: two columns of one batch share a row");
+                    stamp[(size_t)ci[ii]] = b;
+                }
+            }
+        }
+        order.assign(order_in, order_in + d);
+        batch_ptr.assign(bptr_in, bptr_in + nb + 1);
+        return install_schedule();
     }
 
     int n_batches() const { return (int)batch_ptr.size() - 1; }
@@ -1325,6 +1368,29 @@ int spfm_set_schedule(spfm_handle h, int mode, const int32_t* indices_feature,
     GUARD(h);
     return h->set_schedule(mode, indices_feature, conflict_indptr, conflict_indices,
                            conflict_n_rows, order_out, n_batches_out);
+}
+
+int spfm_set_schedule_raw(spfm_handle h, const int32_t* order, const int32_t* batch_ptr,
+                          int32_t n_batches, const int64_t* conflict_indptr,
+                          const int32_t* conflict_indices, int64_t conflict_n_rows) {
+    GUARD(h);
+    return h->set_schedule_raw(order, batch_ptr, n_batches, conflict_indptr, conflict_indices,
+                               conflict_n_rows);
+}
+
+int spfm_get_schedule(spfm_handle h, int32_t* order_out, int32_t* batch_ptr_out,
+                      int32_t* n_batches_out) {
+    if (!h) return SPFM_ERR_INVALID;
+    if (!h->have_schedule) {
+        h->err = "get_schedule: no schedule installed";
+        return SPFM_ERR_INVALID;
+    }
+    if (order_out)
+        std::memcpy(order_out, h->order.data(), sizeof(int32_t) * h->order.size());
+    if (batch_ptr_out)
+        std::memcpy(batch_ptr_out, h->batch_ptr.data(), sizeof(int32_t) * h->batch_ptr.size());
+    if (n_batches_out) *n_batches_out = (int32_t)h->batch_ptr.size() - 1;
+    return SPFM_OK;
 }
 
 int spfm_schedule_build(int mode, int64_t n_rows, int32_t d, const int64_t* indptr,

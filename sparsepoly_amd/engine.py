@@ -178,6 +178,36 @@ class HipEngine(object):
         self.order, self.n_batches = order, nb.value
         return order
 
+    def get_schedule(self, mode="colored"):
+        """The installed schedule as a reusable ``Schedule`` object."""
+        from .schedule import Schedule
+
+        nb = C.c_int32()
+        self._check(self._lib.spfm_get_schedule(self._h, None, None, C.byref(nb)))
+        order = np.empty(self.d, dtype=np.int32)
+        bp = np.empty(nb.value + 1, dtype=np.int32)
+        self._check(self._lib.spfm_get_schedule(self._h, order.ctypes.data_as(_capi._ip),
+                                                bp.ctypes.data_as(_capi._ip), C.byref(nb)))
+        return Schedule(order, bp, mode, (self.n, self.d))
+
+    def install_schedule(self, sched, conflict_csc=None):
+        """Install a precomputed ``sparsepoly_amd.schedule.Schedule`` (validated by the
+        library against the data / the global structure)."""
+        oa, op = _capi.i32(sched.order)
+        ba, bp = _capi.i32(sched.batch_ptr)
+        if oa.shape[0] != self.d:
+            raise ValueError("schedule has %d features, the data has %d" % (oa.shape[0], self.d))
+        if conflict_csc is None:
+            cp, ci, rows = None, None, 0
+        else:
+            cpa, cp = _capi.i64(conflict_csc.indptr)
+            cia, ci = _capi.i32(conflict_csc.indices)
+            rows = conflict_csc.shape[0]
+        self._check(self._lib.spfm_set_schedule_raw(self._h, op, bp, ba.shape[0] - 1, cp, ci,
+                                                    rows))
+        self.order, self.n_batches = oa.copy(), ba.shape[0] - 1
+        return self.order
+
     # ---------------------------------------------------------------- epochs
     def cd_linear_epoch(self, alpha):
         v = C.c_double()

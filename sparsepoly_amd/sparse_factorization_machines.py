@@ -12,7 +12,9 @@ path: without the HIP library or a GPU, ``fit``/``predict`` raise.
 
 Additional keywords (after the reference's, so positional use is unchanged):
 
-``schedule``   'exact' (default): coordinates are visited exactly in the
+``schedule``   a ``sparsepoly_amd.schedule.Schedule`` built earlier for this data (reused
+               as is; fitted estimators expose theirs as ``schedule_``), or
+               'exact' (default): coordinates are visited exactly in the
                reference's order (``np.arange`` or the shuffled order); consecutive
                columns that share no row are processed as one dependent step.
                'colored': the column conflict graph is coloured once and the
@@ -39,6 +41,7 @@ from sklearn.utils.validation import NotFittedError, check_array
 
 from .base import BaseSparsePoly, SparsePolyClassifierMixin, SparsePolyRegressorMixin
 from .engine import HipEngine, canonical_csc
+from .schedule import Schedule
 from .loss import CLASSIFICATION_LOSSES, REGRESSION_LOSSES
 from .regularizer import REGULARIZATION
 
@@ -136,6 +139,18 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         dev = _default_device() if self.device is None else self.device
         return HipEngine(device=dev, precision=self.precision)
 
+    def _set_schedule(self, engine, indices_feature, conflict_csc):
+        """Fix the visiting order of the next epochs (the reference passes
+        ``indices_feature`` to every epoch call: :198-205, :289-295)."""
+        if isinstance(self.schedule, Schedule):
+            order = engine.install_schedule(self.schedule, conflict_csc)
+            self.schedule_ = self.schedule
+        else:
+            order = engine.set_schedule(self.schedule, indices_feature, conflict_csc)
+            self.schedule_ = None  # filled in at the end of fit (needs the batch bounds)
+        self.feature_order_ = order
+        return order
+
     def _sync_params(self, engine, with_P=True):
         """Copy the live device parameters into P_ / w_ (in place)."""
         engine.get_params(self.P_, self.w_, skip_P=not with_P)
@@ -148,16 +163,14 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         converged = False
         alpha, beta, gamma = self._scaled(n_samples)
         if not self.shuffle:
-            self.feature_order_ = engine.set_schedule(self.schedule, indices_feature,
-                                                      conflict_csc)
+            self._set_schedule(engine, indices_feature, conflict_csc)
         it = 0
         for it in range(self.max_iter):
             viol = 0
             if self.shuffle:
                 rng.shuffle(indices_component)
                 rng.shuffle(indices_feature)
-                self.feature_order_ = engine.set_schedule(self.schedule, indices_feature,
-                                                          conflict_csc)
+                self._set_schedule(engine, indices_feature, conflict_csc)
             if self.fit_linear:
                 viol += engine.cd_linear_epoch(alpha)
             if self.fit_lower == "explicit":
@@ -188,15 +201,13 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         converged = False
         alpha, beta, gamma = self._scaled(n_samples)
         if not self.shuffle:
-            self.feature_order_ = engine.set_schedule(self.schedule, indices_feature,
-                                                      conflict_csc)
+            self._set_schedule(engine, indices_feature, conflict_csc)
         it = 0
         for it in range(self.max_iter):
             viol = 0
             if self.shuffle:
                 rng.shuffle(indices_feature)
-                self.feature_order_ = engine.set_schedule(self.schedule, indices_feature,
-                                                          conflict_csc)
+                self._set_schedule(engine, indices_feature, conflict_csc)
             if self.fit_linear:
                 viol += engine.cd_linear_epoch(alpha)
             if self.fit_lower == "explicit":
@@ -267,8 +278,10 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 )
             msg = f"Solver {self.solver} is not supported."
             raise ValueError(msg)
-        if self.schedule not in ("exact", "colored"):
-            raise ValueError("schedule must be 'exact' or 'colored'.")
+        if not isinstance(self.schedule, Schedule) and self.schedule not in ("exact", "colored"):
+            raise ValueError("schedule must be 'exact', 'colored' or a Schedule object.")
+        if isinstance(self.schedule, Schedule) and self.shuffle:
+            raise ValueError("a fixed Schedule cannot be combined with shuffle=True.")
 
         Xc = canonical_csc(X)
         conflict_csc = None
@@ -298,6 +311,8 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 converged, self.n_iter_ = self._fit_pbcd(engine, n_samples, n_features, rng,
                                                          conflict_csc)
             self.n_steps_per_sweep_ = engine.n_batches
+            if self.schedule_ is None:
+                self.schedule_ = engine.get_schedule(self.schedule)
         finally:
             engine.close()
 

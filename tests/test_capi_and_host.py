@@ -212,3 +212,18 @@ def test_row_block_partition():
             assert b == c and b >= a
         sizes = [b - a for a, b in blocks]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_schedule_object_roundtrip(tmp_path):
+    from sparsepoly_amd.schedule import Schedule
+
+    X = sp.random(400, 90, density=0.04, format="csr", random_state=2)
+    s1 = Schedule.build(X, "colored")
+    assert s1.n_batches >= 1 and sorted(s1.order.tolist()) == list(range(90))
+    assert np.diff(s1.batch_ptr).max() <= 64
+    s1.save(tmp_path / "sched.npz")
+    s2 = Schedule.load(tmp_path / "sched.npz")
+    np.testing.assert_array_equal(s1.order, s2.order)
+    np.testing.assert_array_equal(s1.batch_ptr, s2.batch_ptr)
+    assert s2.mode == "colored" and s2.shape == (400, 90) and s2.nnz == X.nnz
+    assert "n_batches=%d" % s1.n_batches in repr(s2)

@@ -444,3 +444,43 @@ def test_estimator_distributed_world1():
         np.testing.assert_allclose(a.w_, b.w_, rtol=0, atol=1e-10)
     finally:
         dist.destroy_process_group()
+
+
+def test_schedule_product_reuse_and_validation():
+    """N1: a schedule built once is reused by later fits (identical result, no
+    re-colouring), survives save/load, and a schedule whose batches share a row or that
+    belongs to other data is rejected by the library instead of being raced on."""
+    from sparsepoly_amd import SparseFactorizationMachineRegressor
+    from sparsepoly_amd.engine import HipEngine
+    from sparsepoly_amd.schedule import Schedule
+
+    z = load_golden("g2_config1.npz")
+    X, y = golden_csr(z), z["y"]
+    kw = dict(degree=2, n_components=4, regularizer="squaredl12", solver="pcd", gamma=1e-3,
+              beta=10.0, max_iter=3, tol=0, random_state=0, precision="f64")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = SparseFactorizationMachineRegressor(schedule="colored", **kw).fit(X, y)
+        assert isinstance(a.schedule_, Schedule) and a.schedule_.n_batches == a.n_steps_per_sweep_
+        b = SparseFactorizationMachineRegressor(schedule=a.schedule_, **kw).fit(X, y)
+        c = SparseFactorizationMachineRegressor(schedule=Schedule.build(X, "colored"), **kw).fit(X, y)
+    np.testing.assert_array_equal(a.feature_order_, b.feature_order_)
+    np.testing.assert_array_equal(a.P_, b.P_)
+    np.testing.assert_array_equal(a.P_, c.P_)
+    # validation
+    eng = HipEngine(0, "f64")
+    eng.set_data(X, y)
+    good = a.schedule_
+    merged = Schedule(good.order, np.array([0, X.shape[1]], dtype=np.int32))  # one huge batch
+    with pytest.raises(ValueError, match="share a row"):
+        eng.install_schedule(merged)
+    dup = Schedule(np.zeros(X.shape[1], dtype=np.int32), good.batch_ptr)
+    with pytest.raises(ValueError, match="not a permutation"):
+        eng.install_schedule(dup)
+    eng.install_schedule(good)
+    got = eng.get_schedule()
+    np.testing.assert_array_equal(got.order, good.order)
+    np.testing.assert_array_equal(got.batch_ptr, good.batch_ptr)
+    eng.close()
+    with pytest.raises(ValueError):
+        SparseFactorizationMachineRegressor(schedule=good, shuffle=True, **kw).fit(X, y)

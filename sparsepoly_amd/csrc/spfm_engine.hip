@@ -21,8 +21,8 @@ void schedule_colored(int64_t, int32_t, const int64_t*, const int32_t*, const in
 void csc_to_csr(int64_t, int32_t, const int64_t*, const int32_t*, std::vector<int64_t>&,
                 std::vector<int32_t>&, std::vector<int64_t>&);
 void build_rowblock_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
-                           const std::vector<int32_t>&, int, std::vector<int32_t>&,
-                           std::vector<int32_t>&);
+                           const std::vector<int32_t>&, int, int, std::vector<int32_t>&,
+                           std::vector<int32_t>&, std::vector<uint32_t>&);
 }  // namespace spfm
 
 using namespace spfm;
@@ -178,7 +178,7 @@ struct spfm_engine {
     int prb_G = 64;
     bool prb_ready = false;
     DevBuf prb_sp, prb_erow, prb_eval, prb_slab, prb_abort, prow_old, d_bptr, prb_stamps,
-        prb_viol, prb_cn;
+        prb_viol, prb_cn, prb_lmask;
     bool prb_stamp_on = false;
     static constexpr size_t kPrbLds = 84 * 1024;  // > half of the CU's 160 KiB: 1 WG per CU
     std::map<std::string, hipGraphExec_t> graphs;
@@ -954,7 +954,12 @@ struct spfm_engine {
         if (prb_G > ncu) prb_G = ncu;
         if (prb_G < 1) prb_G = 1;
         std::vector<int32_t> sp, src;
-        build_rowblock_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, prb_G, sp, src);
+        std::vector<uint32_t> lmask;
+        build_rowblock_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, prb_G, kPrbLong,
+                              sp, src, lmask);
+        HIPC(prb_lmask.alloc(sizeof(uint32_t) * lmask.size()));
+        HIPC(hipMemcpyAsync(prb_lmask.p, lmask.data(), sizeof(uint32_t) * lmask.size(),
+                            hipMemcpyHostToDevice, stream));
         DevBuf d_src;
         HIPC(d_src.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
         HIPC(prb_sp.alloc(sizeof(int32_t) * sp.size()));
@@ -994,6 +999,7 @@ struct spfm_engine {
         a.bptr = d_bptr.as<int32_t>();
         a.desc = d_desc.as<ColDesc>();
         a.sp = prb_sp.as<int32_t>();
+        a.lmask = prb_lmask.as<uint32_t>();
         a.erow = prb_erow.as<int32_t>();
         a.slab = prb_slab.as<double>();
         a.abort_flag = prb_abort.as<unsigned>();

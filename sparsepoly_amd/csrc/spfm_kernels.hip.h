@@ -663,6 +663,7 @@ struct PrbArgs {
     const int32_t* bptr;   // [nb+1] batch boundaries into desc
     const ColDesc* desc;   // columns in visiting order
     const int32_t* sp;     // [G][nb][65] slot boundaries into erow/eval
+    const uint32_t* lmask; // [G][nb][2] bit q: slot q is "long" in this row block
     const int32_t* erow;   // entry row ids, sorted by (workgroup, batch, slot, row)
     double* slab;          // [2][G][64][2]
     unsigned* abort_flag;  // [1]
@@ -763,6 +764,9 @@ __device__ __forceinline__ bool prb_collect_quarter(const PrbArgs& a, int b, int
 // PRB_PF entries (row, value) in registers; a slot with more than 4*PRB_PF entries in
 // this row block falls back to a reload loop for the rest.
 constexpr int PRB_PF = 4;
+// A (workgroup, step, slot) segment longer than this is a "long slot" (a very frequent
+// feature): the 4 lanes of the slot skip it and all 256 worker threads stride over it.
+constexpr int kPrbLong = 48;
 template <typename T>
 struct PrbEntries {
     int e0, e1;
@@ -771,14 +775,22 @@ struct PrbEntries {
 };
 
 __device__ __forceinline__ void prb_load_sp(const PrbArgs& a, int g, int b, int slot, int ncols,
-                                            int& e0, int& e1) {
+                                            int& e0, int& e1, unsigned long long& lmask) {
     e0 = 0;
     e1 = 0;
-    if (slot < ncols) {
+    const uint32_t* lm = a.lmask + ((size_t)g * a.nb + b) * 2;
+    lmask = ((unsigned long long)lm[1] << 32) | (unsigned long long)lm[0];
+    if (slot < ncols && !((lmask >> slot) & 1ull)) {  // long slots: no per-lane entries
         const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
         e0 = spb[slot];
         e1 = spb[slot + 1];
     }
+}
+
+// q-th set bit of m (q < popcount(m))
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int q) {
+    for (int t = 0; t < q; ++t) m &= m - 1;
+    return __builtin_ctzll(m);
 }
 
 template <typename T>
@@ -828,17 +840,19 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
 #pragma unroll
     for (int t = 0; t <= M; ++t) cache[t] = cache_in[t];
 
+    double* sh_long = dyn_lds + 1024;  // [64][4][2] wave partials of long slots
     PrbEntries<T> cur, nxt;
     int c0 = a.bptr[0], c1 = a.bptr[1];
     int c2 = (a.nb > 1) ? a.bptr[2] : c1;
     int c3 = (a.nb > 2) ? a.bptr[3] : c2;
+    unsigned long long lm0 = 0ull, lm1 = 0ull;  // long-slot masks of steps b, b+1
     {
         int e0, e1;
-        prb_load_sp(a, g, 0, slot, c1 - c0, e0, e1);
+        prb_load_sp(a, g, 0, slot, c1 - c0, e0, e1, lm0);
         prb_load_entries<T>(a, eval, e0, e1, sub, cur);
     }
     int ne0 = 0, ne1 = 0;  // slot bounds of step b+1
-    if (a.nb > 1) prb_load_sp(a, g, 1, slot, c2 - c1, ne0, ne1);
+    if (a.nb > 1) prb_load_sp(a, g, 1, slot, c2 - c1, ne0, ne1, lm1);
     double p_slot = (slot < c1 - c0) ? pold_sched[c0 + slot] : 0.0;
     if (tid == 0) *sh_ok = 1;
     // diagnostic stamps (only when a.stamps != nullptr): cycles per phase, thread 0
@@ -917,16 +931,66 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             // beyond the batch are published too (as zeros): every word of a slab is then
             // rewritten at every use of the buffer, so a reader can never meet a stale
             // word that happens to carry the current tag.
-            if (sub == 0) {
+            if (sub == 0 && !((lm0 >> slot) & 1ull)) {
                 double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + slot) * 2;
                 const unsigned long long tag = prb_tag(b);
                 prb_store_granule(sl, ag, tag);
                 prb_store_granule(sl + 1, ah, tag);
             }
         }
+        // ---- long slots of this row block (rare: very frequent features): the whole
+        // workgroup strides over the slot's entries; one extra barrier, taken by all waves
+        const unsigned long long lmu =
+            ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(lm0 >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)lm0);
+        if (lmu != 0ull) {
+            const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
+            int qi = 0;
+            for (unsigned long long mm = lmu; mm != 0ull; mm &= mm - 1, ++qi) {
+                const int q = __builtin_ctzll(mm);
+                if (!control) {
+                    const int le0 = spb[q], le1 = spb[q + 1];
+                    const double pq = pold_sched[c0 + q];
+                    double lg = 0.0, lh = 0.0;
+                    for (int e = le0 + wt; e < le1; e += 256) {
+                        const int i = a.erow[e];
+                        const double x = (double)eval[e];
+                        const typename Vec2<T>::type yv = yy2[i];
+                        double dprev = x;
+#pragma unroll
+                        for (int t = 1; t < M; ++t) {
+                            const double a1 = (double)A[(size_t)i * (M - 1) + (t - 1)];
+                            dprev = x * (a1 - pq * dprev);
+                        }
+                        lg += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * dprev;
+                        lh += dprev * dprev;
+                    }
+                    lg = wave_sum(lg);
+                    lh = wave_sum(lh);
+                    if (lane == 0) {
+                        sh_long[(qi * 4 + (wave - 1)) * 2] = lg;
+                        sh_long[(qi * 4 + (wave - 1)) * 2 + 1] = lh;
+                    }
+                }
+            }
+            __syncthreads();
+            if (!control && wt < qi) {
+                const int q = nth_set_bit(lmu, wt);
+                double tg = 0.0, th = 0.0;
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    tg += sh_long[(wt * 4 + w4) * 2];
+                    th += sh_long[(wt * 4 + w4) * 2 + 1];
+                }
+                double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + q) * 2;
+                const unsigned long long tag = prb_tag(b);
+                prb_store_granule(sl, tg, tag);
+                prb_store_granule(sl + 1, th, tag);
+            }
+        }
         PRB_STAMP(0)
         double p_next = 0.0;
         int n2e0 = 0, n2e1 = 0;
+        unsigned long long lm2 = 0ull;
         if (!control) {
             PRB_WSTAMP(1)  // publish issue
             const bool ok = prb_collect_quarter<2>(a, b, wave - 1, lane, ncols, sh_quart);
@@ -938,9 +1002,9 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 // (bounds already in registers), bounds of b+2
                 prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt);
                 if (slot < c2 - c1) p_next = pold_sched[c1 + slot];
-                if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1);
             }
         }
+        if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
         // B3: quarter sums in LDS.  Raw barrier: only LDS traffic must have landed; the
         // prefetch loads just issued stay in flight across it (a __syncthreads() would
         // add s_waitcnt vmcnt(0) and expose their HBM latency on every step).
@@ -997,10 +1061,26 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                                          yy);
             }
         }
+        if (lmu != 0ull && !control) {  // long slots: every worker thread scatters
+            const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
+            for (unsigned long long mm = lmu; mm != 0ull; mm &= mm - 1) {
+                const int q = __builtin_ctzll(mm);
+                const double upd = sh_delta[q];
+                if (upd != 0.0) {
+                    const double p_old = sh_pold[q];
+                    const int le0 = spb[q], le1 = spb[q + 1];
+                    for (int e = le0 + wt; e < le1; e += 256)
+                        pcd_sync_entry<T, M>((size_t)a.erow[e], (double)eval[e], p_old, upd, lam,
+                                             A, yy);
+                }
+            }
+        }
         cur = nxt;
         p_slot = p_next;
         ne0 = n2e0;
         ne1 = n2e1;
+        lm0 = lm1;
+        lm1 = lm2;
         c0 = c1;
         c1 = c2;
         c2 = c3;
@@ -1038,17 +1118,19 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
     const bool control = wave == 0;
     const int wt = tid - 64;
     const int slot = control ? 64 : (wt >> 2), sub = wt & 3;
+    double* sh_long = dyn_lds + 1024;  // [64][4][2]
     PrbEntries<T> cur, nxt;
     int c0 = a.bptr[0], c1 = a.bptr[1];
     int c2 = (a.nb > 1) ? a.bptr[2] : c1;
     int c3 = (a.nb > 2) ? a.bptr[3] : c2;
+    unsigned long long lm0 = 0ull, lm1 = 0ull;
     {
         int e0, e1;
-        prb_load_sp(a, g, 0, slot, c1 - c0, e0, e1);
+        prb_load_sp(a, g, 0, slot, c1 - c0, e0, e1, lm0);
         prb_load_entries<T>(a, eval, e0, e1, sub, cur);
     }
     int ne0 = 0, ne1 = 0;
-    if (a.nb > 1) prb_load_sp(a, g, 1, slot, c2 - c1, ne0, ne1);
+    if (a.nb > 1) prb_load_sp(a, g, 1, slot, c2 - c1, ne0, ne1, lm1);
     if (tid == 0) *sh_ok = 1;
     for (int b = 0; b < a.nb; ++b) {
         const int ncols = c1 - c0;
@@ -1056,6 +1138,34 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
         double yh[PRB_PF];
         double wl = 0.0, cnl = 0.0;
         int jl = 0;
+        const unsigned long long lmu =
+            ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(lm0 >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)lm0);
+        if (lmu != 0ull) {  // long slots first: whole-workgroup partial sums (see pcd_prb_kernel)
+            const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
+            int qi = 0;
+            for (unsigned long long mm = lmu; mm != 0ull; mm &= mm - 1, ++qi) {
+                const int q = __builtin_ctzll(mm);
+                if (!control) {
+                    const int le0 = spb[q], le1 = spb[q + 1];
+                    double lg = 0.0;
+                    for (int e = le0 + wt; e < le1; e += 256) {
+                        const typename Vec2<T>::type yv = yy2[(size_t)a.erow[e]];
+                        lg += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * (double)eval[e];
+                    }
+                    lg = wave_sum(lg);
+                    if (lane == 0) sh_long[(qi * 4 + (wave - 1)) * 2] = lg;
+                }
+            }
+            __syncthreads();
+            if (!control && wt < qi) {
+                const int q = nth_set_bit(lmu, wt);
+                double tg = 0.0;
+                for (int w4 = 0; w4 < 4; ++w4) tg += sh_long[(wt * 4 + w4) * 2];
+                double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + q) * 2;
+                prb_store_granule(sl, tg, prb_tag(b));
+            }
+        }
         if (control) {
             if (lane < ncols) {
                 wl = w_sched[c0 + lane];
@@ -1082,7 +1192,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
             }
             ag += __shfl_xor(ag, 1, kWave);
             ag += __shfl_xor(ag, 2, kWave);
-            if (sub == 0) {
+            if (sub == 0 && !((lm0 >> slot) & 1ull)) {
                 double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + slot) * 2;
                 prb_store_granule(sl, ag, prb_tag(b));
             }
@@ -1093,7 +1203,8 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
             }
         }
         int n2e0 = 0, n2e1 = 0;
-        if (!control && b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1);
+        unsigned long long lm2 = 0ull;
+        if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // quarter sums in LDS
         if (!*sh_ok) break;
         if (control) {
@@ -1126,9 +1237,25 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 }
             }
         }
+        if (lmu != 0ull && !control) {
+            const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
+            for (unsigned long long mm = lmu; mm != 0ull; mm &= mm - 1) {
+                const int q = __builtin_ctzll(mm);
+                const double upd = sh_delta[q];
+                if (upd != 0.0) {
+                    const int le0 = spb[q], le1 = spb[q + 1];
+                    for (int e = le0 + wt; e < le1; e += 256) {
+                        const size_t i = (size_t)a.erow[e];
+                        yy[2 * i] = (T)((double)yy[2 * i] - upd * (double)eval[e]);
+                    }
+                }
+            }
+        }
         cur = nxt;
         ne0 = n2e0;
         ne1 = n2e1;
+        lm0 = lm1;
+        lm1 = lm2;
         c0 = c1;
         c1 = c2;
         c2 = c3;

@@ -124,10 +124,13 @@ void csc_to_csr(int64_t n, int32_t d, const int64_t* cptr, const int32_t* cidx,
 // batch b, slot q, row).  sp[(g*nb + b)*65 + q] = first entry of slot q (65 = 64 slots
 // + end), src[e] = position of entry e in the CSC arrays.  Requires batches of at
 // most 64 columns and nnz < 2^31.
+// lmask[(g*nb + b)*2 + {0,1}]: bit q set = slot q holds more than `long_thresh` entries
+// of row block g ("long slot": processed by the whole workgroup instead of 4 lanes).
 void build_rowblock_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
                            const std::vector<int32_t>& order,
-                           const std::vector<int32_t>& batch_ptr, int G,
-                           std::vector<int32_t>& sp, std::vector<int32_t>& src) {
+                           const std::vector<int32_t>& batch_ptr, int G, int long_thresh,
+                           std::vector<int32_t>& sp, std::vector<int32_t>& src,
+                           std::vector<uint32_t>& lmask) {
     const int nb = (int)batch_ptr.size() - 1;
     const int64_t rows_per = (n + G - 1) / G > 0 ? (n + G - 1) / G : 1;
     sp.assign((size_t)G * nb * 65 + 1, 0);
@@ -148,6 +151,14 @@ void build_rowblock_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
         sp[t] = (int32_t)run;
         run += c;
     }
+    lmask.assign((size_t)G * nb * 2, 0u);
+    for (int g = 0; g < G; ++g)
+        for (int b = 0; b < nb; ++b) {
+            const size_t base = ((size_t)g * nb + b) * 65;
+            for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q)
+                if (sp[base + q + 1] - sp[base + q] > long_thresh)
+                    lmask[((size_t)g * nb + b) * 2 + (q >> 5)] |= (1u << (q & 31));
+        }
     src.resize((size_t)run);
     std::vector<int32_t> fill(sp.begin(), sp.end());
     for (int b = 0; b < nb; ++b)

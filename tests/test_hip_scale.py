@@ -170,3 +170,40 @@ def test_estimator_augment_and_warm_start(oracle):
     fm.fit(X, y, P_init=P_mid, w_init=w_mid, lams_init=np.ones(4))
     np.testing.assert_allclose(est.P_, fm.P_, rtol=0, atol=1e-9)
     np.testing.assert_allclose(est.w_, fm.w_, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("groups", [2, 64])
+def test_skewed_columns_long_slots(oracle, groups):
+    """Zipf-like data: a few features occur in 30-100 % of the rows, so their entries in one
+    row block exceed what a slot's 4 lanes keep in registers ("long slots": the whole
+    workgroup strides over them).  f64 engine vs oracle in the same coloured order, for
+    pcd (two regularizers, degree 2 and 3) and the persistent linear pass."""
+    rng = np.random.RandomState(4)
+    n, d = 4000, 120
+    cols = [sp.random(n, 1, density=dens, random_state=rng, data_rvs=rng.randn, format="csc")
+            for dens in ([1.0, 0.6, 0.3] + [0.01] * (d - 3))]
+    X = sp.hstack(cols, format="csc")[:, rng.permutation(d)].tocsr()
+    y = rng.randn(n)
+    for reg, degree, k in (("squaredl12", 2, 5), ("omegati", 3, 3), ("l1", 2, 4)):
+        eng, order, P0 = _engine(X.tocsc(), y, k, degree, "pcd", reg, "f64", "colored",
+                                 options={"prb_groups": groups})
+        assert eng.get_option("persistent_active") == 1
+        ic = np.arange(k, dtype=np.int32)
+        viol = []
+        for it in range(2):
+            v = eng.cd_linear_epoch(0.5)
+            for deg in list(range(2, degree)) + [degree]:
+                o = degree - deg if deg != degree else 0
+                v += eng.pcd_epoch(o, deg, 10.0, 1e-3, 1.0, ic)
+            viol.append(v)
+        P, w = eng.get_params()
+        yp = eng.get_y_pred()
+        eng.close()
+        fm = oracle.OracleFM(degree=degree, n_components=k, solver="pcd", regularizer=reg,
+                             alpha=0.5, beta=10.0, gamma=1e-3, tol=0, max_iter=2,
+                             feature_order=order)
+        fm.fit(X, y, P_init=P0, lams_init=np.ones(k))
+        np.testing.assert_allclose(viol, [h[0] for h in fm.history], rtol=1e-9)
+        np.testing.assert_allclose(P, fm.P_, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(w, fm.w_, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(yp, fm.y_pred_, rtol=0, atol=1e-8)

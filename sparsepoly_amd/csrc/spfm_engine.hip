@@ -177,6 +177,8 @@ struct spfm_engine {
     bool persistent = true;
     int prb_G = 64;
     bool prb_ready = false;
+    int prb_has_long = 0;
+    int prb_long = kPrbLong;  // entries per (workgroup, step, slot) above which a slot is "long"
     DevBuf prb_sp, prb_erow, prb_eval, prb_slab, prb_abort, prow_old, d_bptr, prb_stamps,
         prb_viol, prb_cn, prb_lmask;
     bool prb_stamp_on = false;
@@ -955,8 +957,10 @@ struct spfm_engine {
         if (prb_G < 1) prb_G = 1;
         std::vector<int32_t> sp, src;
         std::vector<uint32_t> lmask;
-        build_rowblock_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, prb_G, kPrbLong,
+        build_rowblock_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, prb_G, prb_long,
                               sp, src, lmask);
+        prb_has_long = 0;
+        for (uint32_t m : lmask) prb_has_long |= (m != 0u);
         HIPC(prb_lmask.alloc(sizeof(uint32_t) * lmask.size()));
         HIPC(hipMemcpyAsync(prb_lmask.p, lmask.data(), sizeof(uint32_t) * lmask.size(),
                             hipMemcpyHostToDevice, stream));
@@ -1000,6 +1004,7 @@ struct spfm_engine {
         a.desc = d_desc.as<ColDesc>();
         a.sp = prb_sp.as<int32_t>();
         a.lmask = prb_lmask.as<uint32_t>();
+        a.has_long = prb_has_long;
         a.erow = prb_erow.as<int32_t>();
         a.slab = prb_slab.as<double>();
         a.abort_flag = prb_abort.as<unsigned>();
@@ -1514,6 +1519,13 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->fuse_chain = value != 0;
     } else if (k == "persistent") {
         h->persistent = value != 0;
+        h->prb_ready = false;
+    } else if (k == "prb_long") {
+        if (value < 16) {
+            h->err = "prb_long must be >= 16";
+            return SPFM_ERR_INVALID;
+        }
+        h->prb_long = value;
         h->prb_ready = false;
     } else if (k == "prb_stamps") {
         h->prb_stamp_on = value != 0;

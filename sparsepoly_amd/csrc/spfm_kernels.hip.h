@@ -664,6 +664,7 @@ struct PrbArgs {
     const ColDesc* desc;   // columns in visiting order
     const int32_t* sp;     // [G][nb][65] slot boundaries into erow/eval
     const uint32_t* lmask; // [G][nb][2] bit q: slot q is "long" in this row block
+    int has_long;          // 0: no long slot anywhere in the schedule (masks not even read)
     const int32_t* erow;   // entry row ids, sorted by (workgroup, batch, slot, row)
     double* slab;          // [2][G][64][2]
     unsigned* abort_flag;  // [1]
@@ -778,8 +779,11 @@ __device__ __forceinline__ void prb_load_sp(const PrbArgs& a, int g, int b, int 
                                             int& e0, int& e1, unsigned long long& lmask) {
     e0 = 0;
     e1 = 0;
-    const uint32_t* lm = a.lmask + ((size_t)g * a.nb + b) * 2;
-    lmask = ((unsigned long long)lm[1] << 32) | (unsigned long long)lm[0];
+    lmask = 0ull;
+    if (a.has_long) {
+        const uint32_t* lm = a.lmask + ((size_t)g * a.nb + b) * 2;
+        lmask = ((unsigned long long)lm[1] << 32) | (unsigned long long)lm[0];
+    }
     if (slot < ncols && !((lmask >> slot) & 1ull)) {  // long slots: no per-lane entries
         const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
         e0 = spb[slot];
@@ -991,6 +995,9 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         double p_next = 0.0;
         int n2e0 = 0, n2e1 = 0;
         unsigned long long lm2 = 0ull;
+        // slot bounds + long-slot mask of step b+2: issued before the sweep so that the
+        // (scalar) mask load has landed long before the barrier's lgkmcnt(0)
+        if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
         if (!control) {
             PRB_WSTAMP(1)  // publish issue
             const bool ok = prb_collect_quarter<2>(a, b, wave - 1, lane, ncols, sh_quart);
@@ -1004,7 +1011,6 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 if (slot < c2 - c1) p_next = pold_sched[c1 + slot];
             }
         }
-        if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
         // B3: quarter sums in LDS.  Raw barrier: only LDS traffic must have landed; the
         // prefetch loads just issued stay in flight across it (a __syncthreads() would
         // add s_waitcnt vmcnt(0) and expose their HBM latency on every step).
@@ -1138,6 +1144,8 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
         double yh[PRB_PF];
         double wl = 0.0, cnl = 0.0;
         int jl = 0;
+        int n2e0 = 0, n2e1 = 0;
+        unsigned long long lm2 = 0ull;
         const unsigned long long lmu =
             ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(lm0 >> 32)) << 32) |
             (unsigned)__builtin_amdgcn_readfirstlane((int)lm0);
@@ -1196,15 +1204,14 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + slot) * 2;
                 prb_store_granule(sl, ag, prb_tag(b));
             }
+            if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
             const bool ok = prb_collect_quarter<1>(a, b, wave - 1, lane, ncols, sh_quart);
             if (!ok) *sh_ok = 0;
             if (b + 1 < a.nb) {
                 prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt);
             }
         }
-        int n2e0 = 0, n2e1 = 0;
-        unsigned long long lm2 = 0ull;
-        if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
+        if (control && b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // quarter sums in LDS
         if (!*sh_ok) break;
         if (control) {

@@ -26,6 +26,7 @@ Fixture families:
   g5  per-call regularizer traces (prox_cd / prox_bcd inputs -> outputs, caches)
   g6  anova_kernel / poly_predict, degree 2,3,4, sparse and dense
   g7  API behaviours (n_iter_ semantics, stale P_ in pbcd callbacks, messages)
+  g8  all-subsets model: the reference's own test cells + sparse trajectories
 """
 import contextlib
 import io
@@ -521,7 +522,98 @@ def gen_g7():
     save("g7_api.npz", **arr)
 
 
+# --------------------------------------------------------------------- g8
+def gen_g8():
+    """All-subsets model: replicas of the reference's own test cells
+    (tests/test_pcd.py:354-432, tests/test_pbcd.py:345-425) + a sparse case with
+    per-epoch trajectories driven through pcd_all / pbcd_all directly."""
+    from sparsepoly import SparseAllSubsetsClassifier, SparseAllSubsetsRegressor
+    from sparsepoly.kernels import all_subsets_kernel
+    from sparsepoly.optimizer import pbcd_all, pcd_all
+
+    rng = np.random.RandomState(1)
+    X = rng.randn(20, 4)
+    P = rng.randn(5, 4)
+    lams = rng.randn(5)
+    y_reg = poly_predict(X, P, lams, kernel="all-subsets")
+    out = {"X": X, "y": y_reg, "K": all_subsets_kernel(X, P), "P_true": P, "lams_true": lams}
+    cells = []
+    for solver, regs in (("pcd", ["l1", "omegati"]), ("pbcd", ["l1", "l21", "omegacs"])):
+        for regname in regs:
+            for mean in (True, False):
+                for loss in ("squared", "squared_hinge", "logistic"):
+                    common = dict(n_components=5, beta=1, gamma=1e-3, regularizer=regname,
+                                  warm_start=False, tol=1e-3, max_iter=5, random_state=0,
+                                  mean=mean, shuffle=False, solver=solver)
+                    if loss == "squared":
+                        est = SparseAllSubsetsRegressor(**common)
+                        yy = y_reg
+                    else:
+                        est = SparseAllSubsetsClassifier(loss=loss, **common)
+                        yy = np.sign(y_reg)
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        est.fit(X, yy)
+                    key = "%s|%s|mean%d|%s" % (solver, regname, int(mean), loss)
+                    cells.append(key)
+                    out["P|" + key] = est.P_.copy()
+                    out["n_iter|" + key] = np.array(est.n_iter_)
+                    out["pred|" + key] = est._get_output(X)
+    out["cells"] = np.array(cells)
+    # sparse case, epoch by epoch
+    Xs, ys = small_problem(n=250, d=50, density=0.12, seed=23)
+    Xs.data *= 0.5
+    n, d = Xs.shape
+    out["Xs_data"], out["Xs_indices"], out["Xs_indptr"] = Xs.data, Xs.indices, Xs.indptr
+    out["Xs_shape"] = np.array(Xs.shape)
+    out["ys"] = ys
+    names = []
+    for solver, regname, k in (("pcd", "omegati", 6), ("pcd", "l1", 6), ("pbcd", "omegacs", 6),
+                               ("pbcd", "l21", 6), ("pbcd", "l1", 5)):
+        for loss in ("squared", "logistic"):
+            yy = ys if loss == "squared" else np.where(ys > np.median(ys), 1.0, -1.0)
+            ds = get_dataset(Xs, order="fortran")
+            loss_obj = CLASSIFICATION_LOSSES[loss]
+            reg = REGULARIZATION[regname]()
+            P0 = 0.05 * np.random.RandomState(3).randn(k, d)
+            lam = np.sign(np.random.RandomState(4).randn(k))
+            y_pred = poly_predict(Xs, P0, lam, kernel="all-subsets")
+            beta, gamma, eta = 5.0, 0.01, 0.5
+            viols, losses = [], []
+            jf = np.arange(d, dtype=np.int32)
+            ic = np.arange(k, dtype=np.int32)
+            if solver == "pcd":
+                Pw = P0.copy()
+                A = np.ones(n)
+                reg.init_cache_pcd(-1, d, k)
+            else:
+                Pw = np.array(P0.T)
+                A = np.ones((n, k))
+                reg.init_cache_pbcd(-1, d, k)
+                grad, inv_ss, p_old = np.zeros(k), np.zeros(k), np.zeros(k)
+            for it in range(3):
+                if solver == "pcd":
+                    v = pcd_all.pcd_epoch(Pw, ds, yy, y_pred, lam, beta, gamma, eta, reg,
+                                          loss_obj, A, ic, jf)
+                else:
+                    v = pbcd_all.pbcd_epoch(Pw, ds, yy, y_pred, lam, beta, gamma, eta, reg,
+                                            loss_obj, A, grad, inv_ss, p_old, jf)
+                viols.append(v)
+                losses.append(sum(loss_obj.loss(y_pred[i], yy[i]) for i in range(n)))
+            key = "%s|%s|%s" % (solver, regname, loss)
+            names.append(key)
+            out["sP0|" + key] = P0
+            out["slams|" + key] = lam
+            out["sviol|" + key] = np.array(viols)
+            out["sloss|" + key] = np.array(losses)
+            out["sP|" + key] = Pw if solver == "pcd" else np.array(Pw.T)
+            out["sy_pred|" + key] = y_pred
+    out["scases"] = np.array(names)
+    out["smeta"] = np.array(json.dumps(dict(beta=5.0, gamma=0.01, eta0=0.5)))
+    save("g8_all_subsets.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for g in which:
         globals()["gen_" + g]()

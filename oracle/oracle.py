@@ -127,6 +127,20 @@ def lib():
         _dp, C.c_int, C.c_int64, C.c_int, _lp, _ip, _dp, _dp, _dp, _dp, C.c_int, C.c_double,
         C.c_double, C.c_double, C.c_void_p, C.c_int, _dp, _dp, C.c_int, _ip, C.c_int,
     ]
+    L.spo_pcd_all_epoch.restype = C.c_double
+    L.spo_pcd_all_epoch.argtypes = [
+        _dp, C.c_int, C.c_int64, C.c_int, _lp, _ip, _dp, _dp, _dp, _dp, C.c_double, C.c_double,
+        C.c_double, C.c_void_p, C.c_int, _dp, _ip, C.c_int, _ip, C.c_int,
+    ]
+    L.spo_pbcd_all_epoch.restype = C.c_double
+    L.spo_pbcd_all_epoch.argtypes = [
+        _dp, C.c_int, C.c_int64, C.c_int, _lp, _ip, _dp, _dp, _dp, _dp, C.c_double, C.c_double,
+        C.c_double, C.c_void_p, C.c_int, _dp, _ip, C.c_int,
+    ]
+    L.spo_all_subsets_predict_csr.restype = None
+    L.spo_all_subsets_predict_csr.argtypes = [
+        C.c_int64, _lp, _ip, _dp, _dp, C.c_int, C.c_int, _dp, _dp,
+    ]
     L.spo_anova_predict_csr.restype = None
     L.spo_anova_predict_csr.argtypes = [
         C.c_int64, _lp, _ip, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp,
@@ -280,6 +294,43 @@ def pbcd_epoch(P, X, y, y_pred, lams, degree, beta, gamma, eta, regularizer, los
         _d(y_pred), _d(lams), degree, float(beta), float(gamma), float(eta), regularizer._h,
         LOSSES[loss], _d(A), _d(dA), A.shape[1], _i(jf), jf.size,
     )
+
+
+def pcd_all_epoch(P, X, y, y_pred, lams, beta, gamma, eta, regularizer, loss, A,
+                  indices_component, indices_feature):
+    """optimizer/pcd_all.py:44-102.  P (k, d); A (n)."""
+    ic = np.ascontiguousarray(indices_component, dtype=np.int32)
+    jf = np.ascontiguousarray(indices_feature, dtype=np.int32)
+    return lib().spo_pcd_all_epoch(
+        _d(P), P.shape[0], X.n, X.d, _l(X.indptr), _i(X.indices), _d(X.data), _d(y),
+        _d(y_pred), _d(lams), float(beta), float(gamma), float(eta), regularizer._h,
+        LOSSES[loss], _d(A), _i(ic), ic.size, _i(jf), jf.size,
+    )
+
+
+def pbcd_all_epoch(P, X, y, y_pred, lams, beta, gamma, eta, regularizer, loss, A,
+                   indices_feature):
+    """optimizer/pbcd_all.py:68-132.  P (d, k); A (n, k)."""
+    jf = np.ascontiguousarray(indices_feature, dtype=np.int32)
+    return lib().spo_pbcd_all_epoch(
+        _d(P), P.shape[1], X.n, X.d, _l(X.indptr), _i(X.indices), _d(X.data), _d(y),
+        _d(y_pred), _d(lams), float(beta), float(gamma), float(eta), regularizer._h,
+        LOSSES[loss], _d(A), _i(jf), jf.size,
+    )
+
+
+def all_subsets_predict(X, P, lams):
+    """kernels.py:117-137,140-153 (kernel='all-subsets'): sum_s lams[s] prod_j (1 + x_ij p_sj)."""
+    Xr = sp.csr_matrix(X, dtype=np.float64)
+    indptr = np.ascontiguousarray(Xr.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(Xr.indices, dtype=np.int32)
+    data = np.ascontiguousarray(Xr.data, dtype=np.float64)
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    lams = np.ascontiguousarray(lams, dtype=np.float64)
+    out = np.zeros(Xr.shape[0])
+    lib().spo_all_subsets_predict_csr(Xr.shape[0], _l(indptr), _i(indices), _d(data), _d(P),
+                                      P.shape[0], P.shape[1], _d(lams), _d(out))
+    return out
 
 
 # --------------------------------------------------------------- kernels.py
@@ -507,3 +558,73 @@ class OracleFM(object):
                 break
         self.P_[:, :, :] = np.array(P.swapaxes(1, 2))
         return converged, it
+
+
+class OracleAllSubsets(object):
+    """Restatement of _BaseSparseAllSubsets.fit for solver pcd/pbcd
+    (sparse_all_subsets.py:80-272): P_ (k, d), no linear term, eta0 default 0.1."""
+
+    def __init__(self, loss="squared", n_components=2, solver="pcd", beta=1, gamma=1, eta0=0.1,
+                 mean=False, tol=1e-6, regularizer="omegati", init_lambdas="ones", max_iter=100,
+                 shuffle=False, random_state=None, feature_order=None):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+    def predict(self, X):
+        return all_subsets_predict(X, self.P_, self.lams_)
+
+    def fit(self, X, y, P_init=None, lams_init=None):
+        from sklearn.utils import check_random_state
+
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        n, d = X.shape
+        k = self.n_components
+        rng = check_random_state(self.random_state)
+        reg = Regularizer(self.regularizer)
+        self.P_ = (0.01 * rng.randn(k, d) if P_init is None
+                   else np.array(P_init, dtype=np.float64))
+        if lams_init is not None:
+            self.lams_ = np.array(lams_init, dtype=np.float64)
+        elif self.init_lambdas == "ones":
+            self.lams_ = np.ones(k)
+        else:
+            self.lams_ = np.sign(rng.randn(k))
+        ds = CSC(X)
+        y_pred = np.ascontiguousarray(self.predict(X))
+        beta = self.beta * n if self.mean else self.beta
+        gamma = self.gamma * n if self.mean else self.gamma
+        jf = (np.arange(d, dtype=np.int32) if self.feature_order is None
+              else np.array(self.feature_order, dtype=np.int32))
+        ic = np.arange(k, dtype=np.int32)
+        self.history = []
+        converged = False
+        it = 0
+        if self.solver == "pcd":
+            A = np.ones(n)
+            reg.init_cache_pcd(-1, d, k)
+            P = self.P_
+        else:
+            A = np.ones((n, k))
+            reg.init_cache_pbcd(-1, d, k)
+            P = np.ascontiguousarray(self.P_.T)
+        for it in range(self.max_iter):
+            if self.shuffle:
+                if self.solver == "pcd":
+                    rng.shuffle(ic)
+                rng.shuffle(jf)
+            if self.solver == "pcd":
+                viol = pcd_all_epoch(P, ds, y, y_pred, self.lams_, beta, gamma, self.eta0, reg,
+                                     self.loss, A, ic, jf)
+            else:
+                viol = pbcd_all_epoch(P, ds, y, y_pred, self.lams_, beta, gamma, self.eta0, reg,
+                                      self.loss, A, jf)
+            self.history.append((viol, loss_sum(self.loss, y_pred, y)))
+            if viol < self.tol:
+                converged = True
+                break
+        if self.solver == "pbcd":
+            self.P_[:, :] = P.T
+        self.y_pred_ = y_pred
+        self.n_iter_ = it
+        self.converged_ = converged
+        return self

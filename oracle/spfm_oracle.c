@@ -126,7 +126,8 @@ static void reg_alloc(spo_reg* r, int degree, int d, int k) {
     r->top_degree = degree;
     r->d = d;
     r->k = k;
-    r->ncache = degree + 1;
+    /* degree == -1 (all-subsets): the scalar _cache_all_subsets lives in cache[0] */
+    r->ncache = (degree > 0) ? degree + 1 : 2;
     r->abs_p = (double*)calloc((size_t)d, sizeof(double));
     r->norms = (double*)calloc((size_t)d, sizeof(double));
     r->cache = (double*)calloc((size_t)r->ncache, sizeof(double));
@@ -148,8 +149,9 @@ int spo_reg_init_cache_pcd(spo_reg* r, int degree, int d, int k) {
             reg_alloc(r, degree, d, k);
             return 0;
         case SPO_REG_OMEGATI:
-            if (degree <= 0) return -1;
+            if (degree <= 0 && degree != -1) return -1;
             reg_alloc(r, degree, d, k);
+            if (degree == -1) r->cache[0] = 1.0; /* omegati.py:54-55 */
             return 0;
         default:
             return -2;
@@ -170,9 +172,12 @@ int spo_reg_init_cache_pbcd(spo_reg* r, int degree, int d, int k) {
             r->cache[0] = 0;
             return 0;
         case SPO_REG_OMEGACS:
-            if (degree <= 0) return -1;
+            if (degree <= 0 && degree != -1) return -1;
             reg_alloc(r, degree, d, k);
-            r->dcache[1] = 1.0; /* omegacs.py:46 */
+            if (degree > 0)
+                r->dcache[1] = 1.0; /* omegacs.py:46 */
+            else
+                r->cache[0] = 1.0; /* omegacs.py:47-48 */
             return 0;
         default:
             return -2;
@@ -193,6 +198,13 @@ void spo_reg_compute_cache_pcd(spo_reg* r, const double* P, int degree, int s) {
             sum += r->abs_p[j];
         }
         r->cache[0] = sum; /* np.sum is pairwise: equal to ~1e-16 relative */
+    } else if (r->kind == SPO_REG_OMEGATI && degree == -1) { /* omegati.py:75-80 */
+        r->cache[0] = 1.0;
+        for (int j = 0; j < d; ++j) {
+            double a = fabs(ps[j]);
+            r->abs_p[j] = a;
+            r->cache[0] *= 1.0 + a;
+        }
     } else if (r->kind == SPO_REG_OMEGATI) {
         r->cache[0] = 1.0;
         for (int t = 1; t < r->ncache; ++t) r->cache[t] = 0.0;
@@ -215,8 +227,12 @@ void spo_reg_update_cache_pcd(spo_reg* r, const double* P, int degree, int s, in
         r->cache[0] += fabs(pv);
     } else if (r->kind == SPO_REG_OMEGATI) {
         double a = fabs(pv);
-        for (int deg = 1; deg < degree; ++deg)
-            r->cache[deg] = r->dcache[deg + 1] + r->dcache[deg] * a;
+        if (degree > 0) {
+            for (int deg = 1; deg < degree; ++deg)
+                r->cache[deg] = r->dcache[deg + 1] + r->dcache[deg] * a;
+        } else { /* all-subsets, omegati.py:87-88 */
+            r->cache[0] *= 1.0 + a;
+        }
         r->abs_p[j] = a;
     }
 }
@@ -238,12 +254,17 @@ double spo_reg_prox_cd(spo_reg* r, double p_sj, double strength, int degree, int
     /* OmegaTI */
     {
         double sg = (p_sj > 0) ? 1.0 : -1.0;
-        for (int deg = 2; deg <= degree; ++deg) {
-            r->dcache[deg] = r->cache[deg - 1];
-            r->dcache[deg] -= r->dcache[deg - 1] * r->abs_p[j];
-            if (r->dcache[deg] < 0) r->dcache[deg] = 0.0;
+        if (degree > 0) {
+            for (int deg = 2; deg <= degree; ++deg) {
+                r->dcache[deg] = r->cache[deg - 1];
+                r->dcache[deg] -= r->dcache[deg - 1] * r->abs_p[j];
+                if (r->dcache[deg] < 0) r->dcache[deg] = 0.0;
+            }
+            strength *= r->dcache[degree];
+        } else { /* all-subsets, omegati.py:100-102 */
+            r->cache[0] /= 1.0 + r->abs_p[j];
+            strength *= r->cache[0];
         }
-        strength *= r->dcache[degree];
         double m = fabs(p_sj) - strength;
         return sg * (m > 0 ? m : 0);
     }
@@ -264,6 +285,11 @@ static double row_l2_sqrt(const double* p, int k) {
 
 /* omegacs.py:52-62 (degree > 0 branch) */
 static void omegacs_recompute(spo_reg* r, int degree) {
+    if (degree <= 0) { /* all-subsets, omegacs.py:60-62 */
+        r->cache[0] = 1.0;
+        for (int j = 0; j < r->d; ++j) r->cache[0] *= 1.0 + r->norms[j];
+        return;
+    }
     for (int t = 1; t < r->ncache; ++t) r->cache[t] = 0.0;
     r->cache[0] = 1.0;
     for (int j = 0; j < r->d; ++j) {
@@ -297,6 +323,11 @@ void spo_reg_update_cache_pbcd(spo_reg* r, const double* P, int degree, int j) {
         r->cache[0] -= r->norms[j];
         r->norms[j] = row_l2_sqrt(pj, k);
         r->cache[0] += r->norms[j];
+    } else if (r->kind == SPO_REG_OMEGACS && degree == -1) { /* omegacs.py:77-81 */
+        double l2 = row_l2_sqrt(pj, k);
+        r->cache[0] *= 1.0 + l2;
+        r->norms[j] = l2;
+        if (r->cache[0] < 0) omegacs_recompute(r, -1);
     } else if (r->kind == SPO_REG_OMEGACS) {
         double l2 = row_l2_sqrt(pj, k);
         for (int deg = 1; deg <= degree; ++deg) {
@@ -353,6 +384,18 @@ void spo_reg_prox_bcd(spo_reg* r, double* p_j, double strength, int degree, int 
         return;
     }
     /* OmegaCS */
+    if (degree == -1) { /* all-subsets, omegacs.py:99-101,103-106 */
+        double l2 = row_l2_sqrt(p_j, k);
+        r->cache[0] /= 1.0 + r->norms[j];
+        strength *= r->cache[0];
+        if (l2 > strength) {
+            double f = 1 - strength / l2;
+            for (int s = 0; s < k; ++s) p_j[s] *= f;
+        } else {
+            for (int s = 0; s < k; ++s) p_j[s] = 0.0;
+        }
+        return;
+    }
     {
         double l2 = row_l2_sqrt(p_j, k);
         for (int deg = 2; deg <= degree; ++deg) {
@@ -608,6 +651,158 @@ double spo_pbcd_epoch(double* P, int k, int64_t n, int d, const int64_t* indptr,
     }
     free(grad);
     return sum_viol;
+}
+
+/* ------------------------------------------------------------ all-subsets */
+
+/* sparsepoly/optimizer/pcd_all.py:8-18 */
+void spo_pcd_all_precompute_A(int64_t n, int d, const int64_t* indptr, const int32_t* indices,
+                              const double* data, const double* p_s, double* A) {
+    for (int64_t i = 0; i < n; ++i) A[i] = 1.0;
+    for (int j = 0; j < d; ++j) {
+        const double p_sj = p_s[j];
+        for (int64_t ii = indptr[j]; ii < indptr[j + 1]; ++ii)
+            A[indices[ii]] *= 1.0 + p_sj * data[ii];
+    }
+}
+
+/* sparsepoly/optimizer/pcd_all.py:44-102 (with _update :21-41 inlined); A is (n) */
+double spo_pcd_all_epoch(double* P, int k, int64_t n, int d, const int64_t* indptr,
+                         const int32_t* indices, const double* data, const double* y,
+                         double* y_pred, const double* lams, double beta, double gamma,
+                         double eta, spo_reg* reg, int loss, double* A,
+                         const int32_t* indices_component, int n_comp,
+                         const int32_t* indices_feature, int n_feat) {
+    (void)k;
+    double sum_viol = 0;
+    const double mu = spo_loss_mu(loss);
+    for (int ss = 0; ss < n_comp; ++ss) {
+        const int s = indices_component[ss];
+        spo_pcd_all_precompute_A(n, d, indptr, indices, data, P + (size_t)s * d, A);
+        spo_reg_compute_cache_pcd(reg, P, -1, s);
+        const double lam = lams[s];
+        for (int jj = 0; jj < n_feat; ++jj) {
+            const int j = indices_feature[jj];
+            const int64_t b = indptr[j], e = indptr[j + 1];
+            const double p_sj_old = P[(size_t)s * d + j];
+            double update = 0, inv_step_size = 0;
+            for (int64_t ii = b; ii < e; ++ii) {
+                const int i = indices[ii];
+                const double x_ij = data[ii];
+                const double dA = x_ij * A[i] / (1.0 + x_ij * p_sj_old);
+                update += spo_dloss(loss, y_pred[i], y[i]) * dA;
+                inv_step_size += dA * dA;
+            }
+            inv_step_size *= mu;
+            inv_step_size += beta;
+            update *= lam;
+            update += beta * p_sj_old;
+            update /= inv_step_size;
+            double p_sj_new = p_sj_old - eta * update;
+            p_sj_new = spo_reg_prox_cd(reg, p_sj_new, eta * gamma / inv_step_size, -1, j);
+            update = p_sj_old - p_sj_new;
+            sum_viol += fabs(update);
+            P[(size_t)s * d + j] = p_sj_new;
+            for (int64_t ii = b; ii < e; ++ii) {
+                const int i = indices[ii];
+                const double x_ij = data[ii];
+                y_pred[i] -= lam * A[i];
+                A[i] /= 1.0 + x_ij * p_sj_old;
+                A[i] *= 1.0 + x_ij * p_sj_new;
+                y_pred[i] += lam * A[i];
+            }
+            spo_reg_update_cache_pcd(reg, P, -1, s, j);
+        }
+    }
+    return sum_viol;
+}
+
+/* sparsepoly/optimizer/pbcd_all.py:68-132 (with _update :23-65 inlined); P (d,k), A (n,k) */
+double spo_pbcd_all_epoch(double* P, int k, int64_t n, int d, const int64_t* indptr,
+                          const int32_t* indices, const double* data, const double* y,
+                          double* y_pred, const double* lams, double beta, double gamma,
+                          double eta, spo_reg* reg, int loss, double* A,
+                          const int32_t* indices_feature, int n_feat) {
+    double sum_viol = 0;
+    const double mu = spo_loss_mu(loss);
+    double* grad = (double*)malloc(sizeof(double) * (size_t)k * 3);
+    double* inv_step_sizes = grad + k;
+    double* p_j_old = grad + 2 * k;
+    for (int64_t i = 0; i < n * k; ++i) A[i] = 1.0; /* pbcd_all.py:9-20 */
+    for (int j = 0; j < d; ++j)
+        for (int64_t ii = indptr[j]; ii < indptr[j + 1]; ++ii) {
+            double* Ai = A + (size_t)indices[ii] * k;
+            const double x_ij = data[ii];
+            for (int s = 0; s < k; ++s) Ai[s] *= 1.0 + P[(size_t)j * k + s] * x_ij;
+        }
+    spo_reg_compute_cache_pbcd(reg, P, -1);
+    for (int jj = 0; jj < n_feat; ++jj) {
+        const int j = indices_feature[jj];
+        const int64_t b = indptr[j], e = indptr[j + 1];
+        double* p_j = P + (size_t)j * k;
+        for (int s = 0; s < k; ++s) {
+            p_j_old[s] = p_j[s];
+            grad[s] = 0.0;
+            inv_step_sizes[s] = 0.0;
+        }
+        for (int64_t ii = b; ii < e; ++ii) {
+            const int i = indices[ii];
+            const double x_ij = data[ii];
+            const double dl = spo_dloss(loss, y_pred[i], y[i]);
+            const double* Ai = A + (size_t)i * k;
+            for (int s = 0; s < k; ++s) {
+                const double dA = x_ij * Ai[s] / (1.0 + x_ij * p_j[s]);
+                grad[s] += dl * dA;
+                inv_step_sizes[s] += dA * dA;
+            }
+        }
+        for (int s = 0; s < k; ++s) grad[s] *= lams[s];
+        for (int s = 0; s < k; ++s) grad[s] += beta * p_j[s];
+        double inv_step_size = 0;
+        for (int s = 0; s < k; ++s) inv_step_size += inv_step_sizes[s];
+        inv_step_size *= mu;
+        inv_step_size += beta;
+        for (int s = 0; s < k; ++s) grad[s] /= inv_step_size;
+        for (int s = 0; s < k; ++s) p_j[s] -= eta * grad[s];
+        spo_reg_prox_bcd(reg, p_j, eta * gamma / inv_step_size, -1, j);
+        for (int64_t ii = b; ii < e; ++ii) {
+            const int i = indices[ii];
+            const double x_ij = data[ii];
+            double* Ai = A + (size_t)i * k;
+            double dot = 0.0;
+            for (int s = 0; s < k; ++s) dot += lams[s] * Ai[s];
+            y_pred[i] -= dot;
+            for (int s = 0; s < k; ++s) {
+                Ai[s] /= 1.0 + x_ij * p_j_old[s];
+                Ai[s] *= 1.0 + x_ij * p_j[s];
+            }
+            dot = 0.0;
+            for (int s = 0; s < k; ++s) dot += lams[s] * Ai[s];
+            y_pred[i] += dot;
+        }
+        spo_reg_update_cache_pbcd(reg, P, -1, j);
+        double l1 = 0.0;
+        for (int s = 0; s < k; ++s) l1 += fabs(p_j_old[s] - p_j[s]);
+        sum_viol += l1;
+    }
+    free(grad);
+    return sum_viol;
+}
+
+/* kernels.py:117-137 all_subsets_kernel + poly_predict: out[i] = sum_s lams[s] prod_j (1 + x_ij p_sj) */
+void spo_all_subsets_predict_csr(int64_t n, const int64_t* indptr, const int32_t* indices,
+                                 const double* data, const double* P, int k, int d,
+                                 const double* lams, double* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int s = 0; s < k; ++s) {
+            double a = 1.0;
+            for (int64_t ii = indptr[i]; ii < indptr[i + 1]; ++ii)
+                a *= 1 + data[ii] * P[(size_t)s * d + indices[ii]];
+            acc += a * lams[s];
+        }
+        out[i] = acc;
+    }
 }
 
 /* -------------------------------------------------------- ANOVA predict */

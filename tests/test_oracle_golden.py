@@ -293,3 +293,54 @@ def test_g7_api_facts(oracle):
     np.testing.assert_allclose(fm.lams_, z["shuffle_lams"])
     np.testing.assert_allclose(fm.P_, z["shuffle_P"], rtol=0, atol=TOL)
     np.testing.assert_allclose(fm.w_, z["shuffle_w"], rtol=0, atol=TOL)
+
+
+# ---------------------------------------------------------------- all-subsets (N2)
+def _g8_cells():
+    return [str(c) for c in load_golden("g8_all_subsets.npz")["cells"]]
+
+
+@pytest.mark.parametrize("cell", _g8_cells())
+def test_g8_all_subsets_reference_cells(oracle, cell):
+    """Replicas of reference tests/test_pcd.py:354-432 and tests/test_pbcd.py:345-425."""
+    z = load_golden("g8_all_subsets.npz")
+    solver, regname, mean, loss = cell.split("|")
+    y = z["y"] if loss == "squared" else np.sign(z["y"])
+    fm = oracle.OracleAllSubsets(loss=loss, n_components=5, solver=solver, beta=1, gamma=1e-3,
+                                 regularizer=regname, tol=1e-3, max_iter=5, random_state=0,
+                                 mean=bool(int(mean[4:])))
+    fm.fit(z["X"], y)
+    np.testing.assert_allclose(fm.P_, z["P|" + cell], rtol=0, atol=TOL)
+    assert fm.n_iter_ == int(z["n_iter|" + cell])
+    np.testing.assert_allclose(fm.predict(z["X"]), z["pred|" + cell], rtol=0, atol=1e-9)
+
+
+def _g8_scases():
+    return [str(c) for c in load_golden("g8_all_subsets.npz")["scases"]]
+
+
+@pytest.mark.parametrize("case", _g8_scases())
+def test_g8_all_subsets_sparse_trajectories(oracle, case):
+    import scipy.sparse as sp
+
+    z = load_golden("g8_all_subsets.npz")
+    X = sp.csr_matrix((z["Xs_data"], z["Xs_indices"], z["Xs_indptr"]),
+                      shape=tuple(int(v) for v in z["Xs_shape"]))
+    solver, regname, loss = case.split("|")
+    meta = json.loads(str(z["smeta"]))
+    ys = z["ys"]
+    y = ys if loss == "squared" else np.where(ys > np.median(ys), 1.0, -1.0)
+    fm = oracle.OracleAllSubsets(loss=loss, n_components=z["sP0|" + case].shape[0],
+                                 solver=solver, beta=meta["beta"], gamma=meta["gamma"],
+                                 eta0=meta["eta0"], regularizer=regname, tol=0, max_iter=3)
+    fm.fit(X, y, P_init=z["sP0|" + case], lams_init=z["slams|" + case])
+    np.testing.assert_allclose([h[0] for h in fm.history], z["sviol|" + case], rtol=1e-10)
+    np.testing.assert_allclose([h[1] for h in fm.history], z["sloss|" + case], rtol=1e-10)
+    np.testing.assert_allclose(fm.P_, z["sP|" + case], rtol=0, atol=TOL)
+    np.testing.assert_allclose(fm.y_pred_, z["sy_pred|" + case], rtol=0, atol=1e-9)
+
+
+def test_g8_all_subsets_kernel(oracle):
+    z = load_golden("g8_all_subsets.npz")
+    got = oracle.all_subsets_predict(z["X"], z["P_true"], z["lams_true"])
+    np.testing.assert_allclose(got, z["K"] @ z["lams_true"], rtol=0, atol=1e-12)

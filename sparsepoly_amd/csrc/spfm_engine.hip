@@ -488,11 +488,20 @@ struct spfm_engine {
         if (reg_ < 0 || reg_ > 5) FAIL(SPFM_ERR_INVALID, "Regularizer not supported.");
         if (solver_ != SPFM_SOLVER_PCD && solver_ != SPFM_SOLVER_PBCD)
             FAIL(SPFM_ERR_INVALID, "Solver is not supported.");
-        if (top_degree_ < 2)
-            FAIL(SPFM_ERR_UNSUPPORTED, "degree must be >= 2 for the factorization-machine path");
+        const bool all_subsets = top_degree_ == -1;  // regularizers are called with degree = -1
+        if (!all_subsets && top_degree_ < 2)
+            FAIL(SPFM_ERR_UNSUPPORTED, "degree must be >= 2 (factorization machine) or -1 (all-subsets)");
         if (top_degree_ > SPFM_MAX_DEGREE)
             FAIL(SPFM_ERR_UNSUPPORTED, "degree > 6 is not supported by the HIP engine");
-        if (solver_ == SPFM_SOLVER_PCD) {
+        if (all_subsets) {
+            // sparse_all_subsets.py:33-38: l1 / l21 / omegacs / omegati
+            const bool ok_pcd = (reg_ == SPFM_REG_L1 || reg_ == SPFM_REG_OMEGATI);
+            const bool ok_pbcd = (reg_ == SPFM_REG_L1 || reg_ == SPFM_REG_L21 || reg_ == SPFM_REG_OMEGACS);
+            if ((solver_ == SPFM_SOLVER_PCD && !ok_pcd) || (solver_ == SPFM_SOLVER_PBCD && !ok_pbcd))
+                FAIL(SPFM_ERR_INVALID, "this regularizer cannot be used with this solver (all-subsets)");
+            if (solver_ == SPFM_SOLVER_PBCD && k > 256)
+                FAIL(SPFM_ERR_UNSUPPORTED, "pbcd: n_components > 256 not supported");
+        } else if (solver_ == SPFM_SOLVER_PCD) {
             // init_cache_pcd exists only for l1 / squaredl12 / omegati (README.md:28-32)
             if (reg_ != SPFM_REG_L1 && reg_ != SPFM_REG_SQUAREDL12 && reg_ != SPFM_REG_OMEGATI)
                 FAIL(SPFM_ERR_INVALID, "this regularizer cannot be used with solver='pcd'");
@@ -522,7 +531,7 @@ struct spfm_engine {
         HIPC(hipMemcpyAsync(dcache.p, hd, sizeof(double) * ncache, hipMemcpyHostToDevice, stream));
         // pcd keeps the caches of ALL components (one precompute pass per epoch): same
         // footprint as pbcd's (n, (m-1), k) tensor
-        const size_t arow = (size_t)(top_degree - 1) * k;
+        const size_t arow = (size_t)(top_degree > 0 ? top_degree - 1 : 1) * k;
         HIPC(A.alloc(tsize() * (size_t)(n > 0 ? n : 1) * arow));
         HIPC(ctl.alloc(sizeof(Ctl)));
         HIPC(hipMemsetAsync(ctl.p, 0, sizeof(Ctl), stream));
@@ -660,6 +669,7 @@ struct spfm_engine {
     int anova_dispatch(int M, int64_t rows, const int64_t* rp, const int32_t* ri, const T* rv,
                        const double* Pt_o, double* out) {
         switch (M) {
+            case 0: launch_anova<T, 0>(rows, rp, ri, rv, Pt_o, out); break;
             case 2: launch_anova<T, 2>(rows, rp, ri, rv, Pt_o, out); break;
             case 3: launch_anova<T, 3>(rows, rp, ri, rv, Pt_o, out); break;
             case 4: launch_anova<T, 4>(rows, rp, ri, rv, Pt_o, out); break;
@@ -682,7 +692,7 @@ struct spfm_engine {
         rc = ensure_pt();
         if (rc) return rc;
         HIPC(hipMemsetAsync(out, 0, sizeof(double) * (size_t)rows, stream));
-        rc = anova_dispatch<T>(degree, rows, rp, ri, rv, Pt.as<double>(), out);
+        rc = anova_dispatch<T>(kind_of(degree), rows, rp, ri, rv, Pt.as<double>(), out);
         if (rc) return rc;
         if (add_lower) {
             if (n_orders < 2) FAIL(SPFM_ERR_INVALID, "add_lower_deg2 needs P_[1]");
@@ -899,7 +909,7 @@ struct spfm_engine {
         double* cbuf[2] = {cache.as<double>(), cache.as<double>() + (kMaxDegree + 2)};
         hipLaunchKernelGGL(begin_pass_kernel, dim3(1), dim3(64), 0, stream, c,
                            comp_order.as<int32_t>(), lams.as<double>());
-        const size_t a_stride = (size_t)n * (M - 1);
+        const size_t a_stride = (size_t)n * Kind<M>::AS;
         if (reg != SPFM_REG_L1)
             hipLaunchKernelGGL((pcd_compute_cache_kernel<M>), dim3(1), dim3(kBlock), 0, stream, c,
                                Po, d, reg, cbuf[0]);
@@ -1033,7 +1043,7 @@ struct spfm_engine {
         prof_begin(0, nnz);
         hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS>), dim3(prb_G), dim3(kPrbThreads), kPrbLds,
                            stream, c, prb_args(), prb_eval.as<T>(), A.as<T>(),
-                           (size_t)n * (M - 1), yy.as<T>(), prow_old.as<double>(), Po, d, reg, cb,
+                           (size_t)n * Kind<M>::AS, yy.as<T>(), prow_old.as<double>(), Po, d, reg, cb,
                            mu, beta, gamma, eta, prb_viol.as<double>());
         prof_end(0);
         hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
@@ -1057,6 +1067,7 @@ struct spfm_engine {
     template <typename T>
     int pcd_prb_dispatch(int M, int order_idx, double beta, double gamma, double eta) {
         switch (M) {
+            case 0: return pcd_prb_loss<T, 0>(order_idx, beta, gamma, eta);
             case 2: return pcd_prb_loss<T, 2>(order_idx, beta, gamma, eta);
             case 3: return pcd_prb_loss<T, 3>(order_idx, beta, gamma, eta);
             case 4: return pcd_prb_loss<T, 4>(order_idx, beta, gamma, eta);
@@ -1079,6 +1090,12 @@ struct spfm_engine {
         return SPFM_OK;
     }
 
+    // template parameter for a reference degree: -1 (all-subsets) -> 0
+    static int kind_of(int degree) { return degree == -1 ? 0 : degree; }
+    bool degree_ok(int degree) const {
+        return top_degree == -1 ? degree == -1 : (degree >= 2 && degree <= top_degree);
+    }
+
     // one precompute pass for all components (A_all[s][i][m-1]); needs P^T
     template <typename T, int M>
     int pcd_precompute_all(int order_idx) {
@@ -1086,7 +1103,7 @@ struct spfm_engine {
         pt_valid = false;
         int rc = ensure_pt();
         if (rc) return rc;
-        const size_t lds = sizeof(T) * (size_t)(M - 1) * kWave * 33;
+        const size_t lds = sizeof(T) * (size_t)Kind<M>::AS * kWave * 33;
         HIPC(hipFuncSetAttribute((const void*)pcd_precompute_all_kernel<T, M>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int64_t tiles = (n + 31) / 32;
@@ -1100,6 +1117,7 @@ struct spfm_engine {
     template <typename T>
     int pcd_precompute_all_dispatch(int M, int order_idx) {
         switch (M) {
+            case 0: return pcd_precompute_all<T, 0>(order_idx);
             case 2: return pcd_precompute_all<T, 2>(order_idx);
             case 3: return pcd_precompute_all<T, 3>(order_idx);
             case 4: return pcd_precompute_all<T, 4>(order_idx);
@@ -1112,6 +1130,7 @@ struct spfm_engine {
     template <typename T>
     int pcd_pass_dispatch(int M, int order_idx, double beta, double gamma, double eta) {
         switch (M) {
+            case 0: return pcd_pass_body<T, 0>(order_idx, beta, gamma, eta);
             case 2: return pcd_pass_body<T, 2>(order_idx, beta, gamma, eta);
             case 3: return pcd_pass_body<T, 3>(order_idx, beta, gamma, eta);
             case 4: return pcd_pass_body<T, 4>(order_idx, beta, gamma, eta);
@@ -1127,7 +1146,7 @@ struct spfm_engine {
         if (rc) return rc;
         if (solver != SPFM_SOLVER_PCD) FAIL(SPFM_ERR_INVALID, "engine is not configured for pcd");
         if (order_idx < 0 || order_idx >= n_orders) FAIL(SPFM_ERR_INVALID, "bad order index");
-        if (degree < 2 || degree > top_degree) FAIL(SPFM_ERR_INVALID, "bad degree");
+        if (!degree_ok(degree)) FAIL(SPFM_ERR_INVALID, "bad degree");
         if (!ic || n_comp < 0 || n_comp > k) FAIL(SPFM_ERR_INVALID, "bad indices_component");
         for (int q = 0; q < n_comp; ++q)
             if (ic[q] < 0 || ic[q] >= k) FAIL(SPFM_ERR_INVALID, "indices_component out of range");
@@ -1140,19 +1159,20 @@ struct spfm_engine {
         HIPC(hipMemsetAsync(ctl.p, 0, sizeof(Ctl), stream));
         const std::string key = fkey("pcd", {beta, gamma, eta},
                                      {order_idx, degree, loss, reg, sched_version});
-        rc = dtype == SPFM_F32 ? pcd_precompute_all_dispatch<float>(degree, order_idx)
-                               : pcd_precompute_all_dispatch<double>(degree, order_idx);
+        const int M = kind_of(degree);
+        rc = dtype == SPFM_F32 ? pcd_precompute_all_dispatch<float>(M, order_idx)
+                               : pcd_precompute_all_dispatch<double>(M, order_idx);
         if (rc) return rc;
         const bool use_prb = prb_usable();
         for (int pass = 0; pass < n_comp; ++pass) {
             if (use_prb) {
-                rc = dtype == SPFM_F32 ? pcd_prb_dispatch<float>(degree, order_idx, beta, gamma, eta)
-                                       : pcd_prb_dispatch<double>(degree, order_idx, beta, gamma, eta);
+                rc = dtype == SPFM_F32 ? pcd_prb_dispatch<float>(M, order_idx, beta, gamma, eta)
+                                       : pcd_prb_dispatch<double>(M, order_idx, beta, gamma, eta);
             } else {
                 rc = run_cached(key, [&]() {
                     return dtype == SPFM_F32
-                               ? pcd_pass_dispatch<float>(degree, order_idx, beta, gamma, eta)
-                               : pcd_pass_dispatch<double>(degree, order_idx, beta, gamma, eta);
+                               ? pcd_pass_dispatch<float>(M, order_idx, beta, gamma, eta)
+                               : pcd_pass_dispatch<double>(M, order_idx, beta, gamma, eta);
                 });
             }
             if (rc) return rc;
@@ -1200,7 +1220,7 @@ struct spfm_engine {
                                delta.as<double>(), pold.as<double>(), pb_scal.as<double>());
             if (chained)
                 hipLaunchKernelGGL((pbcd_chain_kernel<M>), dim3(1), dim3(kWave), 0, stream, desc,
-                                   nc, d, reg, rs, top_degree + 1, pb_scal.as<double>());
+                                   nc, d, reg, rs, top_degree > 0 ? top_degree + 1 : 1, pb_scal.as<double>());
             prof_begin(3, bn);
             hipLaunchKernelGGL((pbcd_sync_kernel<T, M, L, C>), dim3(nc * kPbW), dim3(kBlock), 0,
                                stream, desc, cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
@@ -1225,6 +1245,7 @@ struct spfm_engine {
     template <typename T>
     int pbcd_dispatch(int M, int order_idx, double beta, double gamma, double eta) {
         switch (M) {
+            case 0: return pbcd_body<T, 0>(order_idx, beta, gamma, eta);
             case 2: return pbcd_body<T, 2>(order_idx, beta, gamma, eta);
             case 3: return pbcd_body<T, 3>(order_idx, beta, gamma, eta);
             case 4: return pbcd_body<T, 4>(order_idx, beta, gamma, eta);
@@ -1240,15 +1261,15 @@ struct spfm_engine {
         if (rc) return rc;
         if (solver != SPFM_SOLVER_PBCD) FAIL(SPFM_ERR_INVALID, "engine is not configured for pbcd");
         if (order_idx < 0 || order_idx >= n_orders) FAIL(SPFM_ERR_INVALID, "bad order index");
-        if (degree < 2 || degree > top_degree) FAIL(SPFM_ERR_INVALID, "bad degree");
+        if (!degree_ok(degree)) FAIL(SPFM_ERR_INVALID, "bad degree");
         rc = ensure_pt();
         if (rc) return rc;
         p_valid = false;
         const std::string key = fkey("pbcd", {beta, gamma, eta},
                                      {order_idx, degree, loss, reg, sched_version});
         rc = run_cached(key, [&]() {
-            return dtype == SPFM_F32 ? pbcd_dispatch<float>(degree, order_idx, beta, gamma, eta)
-                                     : pbcd_dispatch<double>(degree, order_idx, beta, gamma, eta);
+            return dtype == SPFM_F32 ? pbcd_dispatch<float>(kind_of(degree), order_idx, beta, gamma, eta)
+                                     : pbcd_dispatch<double>(kind_of(degree), order_idx, beta, gamma, eta);
         });
         if (rc) return rc;
         return epoch_epilogue(viol);

@@ -129,6 +129,29 @@ struct Vec2<double> {
     using type = double2;
 };
 
+// Model kind by template parameter M: M >= 2 = factorization machine of degree M (ANOVA
+// kernel, caches A[i, 1..M-1]); M == 0 = all-subsets model (kernel prod_j (1 + p_j x_j),
+// one cache value A[i] per component; reference optimizer/pcd_all.py, pbcd_all.py,
+// regularizers called with degree = -1).
+template <int M>
+struct Kind {
+    static constexpr int AS = (M == 0) ? 1 : (M - 1);  // cache values per (row, component)
+};
+
+// dA_{M-1} of pcd._grad_anova (pcd.py:8-12) or the all-subsets derivative
+// x A / (1 + x p) (pcd_all.py:28) from the cache values a[0..AS)
+template <int M>
+__device__ __forceinline__ double grad_factor(const double* a, double x, double p) {
+    if constexpr (M == 0) {
+        return x * a[0] / (1.0 + x * p);
+    } else {
+        double dprev = x;
+#pragma unroll
+        for (int t = 1; t < M; ++t) dprev = x * (a[t - 1] - p * dprev);
+        return dprev;
+    }
+}
+
 // ------------------------------------------------------------ control kernels
 
 __global__ void begin_pass_kernel(Ctl* ctl, const int32_t* comp_order, const double* lams) {
@@ -170,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void pcd_precompute_all_kernel(
     constexpr int R = 32;       // rows per tile
     constexpr int RP = R + 1;   // padded row stride in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char pre_lds[];
-    T* tile = reinterpret_cast<T*>(pre_lds);  // [(M-1)][64][RP]
+    T* tile = reinterpret_cast<T*>(pre_lds);  // [AS][64][RP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int64_t tile0 = (int64_t)blockIdx.x * R; tile0 < n; tile0 += (int64_t)gridDim.x * R) {
         for (int s0 = 0; s0 < k; s0 += kWave) {
@@ -179,10 +202,11 @@ __global__ __launch_bounds__(kBlock) void pcd_precompute_all_kernel(
             for (int r = wave; r < R; r += kBlock / kWave) {
                 const int64_t i = tile0 + r;
                 if (i >= n) break;
-                double a[M];
+                constexpr int NA = (M == 0) ? 2 : M;
+                double a[NA];
                 a[0] = 1.0;
 #pragma unroll
-                for (int t = 1; t < M; ++t) a[t] = 0.0;
+                for (int t = 1; t < NA; ++t) a[t] = (M == 0) ? 1.0 : 0.0;  // M==0: a[1] = product
                 const int64_t b = rptr[i], e = rptr[i + 1];
                 for (int64_t c = b; c < e; c += kWave) {
                     const int cnt = (int)((e - c < kWave) ? (e - c) : kWave);
@@ -206,24 +230,29 @@ __global__ __launch_bounds__(kBlock) void pcd_precompute_all_kernel(
                                         __float_as_int(my_xf), q + u));
                                 else
                                     x = readlane_d(my_xd, q + u);
+                                if constexpr (M == 0) {
+                                    a[1] *= 1.0 + pv[u] * x;  // pcd_all.py:18
+                                } else {
 #pragma unroll
-                                for (int t = M - 1; t >= 1; --t) a[t] += a[t - 1] * pv[u] * x;
+                                    for (int t = M - 1; t >= 1; --t) a[t] += a[t - 1] * pv[u] * x;
+                                }
                             }
                         }
                     }
                 }
 #pragma unroll
-                for (int t = 1; t < M; ++t) tile[((t - 1) * kWave + lane) * RP + r] = (T)a[t];
+                for (int t = 1; t <= Kind<M>::AS; ++t)
+                    tile[((t - 1) * kWave + lane) * RP + r] = (T)a[t];
             }
             __syncthreads();
-            const int per_s = R * (M - 1);
+            constexpr int AS = Kind<M>::AS;
+            const int per_s = R * AS;
             for (int idx = tid; idx < kWave * per_s; idx += kBlock) {
                 const int sl = idx / per_s, rem = idx - sl * per_s;
-                const int r = rem / (M - 1), t1 = rem - r * (M - 1);
+                const int r = rem / AS, t1 = rem - r * AS;
                 const int64_t i = tile0 + r;
                 if (s0 + sl < k && i < n)
-                    A_all[((size_t)(s0 + sl) * n + i) * (M - 1) + t1] =
-                        tile[(t1 * kWave + sl) * RP + r];
+                    A_all[((size_t)(s0 + sl) * n + i) * AS + t1] = tile[(t1 * kWave + sl) * RP + r];
             }
             __syncthreads();
         }
@@ -256,6 +285,18 @@ __global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __
         return;
     }
     if (reg != REG_OMEGATI) return;
+    if constexpr (M == 0) {  // omegati.py:75-80: _cache_all_subsets = prod_j (1 + |p_sj|)
+        double pr = 1.0;
+        for (int j = tid; j < d; j += kBlock) pr *= 1.0 + fabs(ps[j]);
+        sh[tid] = pr;
+        __syncthreads();
+        for (int half = kBlock / 2; half >= 1; half >>= 1) {
+            if (tid < half) sh[tid] *= sh[tid + half];
+            __syncthreads();
+        }
+        if (tid == 0) cache[0] = sh[0];
+        return;
+    }
     double c[M + 1];
     c[0] = 1.0;
 #pragma unroll
@@ -308,17 +349,16 @@ __global__ __launch_bounds__(kBlock) void pcd_grad_kernel(
     const T* __restrict__ A = A_all + (size_t)ctl->s * a_stride;
     const double p = P[(size_t)ctl->s * d + cd.j];
     const int64_t b = cd.start, e = cd.start + cd.len;
+    constexpr int AS = Kind<M>::AS;
     double g = 0.0, h = 0.0;
     for (int64_t ii = b + threadIdx.x; ii < e; ii += kBlock) {
         const int i = cidx[ii];
         const double x = (double)cval[ii];
         const typename Vec2<T>::type yv = yy[i];
-        double dprev = x;  // dA[0]
+        double a[AS];
 #pragma unroll
-        for (int t = 1; t < M; ++t) {
-            const double a = (double)A[(size_t)i * (M - 1) + (t - 1)];
-            dprev = x * (a - p * dprev);
-        }
+        for (int t = 0; t < AS; ++t) a[t] = (double)A[(size_t)i * AS + t];
+        const double dprev = grad_factor<M>(a, x, p);
         g += dloss_dev(loss, (double)yv.x, (double)yv.y) * dprev;
         h += dprev * dprev;
     }
@@ -424,7 +464,23 @@ __device__ __forceinline__ double pcd_chain_lanes(int reg, int lane, int last, b
     {
         const double apin = fabs(pin);
         const double sg = (pin > 0) ? 1.0 : -1.0;
-        if (M == 2) {
+        if constexpr (M == 0) {
+            // all-subsets (omegati.py:100-102, 87-88): c /= 1 + |p_old|; strength *= c;
+            // soft-threshold; c *= 1 + |p_new| -- multiplicative, so a plain serial loop
+            double c = cache[0];
+            for (int i = 0; i <= last; ++i) {
+                const double ai = readlane_d(ab, i), si = readlane_d(st, i),
+                             pi = readlane_d(apin, i);
+                c /= 1.0 + ai;
+                const double m = pi - si * c;
+                const double r = (m > 0) ? m : 0.0;
+                c *= 1.0 + r;
+                if (lane == i) mine = r;
+            }
+            cache[0] = c;
+            return sg * mine;
+        }
+        if constexpr (M == 2) {
             // degree 2: u = max(c - a, 0); r = max(p - s u, 0); c' = u + r  (dcache[1] = 1)
             const double c0 = cache[1];
             const bool act = valid && lane <= last;
@@ -462,6 +518,7 @@ __device__ __forceinline__ double pcd_chain_lanes(int reg, int lane, int last, b
             cache[1] = readlane_d(al, last) * c0 + readlane_d(be, last);
             return sg * r;
         }
+        if constexpr (M > 2)
         for (int i = 0; i <= last; ++i) {
             const double ai = readlane_d(ab, i), si = readlane_d(st, i), pi = readlane_d(apin, i);
             double dc[M + 2];
@@ -535,6 +592,17 @@ template <typename T, int M>
 __device__ __forceinline__ void pcd_sync_entry(size_t i, double x, double p_old, double upd,
                                                double lam, T* __restrict__ A,
                                                T* __restrict__ yy) {
+    if constexpr (M == 0) {  // pcd_all.py:92-98
+        const double a0 = (double)A[i];
+        double yh = (double)yy[2 * i];
+        yh -= lam * a0;
+        double a1 = a0 / (1.0 + x * p_old);
+        a1 *= 1.0 + x * (p_old - upd);
+        yh += lam * a1;
+        A[i] = (T)a1;
+        yy[2 * i] = (T)yh;
+        return;
+    }
     double dprev = x;
 #pragma unroll
     for (int t = 1; t < M; ++t) {
@@ -881,7 +949,8 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         const int c4 = (b + 4 <= a.nb) ? a.bptr[b + 4] : c3;  // used two steps from now
         // ---- phase 1 (workers): gather the rows of the prefetched entries, partial sums
         // (pcd.py:52-59); A / yhat values stay in registers for phase 3
-        double av[PRB_PF][M > 1 ? M - 1 : 1];
+        constexpr int AS = Kind<M>::AS;
+        double av[PRB_PF][AS];
         double yh[PRB_PF], yt[PRB_PF], dlast[PRB_PF];
         double pl = 0.0;
         int jl = 0;
@@ -898,15 +967,12 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 yh[u] = (double)yv.x;
                 yt[u] = (double)yv.y;
 #pragma unroll
-                for (int t = 1; t < M; ++t) av[u][t - 1] = (double)A[i * (M - 1) + (t - 1)];
+                for (int t = 0; t < AS; ++t) av[u][t] = (double)A[i * AS + t];
             }
             double ag = 0.0, ah = 0.0;
 #pragma unroll
             for (int u = 0; u < PRB_PF; ++u) {
-                const double x = (double)cur.x[u];
-                double dprev = x;
-#pragma unroll
-                for (int t = 1; t < M; ++t) dprev = x * (av[u][t - 1] - p_slot * dprev);
+                const double dprev = grad_factor<M>(av[u], (double)cur.x[u], p_slot);
                 dlast[u] = dprev;
                 const double dl = dloss_dev(LOSS, yh[u], yt[u]);
                 const bool v = cur.e0 + sub + 4 * u < cur.e1;
@@ -917,12 +983,10 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 const int i = a.erow[e];
                 const double x = (double)eval[e];
                 const typename Vec2<T>::type yv = yy2[i];
-                double dprev = x;
+                double a1[AS];
 #pragma unroll
-                for (int t = 1; t < M; ++t) {
-                    const double a1 = (double)A[(size_t)i * (M - 1) + (t - 1)];
-                    dprev = x * (a1 - p_slot * dprev);
-                }
+                for (int t = 0; t < AS; ++t) a1[t] = (double)A[(size_t)i * AS + t];
+                const double dprev = grad_factor<M>(a1, x, p_slot);
                 ag += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * dprev;
                 ah += dprev * dprev;
             }
@@ -960,12 +1024,11 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                         const int i = a.erow[e];
                         const double x = (double)eval[e];
                         const typename Vec2<T>::type yv = yy2[i];
-                        double dprev = x;
+                        double a1[Kind<M>::AS];
 #pragma unroll
-                        for (int t = 1; t < M; ++t) {
-                            const double a1 = (double)A[(size_t)i * (M - 1) + (t - 1)];
-                            dprev = x * (a1 - pq * dprev);
-                        }
+                        for (int t = 0; t < Kind<M>::AS; ++t)
+                            a1[t] = (double)A[(size_t)i * Kind<M>::AS + t];
+                        const double dprev = grad_factor<M>(a1, x, pq);
                         lg += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * dprev;
                         lh += dprev * dprev;
                     }
@@ -1051,15 +1114,24 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                     if (cur.e0 + sub + 4 * u < cur.e1) {
                         const size_t i = (size_t)cur.row[u];
                         const double x = (double)cur.x[u];
-                        double dprev = x;
+                        if constexpr (M == 0) {  // pcd_all.py:92-98
+                            double yn = yh[u] - lam * av[u][0];
+                            double an = av[u][0] / (1.0 + x * p_old);
+                            an *= 1.0 + x * (p_old - upd);
+                            yn += lam * an;
+                            A[i] = (T)an;
+                            yy[2 * i] = (T)yn;
+                        } else {
+                            double dprev = x;
 #pragma unroll
-                        for (int t = 1; t < M; ++t) {
-                            const double a1 = av[u][t - 1];
-                            const double dcur = x * (a1 - p_old * dprev);
-                            A[i * (M - 1) + (t - 1)] = (T)(a1 - upd * dprev);
-                            dprev = dcur;
+                            for (int t = 1; t < M; ++t) {
+                                const double a1 = av[u][t - 1];
+                                const double dcur = x * (a1 - p_old * dprev);
+                                A[i * (M - 1) + (t - 1)] = (T)(a1 - upd * dprev);
+                                dprev = dcur;
+                            }
+                            yy[2 * i] = (T)(yh[u] - lam * upd * dlast[u]);
                         }
-                        yy[2 * i] = (T)(yh[u] - lam * upd * dlast[u]);
                     }
                 }
                 for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4)
@@ -1448,18 +1520,26 @@ __global__ __launch_bounds__(kBlock) void pbcd_precompute_kernel(
     if (tid >= n * k) return;
     const int64_t i = tid / k;
     const int s = (int)(tid - i * k);
-    double a[M];
-    a[0] = 1.0;
+    if constexpr (M == 0) {  // pbcd_all.py:9-20
+        double a = 1.0;
+        for (int64_t ii = rptr[i]; ii < rptr[i + 1]; ++ii)
+            a *= 1.0 + P[(size_t)ridx[ii] * k + s] * (double)rval[ii];
+        A[(size_t)i * k + s] = (T)a;
+    } else {
+        double a[M];
+        a[0] = 1.0;
 #pragma unroll
-    for (int t = 1; t < M; ++t) a[t] = 0.0;
-    for (int64_t ii = rptr[i]; ii < rptr[i + 1]; ++ii) {
-        const double p = P[(size_t)ridx[ii] * k + s];
-        const double x = (double)rval[ii];
+        for (int t = 1; t < M; ++t) a[t] = 0.0;
+        for (int64_t ii = rptr[i]; ii < rptr[i + 1]; ++ii) {
+            const double p = P[(size_t)ridx[ii] * k + s];
+            const double x = (double)rval[ii];
 #pragma unroll
-        for (int t = M - 1; t >= 1; --t) a[t] += a[t - 1] * p * x;
+            for (int t = M - 1; t >= 1; --t) a[t] += a[t - 1] * p * x;
+        }
+#pragma unroll
+        for (int t = 1; t < M; ++t)
+            A[(size_t)i * (M - 1) * k + (size_t)(t - 1) * k + s] = (T)a[t];
     }
-#pragma unroll
-    for (int t = 1; t < M; ++t) A[(size_t)i * (M - 1) * k + (size_t)(t - 1) * k + s] = (T)a[t];
 }
 
 // norms[j] = ||P[j,:]||_2 for all j (squaredl21.py:36-38, omegacs.py:64-66):
@@ -1492,6 +1572,18 @@ __global__ __launch_bounds__(kBlock) void pbcd_compute_cache_kernel(int d, int r
         return;
     }
     if (reg != REG_OMEGACS) return;
+    if constexpr (M == 0) {  // omegacs.py:60-62: _cache_all_subsets = prod_j (1 + norm_j)
+        double pr = 1.0;
+        for (int j = tid; j < d; j += kBlock) pr *= 1.0 + rs.norms[j];
+        sh[tid] = pr;
+        __syncthreads();
+        for (int half = kBlock / 2; half >= 1; half >>= 1) {
+            if (tid < half) sh[tid] *= sh[tid + half];
+            __syncthreads();
+        }
+        if (tid == 0) rs.cache[0] = sh[0];
+        return;
+    }
     double c[M + 1];
     c[0] = 1.0;
 #pragma unroll
@@ -1563,11 +1655,12 @@ __global__ __launch_bounds__(kBlock) void pbcd_grad_kernel(
     }
     double hs = 0.0, dummy = 0.0;
     const int64_t e = cd.start + cd.len;
-    const size_t slab = (size_t)(M - 1) * k;
+    constexpr int AS = Kind<M>::AS;
+    const size_t slab = (size_t)AS * k;
     for (int64_t ii0 = cd.start + (int64_t)w * G + grp; ii0 < e; ii0 += (int64_t)U * G * kPbW) {
         int iu[U];
         double xu[U], dlu[U];
-        double au[U][C][M > 1 ? M - 1 : 1];
+        double au[U][C][AS];
 #pragma unroll
         for (int u = 0; u < U; ++u) {  // all loads of U entries in flight together
             const int64_t ii = ii0 + (int64_t)u * G * kPbW;
@@ -1584,10 +1677,9 @@ __global__ __launch_bounds__(kBlock) void pbcd_grad_kernel(
                 for (int c = 0; c < C; ++c) {
                     const int s = lane + c * L;
 #pragma unroll
-                    for (int t = 1; t < M; ++t)
-                        au[u][c][t - 1] =
-                            (s < k) ? (double)A[(size_t)iu[u] * slab + (size_t)(t - 1) * k + s]
-                                    : 0.0;
+                    for (int t = 0; t < AS; ++t)
+                        au[u][c][t] =
+                            (s < k) ? (double)A[(size_t)iu[u] * slab + (size_t)t * k + s] : 0.0;
                 }
             }
         }
@@ -1598,10 +1690,7 @@ __global__ __launch_bounds__(kBlock) void pbcd_grad_kernel(
                 for (int c = 0; c < C; ++c) {
                     const int s = lane + c * L;
                     if (s < k) {
-                        double dprev = xu[u];
-#pragma unroll
-                        for (int t = 1; t < M; ++t)
-                            dprev = xu[u] * (au[u][c][t - 1] - p[c] * dprev);
+                        const double dprev = grad_factor<M>(au[u][c], xu[u], p[c]);
                         grad[c] += dlu[u] * dprev;
                         hs += dprev * dprev;
                     }
@@ -1710,7 +1799,7 @@ __global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
             st0 = scal[4 * q + 1];
             njl = rs.norms[j];
         }
-        if (M == 2) {
+        if constexpr (M == 2) {
             // Degree 2: the cache is one scalar c (= sum of block norms) and column i maps it
             // through c' = (c - n_i) + max(l2_i - t_i (c - n_i), 0), t_i = st0 (omegacs) or
             // 2 st0 / (1 + 2 st0) (squaredl21): the same piecewise-affine recurrence as
@@ -1763,6 +1852,31 @@ __global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 continue;
             }
+        }
+        if constexpr (M == 0) {
+            // all-subsets OmegaCS (omegacs.py:99-106, 77-81): c /= 1 + n_j; strength = st0 c;
+            // shrink; c *= 1 + new norm.  Multiplicative: serial loop over the chunk.
+            double c = cache[0];
+            double f_m = 0.0, l2n_m = 0.0;
+            for (int i = 0; i < cnt; ++i) {
+                const double l2i = readlane_d(l2, i), si = readlane_d(st0, i),
+                             nj = readlane_d(njl, i);
+                c /= 1.0 + nj;
+                const double strength = si * c;
+                const double f = (l2i > strength) ? (1.0 - strength / l2i) : 0.0;
+                const double l2n = f * l2i;
+                c *= 1.0 + l2n;
+                if (lane == i) {
+                    f_m = f;
+                    l2n_m = l2n;
+                }
+            }
+            cache[0] = c;
+            if (valid) {
+                scal[4 * q + 2] = f_m;
+                rs.norms[j] = l2n_m;
+            }
+            continue;
         }
         double f_mine = 0.0, l2n_mine = 0.0;
 // rare fallback paths re-read all d norms from memory: first store the norms of the
@@ -1940,12 +2054,20 @@ __global__ __launch_bounds__(kBlock) void pbcd_sync_kernel(
     }
     if (!__syncthreads_or(any ? 1 : 0)) return;  // block did not move: exact no-op
     const int64_t e = cd.start + cd.len;
-    const size_t slab = (size_t)(M - 1) * k;
+    const size_t slab = (size_t)Kind<M>::AS * k;
     constexpr int U = 4;  // entries per group in flight
+    constexpr int AS = Kind<M>::AS;
+    double lamc[C], pn[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int s = lane + c * L;
+        lamc[c] = (s < k) ? lams[s] : 0.0;
+        pn[c] = po[c] - up[c];
+    }
     for (int64_t ii0 = cd.start + (int64_t)w * G + grp; ii0 < e; ii0 += (int64_t)U * G * kPbW) {
         int iu[U];
         double xu[U];
-        double au[U][C][M > 1 ? M - 1 : 1];
+        double au[U][C][AS];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t ii = ii0 + (int64_t)u * G * kPbW;
@@ -1960,10 +2082,9 @@ __global__ __launch_bounds__(kBlock) void pbcd_sync_kernel(
                 for (int c = 0; c < C; ++c) {
                     const int s = lane + c * L;
 #pragma unroll
-                    for (int t = 1; t < M; ++t)
-                        au[u][c][t - 1] =
-                            (s < k) ? (double)A[(size_t)iu[u] * slab + (size_t)(t - 1) * k + s]
-                                    : 0.0;
+                    for (int t = 0; t < AS; ++t)
+                        au[u][c][t] =
+                            (s < k) ? (double)A[(size_t)iu[u] * slab + (size_t)t * k + s] : 0.0;
                 }
             }
         }
@@ -1971,24 +2092,43 @@ __global__ __launch_bounds__(kBlock) void pbcd_sync_kernel(
         for (int u = 0; u < U; ++u) {
             if (iu[u] >= 0) {
                 const size_t i = (size_t)iu[u];
-                double acc = 0.0;
+                if constexpr (M == 0) {  // pbcd_all.py:121-127
+                    double d_old = 0.0, d_new = 0.0;
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const int s = lane + c * L;
-                    if (s < k) {
-                        double dprev = xu[u];
-#pragma unroll
-                        for (int t = 1; t < M; ++t) {
-                            const double a = au[u][c][t - 1];
-                            const double dcur = xu[u] * (a - po[c] * dprev);
-                            A[i * slab + (size_t)(t - 1) * k + s] = (T)(a - up[c] * dprev);
-                            dprev = dcur;
+                    for (int c = 0; c < C; ++c) {
+                        const int s = lane + c * L;
+                        if (s < k) {
+                            const double a0 = au[u][c][0];
+                            double a1 = a0 / (1.0 + xu[u] * po[c]);
+                            a1 *= 1.0 + xu[u] * pn[c];
+                            A[i * slab + s] = (T)a1;
+                            d_old += lamc[c] * a0;
+                            d_new += lamc[c] * a1;
                         }
-                        acc += lu[c] * dprev;
                     }
+                    d_old = group_sum(d_old, L);
+                    d_new = group_sum(d_new, L);
+                    if (lane == 0) yy[2 * i] = (T)(((double)yy[2 * i] - d_old) + d_new);
+                } else {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const int s = lane + c * L;
+                        if (s < k) {
+                            double dprev = xu[u];
+#pragma unroll
+                            for (int t = 1; t < M; ++t) {
+                                const double a = au[u][c][t - 1];
+                                const double dcur = xu[u] * (a - po[c] * dprev);
+                                A[i * slab + (size_t)(t - 1) * k + s] = (T)(a - up[c] * dprev);
+                                dprev = dcur;
+                            }
+                            acc += lu[c] * dprev;
+                        }
+                    }
+                    acc = group_sum(acc, L);
+                    if (lane == 0) yy[2 * i] = (T)((double)yy[2 * i] - acc);
                 }
-                acc = group_sum(acc, L);
-                if (lane == 0) yy[2 * i] = (T)((double)yy[2 * i] - acc);
             }
         }
     }
@@ -2020,16 +2160,23 @@ __global__ __launch_bounds__(kBlock) void anova_predict_kernel(
     double acc = 0.0;
     const int64_t b = rptr[row], e = rptr[row + 1];
     for (int s = lane; s < k; s += kWave) {
-        double a[M + 1];
-        a[0] = 1.0;
+        if constexpr (M == 0) {  // all-subsets kernel, kernels.py:117-137
+            double a = 1.0;
+            for (int64_t ii = b; ii < e; ++ii)
+                a *= 1 + (double)rval[ii] * Pt[(size_t)ridx[ii] * k + s];
+            acc += a * lams[s];
+        } else {
+            double a[M + 1];
+            a[0] = 1.0;
 #pragma unroll
-        for (int t = 1; t <= M; ++t) a[t] = 0.0;
-        for (int64_t ii = b; ii < e; ++ii) {
-            const double px = Pt[(size_t)ridx[ii] * k + s] * (double)rval[ii];
+            for (int t = 1; t <= M; ++t) a[t] = 0.0;
+            for (int64_t ii = b; ii < e; ++ii) {
+                const double px = Pt[(size_t)ridx[ii] * k + s] * (double)rval[ii];
 #pragma unroll
-            for (int t = M; t >= 1; --t) a[t] += a[t - 1] * px;
+                for (int t = M; t >= 1; --t) a[t] += a[t - 1] * px;
+            }
+            acc += a[M] * lams[s];
         }
-        acc += a[M] * lams[s];
     }
     acc = wave_sum(acc);
     if (lane == 0) out[row] += acc;

@@ -173,6 +173,7 @@ def test_package_exports_reference_names():
     import sparsepoly_amd as sa
 
     for name in ["L1", "L21", "OmegaCS", "OmegaTI", "SquaredL12", "SquaredL21",
+                 "SparseAllSubsetsClassifier", "SparseAllSubsetsRegressor",
                  "SparseFactorizationMachineClassifier", "SparseFactorizationMachineRegressor"]:
         assert hasattr(sa, name)
     from sparsepoly_amd.regularizer import REGULARIZATION

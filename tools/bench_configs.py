@@ -25,6 +25,9 @@ CFG = {
     "c3": dict(solver="pcd", reg="omegati", degree=3, k=16, beta=10.0, gamma=1e-6),
     "c4": dict(solver="pbcd", reg="omegacs", degree=2, k=30, beta=1.0, gamma=1e-3),
     "c2": dict(solver="pcd", reg="squaredl12", degree=2, k=30, beta=10.0, gamma=1e-4),
+    # all-subsets model (degree -1): SparseAllSubsets*, pcd_all / pbcd_all
+    "as_pcd": dict(solver="pcd", reg="omegati", degree=-1, k=30, beta=10.0, gamma=1e-7),
+    "as_pbcd": dict(solver="pbcd", reg="omegacs", degree=-1, k=30, beta=1.0, gamma=1e-7),
 }
 for name in which:
     c = CFG[name]
@@ -34,16 +37,17 @@ for name in which:
         eng.set_option(key, int(val))
     eng.set_data(Xc, y)
     m, k = c["degree"], c["k"]
-    P0 = 0.01 * np.random.RandomState(0).randn(m - 1, k, d)
+    allsub = m == -1
+    P0 = 0.01 * np.random.RandomState(0).randn(1 if allsub else m - 1, k, d)
     eng.set_params(P0, np.zeros(d), np.ones(k))
     eng.configure(c["solver"], "squared", c["reg"], m)
-    eng.init_pred(m, True, m == 3)
+    eng.init_pred(m, not allsub, m == 3)
     eng.set_schedule("colored", np.arange(d, dtype=np.int32))
     ic = np.arange(k, dtype=np.int32)
 
     def it():
-        v = eng.cd_linear_epoch(1.0)
-        for deg in list(range(2, m)) + [m]:
+        v = 0.0 if allsub else eng.cd_linear_epoch(1.0)  # the all-subsets model has no linear term
+        for deg in ([m] if allsub else list(range(2, m)) + [m]):
             o = m - deg if deg != m else 0
             if c["solver"] == "pcd":
                 v += eng.pcd_epoch(o, deg, c["beta"], c["gamma"], 1.0, ic)
@@ -57,7 +61,11 @@ for name in which:
     for _ in range(steps):
         viol.append(it())
     dt = (time.perf_counter() - t0) / steps
-    if c["solver"] == "pcd":
+    if allsub:  # one cache value per (row, component), like degree 2, no linear epoch
+        b_alg = (8 * nnz + 4 * n * k + k * nnz * 28) if c["solver"] == "pcd" else \
+                (8 * nnz + 4 * n * k + nnz * (20 + 8 * k))
+        nsteps = (k if c["solver"] == "pcd" else 1) * eng.n_batches
+    elif c["solver"] == "pcd":
         b_alg = sum(8 * nnz + 4 * (deg - 1) * n * k + k * nnz * (20 + 8 * (deg - 1))
                     for deg in range(2, m + 1)) + 20 * nnz
         nsteps = (k * (m - 1) + 1) * eng.n_batches

@@ -26,8 +26,10 @@ CFG = {
     "c4": dict(solver="pbcd", reg="omegacs", degree=2, k=30, beta=1.0, gamma=1e-3),
     "c2": dict(solver="pcd", reg="squaredl12", degree=2, k=30, beta=10.0, gamma=1e-4),
     # all-subsets model (degree -1): SparseAllSubsets*, pcd_all / pbcd_all
-    "as_pcd": dict(solver="pcd", reg="omegati", degree=-1, k=30, beta=10.0, gamma=1e-7),
-    "as_pbcd": dict(solver="pbcd", reg="omegacs", degree=-1, k=30, beta=1.0, gamma=1e-7),
+    # (l1 / l21: omegati / omegacs multiply the threshold by prod_j (1 + |p_j|) = e^800 here,
+    # which overflows in the reference too)
+    "as_pcd": dict(solver="pcd", reg="l1", degree=-1, k=30, beta=10.0, gamma=1e-3),
+    "as_pbcd": dict(solver="pbcd", reg="l21", degree=-1, k=30, beta=1.0, gamma=1e-3),
 }
 for name in which:
     c = CFG[name]
@@ -39,7 +41,8 @@ for name in which:
     m, k = c["degree"], c["k"]
     allsub = m == -1
     P0 = 0.01 * np.random.RandomState(0).randn(1 if allsub else m - 1, k, d)
-    eng.set_params(P0, np.zeros(d), np.ones(k))
+    lams = np.where(np.arange(k) % 2 == 0, 1.0, -1.0) if allsub else np.ones(k)
+    eng.set_params(P0, np.zeros(d), lams)
     eng.configure(c["solver"], "squared", c["reg"], m)
     eng.init_pred(m, not allsub, m == 3)
     eng.set_schedule("colored", np.arange(d, dtype=np.int32))

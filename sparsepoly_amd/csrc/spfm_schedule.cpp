@@ -44,50 +44,69 @@ void schedule_exact(int64_t n_rows, int32_t d, const int64_t* cptr, const int32_
 }
 
 // COLORED: first-fit greedy colouring of the column conflict graph, visiting the
-// columns in `order`.  Per row a bitset of the colours already present in that
-// row; a column takes the lowest colour absent from all of its rows (and not
-// full).  out_order = colour classes concatenated (columns keep their relative
-// visiting order inside a class).
+// columns in `order`.  Every row keeps the list of colours already present in it (at
+// most its number of entries); a column marks the colours of all its rows in a small
+// local bitset and takes the lowest colour that is absent and not full.  Reading the
+// rows' short lists (instead of one bitset of all colours per row) keeps the traffic
+// per column at ~(entries x colours-so-far-in-row) bytes.  out_order = colour classes
+// concatenated (columns keep their relative visiting order inside a class).
 void schedule_colored(int64_t n_rows, int32_t d, const int64_t* cptr, const int32_t* cidx,
                       const int32_t* order, int max_batch, std::vector<int32_t>& out_order,
                       std::vector<int32_t>& batch_ptr) {
-    size_t W = 8;  // 64-bit words per row (grows)
-    std::vector<uint64_t> bits((size_t)n_rows * W, 0);
-    std::vector<uint64_t> full(W, 0), acc(W, 0);
+    // row capacities = entries per row
+    std::vector<int64_t> rstart((size_t)n_rows + 1, 0);
+    const int64_t nnz = cptr[d];
+    for (int64_t ii = 0; ii < nnz; ++ii) rstart[(size_t)cidx[ii] + 1]++;
+    for (int64_t i = 0; i < n_rows; ++i) rstart[(size_t)i + 1] += rstart[(size_t)i];
+    std::vector<int32_t> rcol((size_t)nnz);          // colours present in each row
+    std::vector<int32_t> rcnt((size_t)n_rows, 0);
+    std::vector<uint64_t> used, full;
     std::vector<std::vector<int32_t>> classes;
     for (int32_t pos = 0; pos < d; ++pos) {
         const int32_t j = order[pos];
-        std::copy(full.begin(), full.end(), acc.begin());
-        for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
-            const uint64_t* rb = &bits[(size_t)cidx[ii] * W];
-            for (size_t w = 0; w < W; ++w) acc[w] |= rb[w];
+        const size_t W = classes.size() / 64 + 1;
+        if (used.size() < W) {
+            used.resize(W, 0);
+            full.resize(W, 0);
         }
-        size_t c = W * 64;
+        for (size_t w = 0; w < W; ++w) used[w] = full[w];
+        // the rows of a column are scattered over the whole matrix: every access below is a
+        // cache miss unless requested ahead (two-stage software prefetch)
+        const int64_t cb = cptr[j], ce = cptr[j + 1];
+        constexpr int64_t PD = 16;
+        for (int64_t ii = cb; ii < ce; ++ii) {
+            if (ii + 2 * PD < ce) {
+                const int32_t i2 = cidx[ii + 2 * PD];
+                __builtin_prefetch(&rstart[(size_t)i2]);
+                __builtin_prefetch(&rcnt[(size_t)i2]);
+            }
+            if (ii + PD < ce) __builtin_prefetch(&rcol[(size_t)rstart[(size_t)cidx[ii + PD]]]);
+            const int32_t i = cidx[ii];
+            const int32_t* rc = &rcol[(size_t)rstart[(size_t)i]];
+            const int32_t cnt = rcnt[(size_t)i];
+            for (int32_t t = 0; t < cnt; ++t) used[(size_t)rc[t] >> 6] |= 1ull << (rc[t] & 63);
+        }
+        size_t c = classes.size();
         for (size_t w = 0; w < W; ++w) {
-            if (~acc[w]) {
-                c = w * 64 + (size_t)__builtin_ctzll(~acc[w]);
+            if (~used[w]) {
+                const size_t cand = w * 64 + (size_t)__builtin_ctzll(~used[w]);
+                if (cand < c) c = cand;
                 break;
             }
         }
-        if (c > classes.size()) c = classes.size();  // first unused colour
-        if (c == classes.size()) {
-            classes.emplace_back();
-            if (c >= W * 64) {  // grow the per-row bitsets
-                const size_t W2 = W * 2;
-                std::vector<uint64_t> nb((size_t)n_rows * W2, 0);
-                for (int64_t r = 0; r < n_rows; ++r)
-                    std::memcpy(&nb[(size_t)r * W2], &bits[(size_t)r * W], W * sizeof(uint64_t));
-                bits.swap(nb);
-                full.resize(W2, 0);
-                acc.resize(W2, 0);
-                W = W2;
-            }
-        }
+        if (c == classes.size()) classes.emplace_back();
         classes[c].push_back(j);
-        if ((int)classes[c].size() >= max_batch) full[c >> 6] |= (1ull << (c & 63));
-        const uint64_t m = 1ull << (c & 63);
-        const size_t cw = c >> 6;
-        for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) bits[(size_t)cidx[ii] * W + cw] |= m;
+        if ((int)classes[c].size() >= max_batch) {
+            if (full.size() <= (c >> 6)) {
+                full.resize((c >> 6) + 1, 0);
+                used.resize((c >> 6) + 1, 0);
+            }
+            full[c >> 6] |= (1ull << (c & 63));
+        }
+        for (int64_t ii = cb; ii < ce; ++ii) {  // rows are warm from the pass above
+            const int32_t i = cidx[ii];
+            rcol[(size_t)rstart[(size_t)i] + rcnt[(size_t)i]++] = (int32_t)c;
+        }
     }
     out_order.clear();
     out_order.reserve((size_t)d);

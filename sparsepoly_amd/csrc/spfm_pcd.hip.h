@@ -1,0 +1,537 @@
+// spfm_pcd.hip.h -- pcd: precompute, regularizer cache, gradient, chain (affine scan), scatter
+// Part of the gfx950 device code of the sparse-FM proximal CD core; see
+// spfm_kernels.hip.h for the execution model and DESIGN.md section 3.
+#pragma once
+#include "spfm_common.hip.h"
+
+namespace spfm {
+
+// ---------------------------------------------------------- pcd: precompute
+
+// pcd._precompute_A_all_degree (optimizer/pcd.py:15-30): per row the reference's column
+// sweep visits the row's entries in ascending column order; the kernel below keeps that
+// order inside every row.  A[i, M] is never read during training (pcd.py:11-12) and is
+// not stored.
+// All components in one pass over the CSR image (the "one precompute pass for all s"
+// of the roofline model): A_all[s][i][t-1] = A^{(s)}[i, t].  Valid because
+// P[s,:] changes only during pass s, so A^{(s)} computed from the epoch-start P equals
+// what the reference recomputes at the start of pass s (pcd.py:94).  One wavefront per
+// row at a time, lanes over components (P^T rows are coalesced 8k-byte reads), 8 P^T
+// loads in flight; results are staged through LDS so that the per-component slabs
+// are written in contiguous runs.  Pt is (d, k).
+template <typename T, int M>
+__global__ __launch_bounds__(kBlock) void pcd_precompute_all_kernel(
+    int64_t n, int k, const int64_t* __restrict__ rptr, const int32_t* __restrict__ ridx,
+    const T* __restrict__ rval, const double* __restrict__ Pt, T* __restrict__ A_all) {
+    constexpr int R = 32;       // rows per tile
+    constexpr int RP = R + 1;   // padded row stride in LDS
+    extern __shared__ __attribute__((aligned(16))) unsigned char pre_lds[];
+    T* tile = reinterpret_cast<T*>(pre_lds);  // [AS][64][RP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int64_t tile0 = (int64_t)blockIdx.x * R; tile0 < n; tile0 += (int64_t)gridDim.x * R) {
+        for (int s0 = 0; s0 < k; s0 += kWave) {
+            const int s = s0 + lane;
+            const bool sv = s < k;
+            for (int r = wave; r < R; r += kBlock / kWave) {
+                const int64_t i = tile0 + r;
+                if (i >= n) break;
+                constexpr int NA = (M == 0) ? 2 : M;
+                double a[NA];
+                a[0] = 1.0;
+#pragma unroll
+                for (int t = 1; t < NA; ++t) a[t] = (M == 0) ? 1.0 : 0.0;  // M==0: a[1] = product
+                const int64_t b = rptr[i], e = rptr[i + 1];
+                for (int64_t c = b; c < e; c += kWave) {
+                    const int cnt = (int)((e - c < kWave) ? (e - c) : kWave);
+                    const int my_col = (lane < cnt) ? ridx[c + lane] : 0;
+                    const float my_xf = (lane < cnt) ? (float)rval[c + lane] : 0.f;
+                    const double my_xd = (lane < cnt) ? (double)rval[c + lane] : 0.0;
+                    for (int q = 0; q < cnt; q += 8) {
+                        double pv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int src = (q + u < cnt) ? (q + u) : q;
+                            const int col = __builtin_amdgcn_readlane(my_col, src);
+                            pv[u] = sv ? Pt[(size_t)col * k + s] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (q + u < cnt) {
+                                double x;
+                                if (sizeof(T) == 4)
+                                    x = (double)__int_as_float(__builtin_amdgcn_readlane(
+                                        __float_as_int(my_xf), q + u));
+                                else
+                                    x = readlane_d(my_xd, q + u);
+                                if constexpr (M == 0) {
+                                    a[1] *= 1.0 + pv[u] * x;  // pcd_all.py:18
+                                } else {
+#pragma unroll
+                                    for (int t = M - 1; t >= 1; --t) a[t] += a[t - 1] * pv[u] * x;
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 1; t <= Kind<M>::AS; ++t)
+                    tile[((t - 1) * kWave + lane) * RP + r] = (T)a[t];
+            }
+            __syncthreads();
+            constexpr int AS = Kind<M>::AS;
+            const int per_s = R * AS;
+            for (int idx = tid; idx < kWave * per_s; idx += kBlock) {
+                const int sl = idx / per_s, rem = idx - sl * per_s;
+                const int r = rem / AS, t1 = rem - r * AS;
+                const int64_t i = tile0 + r;
+                if (s0 + sl < k && i < n)
+                    A_all[((size_t)(s0 + sl) * n + i) * AS + t1] = tile[(t1 * kWave + sl) * RP + r];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------- pcd: regularizer cache
+
+// regularizer.compute_cache_pcd(P, degree, s): squaredl12.py:42-45 (|P[s]| and
+// its sum), omegati.py:62-74 (|P[s]| and the elementary symmetric polynomials
+// e_0..e_M of |P[s,:]|).  One workgroup; e_t by per-thread DP over a strided
+// subset, then a tree of truncated polynomial products (e_t is symmetric, so any
+// partition of the features gives the same value up to rounding).
+template <int M>
+__global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __restrict__ ctl,
+                                                                    const double* __restrict__ P,
+                                                                    int d, int reg,
+                                                                    double* __restrict__ cache) {
+    __shared__ double sh[kBlock * (M + 1)];
+    const double* ps = P + (size_t)ctl->s * d;
+    const int tid = threadIdx.x;
+    if (reg == REG_SQL12) {
+        double a = 0, b = 0;
+        for (int j = tid; j < d; j += kBlock) {
+            const double v = fabs(ps[j]);
+            a += v;
+        }
+        block_sum2(a, b, sh);
+        if (tid == 0) cache[0] = a;
+        return;
+    }
+    if (reg != REG_OMEGATI) return;
+    if constexpr (M == 0) {  // omegati.py:75-80: _cache_all_subsets = prod_j (1 + |p_sj|)
+        double pr = 1.0;
+        for (int j = tid; j < d; j += kBlock) pr *= 1.0 + fabs(ps[j]);
+        sh[tid] = pr;
+        __syncthreads();
+        for (int half = kBlock / 2; half >= 1; half >>= 1) {
+            if (tid < half) sh[tid] *= sh[tid + half];
+            __syncthreads();
+        }
+        if (tid == 0) cache[0] = sh[0];
+        return;
+    }
+    double c[M + 1];
+    c[0] = 1.0;
+#pragma unroll
+    for (int t = 1; t <= M; ++t) c[t] = 0.0;
+    for (int j = tid; j < d; j += kBlock) {
+        const double v = fabs(ps[j]);
+#pragma unroll
+        for (int t = M; t >= 1; --t) c[t] += c[t - 1] * v;
+    }
+#pragma unroll
+    for (int t = 0; t <= M; ++t) sh[tid * (M + 1) + t] = c[t];
+    __syncthreads();
+    for (int half = kBlock / 2; half >= 1; half >>= 1) {
+        if (tid < half) {
+            double o[M + 1];
+#pragma unroll
+            for (int t = 0; t <= M; ++t) {
+                double acc = 0.0;
+#pragma unroll
+                for (int u = 0; u <= t; ++u)
+                    acc += sh[tid * (M + 1) + u] * sh[(tid + half) * (M + 1) + (t - u)];
+                o[t] = acc;
+            }
+#pragma unroll
+            for (int t = 0; t <= M; ++t) sh[tid * (M + 1) + t] = o[t];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int t = 0; t <= M; ++t) cache[t] = sh[t];
+    }
+}
+
+// ------------------------------------------------------------- pcd: gradient
+
+// First pass of pcd._update (optimizer/pcd.py:52-59) for every column of one
+// batch: part[2q] = sum_i dloss(yhat_i, y_i) * dA_i[M-1], part[2q+1] = sum_i
+// dA_i[M-1]^2 with dA from _grad_anova (pcd.py:8-12); pold[q] = P[s, j] (the
+// snapshot every workgroup of the following chain reads).  One workgroup per column.
+template <typename T, int M>
+__global__ __launch_bounds__(kBlock) void pcd_grad_kernel(
+    const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc,
+    const int32_t* __restrict__ cidx, const T* __restrict__ cval, const T* __restrict__ A_all,
+    size_t a_stride, const typename Vec2<T>::type* __restrict__ yy, const double* __restrict__ P,
+    int d, int loss, double* __restrict__ part, double* __restrict__ pold) {
+    __shared__ double red[16];
+    const int q = blockIdx.x;
+    const ColDesc cd = desc[q];
+    const T* __restrict__ A = A_all + (size_t)ctl->s * a_stride;
+    const double p = P[(size_t)ctl->s * d + cd.j];
+    const int64_t b = cd.start, e = cd.start + cd.len;
+    constexpr int AS = Kind<M>::AS;
+    double g = 0.0, h = 0.0;
+    for (int64_t ii = b + threadIdx.x; ii < e; ii += kBlock) {
+        const int i = cidx[ii];
+        const double x = (double)cval[ii];
+        const typename Vec2<T>::type yv = yy[i];
+        double a[AS];
+#pragma unroll
+        for (int t = 0; t < AS; ++t) a[t] = (double)A[(size_t)i * AS + t];
+        const double dprev = grad_factor<M>(a, x, p);
+        g += dloss_dev(loss, (double)yv.x, (double)yv.y) * dprev;
+        h += dprev * dprev;
+    }
+    block_sum2(g, h, red);
+    if (threadIdx.x == 0) {
+        part[2 * q] = g;
+        part[2 * q + 1] = h;
+        pold[q] = p;
+    }
+}
+
+// ---------------------------------------------------------------- pcd: chain
+
+// ---- speculative affine scan for the degree-2 cache recurrences --------------
+// For degree 2 the regularizer cache is one scalar c and column i maps it through a
+// piecewise-affine f_i (squaredl12.py:47-57: c' = (c - a) + max(p - t (c - a), 0);
+// omegati.py:76-99 at degree 2: u = max(c - a, 0), c' = u + max(p - s u, 0)).  Given
+// the branch each column takes, f_i is affine, and the values seen by all 64 columns
+// follow from ONE wave-parallel prefix composition of affine maps (6 shuffle steps)
+// instead of a 64-long dependent loop.  The branches are guessed (from the previous
+// round's values, initially from c at the start of the batch), the scan is evaluated,
+// and every lane re-checks its own branch with the value it actually receives; all
+// lanes before the first mismatch are then provably right, so each round fixes at
+// least one more column and the fixed point is exactly the sequential result (up to
+// the rounding of composed vs. step-by-step affine evaluation, ~1e-16 relative).
+__device__ __forceinline__ void affine_scan_inclusive(double& al, double& be, int lane) {
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const double oa = __shfl_up(al, o, kWave);
+        const double ob = __shfl_up(be, o, kWave);
+        if (lane >= o) {  // mine after other: x -> al*(oa*x + ob) + be
+            be = al * ob + be;
+            al = al * oa;
+        }
+    }
+}
+
+// value of the cache in front of column `lane` given c0 and the inclusive scan
+__device__ __forceinline__ double affine_before(double al_inc, double be_inc, double c0, int lane) {
+    const double pa = __shfl_up(al_inc, 1, kWave);
+    const double pb = __shfl_up(be_inc, 1, kWave);
+    return (lane == 0) ? c0 : (pa * c0 + pb);
+}
+
+// Second half of pcd._update (optimizer/pcd.py:61-68) for up to 64 columns held one
+// per lane: step size and gradient step are lane-parallel, then the prox and the
+// regularizer's cache recurrence run as a wave-uniform serial loop over columns
+// 0..last in batch order (prox_cd: l1.py:32-33, squaredl12.py:52-57,
+// omegati.py:82-99,104; update_cache_pcd: squaredl12.py:47-50, omegati.py:76-80).
+// Returns this lane's new coordinate.  _abs_p[j] of the reference equals |p_old|
+// here because a sweep visits every j exactly once per pass.
+// Rounding note: squaredl12's 2*st*dcache/(1+2*st) is evaluated as
+// (2*st/(1+2*st))*dcache so that the division leaves the serial loop.
+template <int M>
+__device__ __forceinline__ double pcd_chain_lanes(int reg, int lane, int last, bool valid,
+                                                  double p_old, double g, double h, double lam,
+                                                  double mu, double beta, double gamma,
+                                                  double eta, double (&cache)[M + 1]) {
+    double pin = 0.0, st = 0.0;
+    if (valid) {
+        double inv = h * mu;
+        inv += beta;
+        double upd = g * lam;
+        upd += beta * p_old;
+        upd /= inv;
+        pin = p_old - eta * upd;
+        st = eta * gamma / inv;
+    }
+    if (reg == REG_L1) {
+        const double sg = (pin > 0) ? 1.0 : ((pin < 0) ? -1.0 : 0.0);
+        const double m = fabs(pin) - st;
+        return sg * (m > 0.0 ? m : 0.0);
+    }
+    const double ab = fabs(p_old);
+    double mine = 0.0;
+    if (reg == REG_SQL12) {
+        const double den = 1 + 2 * st;
+        const double pp = pin / den;
+        const double app = fabs(pp);
+        const double tt = 2 * st / den;
+        const double sg = (pp > 0) ? 1.0 : -1.0;
+        const double c0 = cache[0];
+        const bool act = valid && lane <= last;
+        // branch guess: evaluate every column at c0
+        bool nz = (app - tt * (c0 - ab)) > 0;
+        double cb = c0, m = 0.0, al = 1.0, be = 0.0;
+        for (int round = 0; round <= kWave; ++round) {
+            al = act ? (nz ? (1.0 - tt) : 1.0) : 1.0;
+            be = act ? (nz ? (app - (1.0 - tt) * ab) : -ab) : 0.0;
+            affine_scan_inclusive(al, be, lane);
+            cb = affine_before(al, be, c0, lane);
+            m = fma(-tt, cb - ab, app);
+            const bool nz2 = m > 0;
+            const unsigned long long bad = __ballot(act && (nz2 != nz));
+            nz = nz2;
+            if (bad == 0ull) break;
+        }
+        const double r = (act && nz) ? m : 0.0;
+        cache[0] = readlane_d(al, last) * c0 + readlane_d(be, last);
+        return sg * r;
+    }
+    // REG_OMEGATI
+    {
+        const double apin = fabs(pin);
+        const double sg = (pin > 0) ? 1.0 : -1.0;
+        if constexpr (M == 0) {
+            // all-subsets (omegati.py:100-102, 87-88): c /= 1 + |p_old|; strength *= c;
+            // soft-threshold; c *= 1 + |p_new| -- multiplicative, so a plain serial loop
+            double c = cache[0];
+            for (int i = 0; i <= last; ++i) {
+                const double ai = readlane_d(ab, i), si = readlane_d(st, i),
+                             pi = readlane_d(apin, i);
+                c /= 1.0 + ai;
+                const double m = pi - si * c;
+                const double r = (m > 0) ? m : 0.0;
+                c *= 1.0 + r;
+                if (lane == i) mine = r;
+            }
+            cache[0] = c;
+            return sg * mine;
+        }
+        if constexpr (M == 2) {
+            // degree 2: u = max(c - a, 0); r = max(p - s u, 0); c' = u + r  (dcache[1] = 1)
+            const double c0 = cache[1];
+            const bool act = valid && lane <= last;
+            bool pos = (c0 - ab) >= 0;                       // clip of omegati.py:97-98 inactive
+            bool nz = (apin - st * (pos ? (c0 - ab) : 0.0)) > 0;
+            double cb = c0, u = 0.0, m = 0.0, al = 1.0, be = 0.0;
+            for (int round = 0; round <= kWave; ++round) {
+                if (!act) {
+                    al = 1.0;
+                    be = 0.0;
+                } else if (!pos) {   // u = 0, r = p
+                    al = 0.0;
+                    be = apin;
+                } else if (nz) {     // c' = (1 - s)(c - a) + p
+                    al = 1.0 - st;
+                    be = apin - al * ab;
+                } else {             // c' = c - a
+                    al = 1.0;
+                    be = -ab;
+                }
+                affine_scan_inclusive(al, be, lane);
+                cb = affine_before(al, be, c0, lane);
+                const double v = cb - ab;
+                const bool pos2 = !(v < 0);
+                u = pos2 ? v : 0.0;
+                m = apin - st * u;
+                const bool nz2 = m > 0;
+                const unsigned long long bad =
+                    __ballot(act && ((pos2 != pos) || (pos2 && (nz2 != nz))));
+                pos = pos2;
+                nz = nz2;
+                if (bad == 0ull) break;
+            }
+            const double r = act ? ((m > 0) ? m : 0.0) : 0.0;
+            cache[1] = readlane_d(al, last) * c0 + readlane_d(be, last);
+            return sg * r;
+        }
+        if constexpr (M > 2)
+        for (int i = 0; i <= last; ++i) {
+            const double ai = readlane_d(ab, i), si = readlane_d(st, i), pi = readlane_d(apin, i);
+            double dc[M + 2];
+            dc[1] = 1.0;
+#pragma unroll
+            for (int deg = 2; deg <= M; ++deg) {
+                double v = cache[deg - 1];
+                v -= dc[deg - 1] * ai;
+                dc[deg] = (v < 0) ? 0.0 : v;
+            }
+            const double m = pi - si * dc[M];
+            const double r = (m > 0) ? m : 0.0;
+#pragma unroll
+            for (int deg = 1; deg < M; ++deg) cache[deg] = dc[deg + 1] + dc[deg] * r;
+            if (lane == i) mine = r;
+        }
+        return sg * mine;
+    }
+}
+
+// Stand-alone chain for batches of more than 64 columns (and for the multi-kernel
+// path): one wavefront, 64 columns at a time; writes P[s,j], sum_viol
+// (pcd.py:119-121) and delta = p_old - p_new for the sync kernel.
+template <int M>
+__global__ __launch_bounds__(kWave) void pcd_chain_kernel(
+    const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc, int ncols,
+    double* __restrict__ P, int d, const double* __restrict__ part,
+    const double* __restrict__ pold, int reg, const double* __restrict__ cache_in,
+    double* __restrict__ cache_out, double mu, double beta, double gamma, double eta,
+    double* __restrict__ delta, double* __restrict__ viol_col) {
+    const int lane = threadIdx.x;
+    const double lam = ctl->lam;
+    double* ps = P + (size_t)ctl->s * d;
+    double cache[M + 1];
+#pragma unroll
+    for (int t = 0; t <= M; ++t) cache[t] = cache_in[t];
+    for (int base = 0; base < ncols; base += kWave) {
+        const int q = base + lane;
+        const bool valid = q < ncols;
+        const int cnt = min(kWave, ncols - base);
+        double p_old = 0.0, g = 0.0, h = 0.0;
+        int j = 0;
+        if (valid) {
+            j = desc[q].j;
+            p_old = pold[q];
+            g = part[2 * q];
+            h = part[2 * q + 1];
+        }
+        const double res =
+            pcd_chain_lanes<M>(reg, lane, cnt - 1, valid, p_old, g, h, lam, mu, beta, gamma, eta,
+                               cache);
+        if (valid) {
+            const double dl = p_old - res;
+            ps[j] = res;
+            delta[q] = dl;
+            viol_col[j] += fabs(dl);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t <= M; ++t) cache_out[t] = cache[t];
+    }
+}
+
+// ----------------------------------------------------------------- pcd: sync
+
+// "synchronize predictions and caches" (optimizer/pcd.py:124-133) for every
+// column of one batch.  A column whose coordinate did not move is skipped (the
+// reference's loop is an exact no-op for update == 0).
+template <typename T, int M>
+__device__ __forceinline__ void pcd_sync_entry(size_t i, double x, double p_old, double upd,
+                                               double lam, T* __restrict__ A,
+                                               T* __restrict__ yy) {
+    if constexpr (M == 0) {  // pcd_all.py:92-98
+        const double a0 = (double)A[i];
+        double yh = (double)yy[2 * i];
+        yh -= lam * a0;
+        double a1 = a0 / (1.0 + x * p_old);
+        a1 *= 1.0 + x * (p_old - upd);
+        yh += lam * a1;
+        A[i] = (T)a1;
+        yy[2 * i] = (T)yh;
+        return;
+    }
+    double dprev = x;
+#pragma unroll
+    for (int t = 1; t < M; ++t) {
+        const size_t at = i * (M - 1) + (t - 1);
+        const double a = (double)A[at];
+        const double dcur = x * (a - p_old * dprev);
+        A[at] = (T)(a - upd * dprev);
+        dprev = dcur;
+    }
+    const double yh = (double)yy[2 * i];
+    yy[2 * i] = (T)(yh - lam * upd * dprev);
+}
+
+template <typename T, int M>
+__global__ __launch_bounds__(kBlock) void pcd_sync_kernel(
+    const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc,
+    const int32_t* __restrict__ cidx, const T* __restrict__ cval, T* __restrict__ A_all,
+    size_t a_stride, T* __restrict__ yy /* (yhat,y) pairs */, const double* __restrict__ delta,
+    const double* __restrict__ pold) {
+    const int q = blockIdx.x;
+    const double upd = delta[q];
+    if (upd == 0.0) return;
+    T* __restrict__ A = A_all + (size_t)ctl->s * a_stride;
+    const double p_old = pold[q];
+    const double lam = ctl->lam;
+    const ColDesc cd = desc[q];
+    const int64_t b = cd.start, e = cd.start + cd.len;
+    for (int64_t ii = b + threadIdx.x; ii < e; ii += kBlock)
+        pcd_sync_entry<T, M>((size_t)cidx[ii], (double)cval[ii], p_old, upd, lam, A, yy);
+}
+
+// Fused chain + sync for batches of at most 64 columns: every workgroup runs the
+// (cheap, scalar) chain redundantly up to its own column while its other waves
+// already have the column's entries and their A / yhat values in flight; only the
+// last workgroup publishes the regularizer cache (double-buffered: cache_in is
+// never written in this launch).  Saves one dependent kernel boundary per step.
+template <typename T, int M>
+__global__ __launch_bounds__(kBlock) void pcd_chain_sync_kernel(
+    const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc, int ncols,
+    double* __restrict__ P, int d, const double* __restrict__ part,
+    const double* __restrict__ pold, int reg, const double* __restrict__ cache_in,
+    double* __restrict__ cache_out, double mu, double beta, double gamma, double eta,
+    const int32_t* __restrict__ cidx, const T* __restrict__ cval, T* __restrict__ A_all,
+    size_t a_stride, T* __restrict__ yy, double* __restrict__ viol_col) {
+    __shared__ double sh[2];
+    T* __restrict__ A = A_all + (size_t)ctl->s * a_stride;
+    constexpr int PF = 2;  // entries per thread fetched before the chain result is known
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ColDesc cd = desc[q];
+    const double lam = ctl->lam;
+    int ri[PF];
+    double rx[PF];
+    bool rv[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int off = tid + u * kBlock;
+        rv[u] = off < cd.len;
+        ri[u] = rv[u] ? cidx[cd.start + off] : 0;
+        rx[u] = rv[u] ? (double)cval[cd.start + off] : 0.0;
+    }
+    if (wave == 0) {
+        const bool valid = lane < ncols;
+        double p_old = 0.0, g = 0.0, h = 0.0;
+        if (valid) {
+            p_old = pold[lane];
+            g = part[2 * lane];
+            h = part[2 * lane + 1];
+        }
+        double cache[M + 1];
+#pragma unroll
+        for (int t = 0; t <= M; ++t) cache[t] = cache_in[t];
+        const double res = pcd_chain_lanes<M>(reg, lane, q, valid, p_old, g, h, lam, mu, beta,
+                                              gamma, eta, cache);
+        if (lane == q) {
+            const double dl = p_old - res;
+            P[(size_t)ctl->s * d + cd.j] = res;
+            viol_col[cd.j] += fabs(dl);
+            sh[0] = dl;
+            sh[1] = p_old;
+        }
+        if (q == ncols - 1 && lane == 0) {
+#pragma unroll
+            for (int t = 0; t <= M; ++t) cache_out[t] = cache[t];
+        }
+    }
+    __syncthreads();
+    const double upd = sh[0];
+    if (upd == 0.0) return;
+    const double p_old = sh[1];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (rv[u]) pcd_sync_entry<T, M>((size_t)ri[u], rx[u], p_old, upd, lam, A, yy);
+    for (int64_t ii = cd.start + tid + PF * kBlock; ii < cd.start + cd.len; ii += kBlock)
+        pcd_sync_entry<T, M>((size_t)cidx[ii], (double)cval[ii], p_old, upd, lam, A, yy);
+}
+
+
+}  // namespace spfm

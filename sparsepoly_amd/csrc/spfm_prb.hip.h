@@ -1,0 +1,690 @@
+// spfm_prb.hip.h -- persistent row-block passes (pcd_prb_kernel, lin_prb_kernel) and their exchange
+// Part of the gfx950 device code of the sparse-FM proximal CD core; see
+// spfm_kernels.hip.h for the execution model and DESIGN.md section 3.
+#pragma once
+#include "spfm_common.hip.h"
+#include "spfm_pcd.hip.h"
+
+namespace spfm {
+
+// ------------------------------------------- persistent row-block pass (PRB)
+//
+// One launch sweeps ALL batches of a component pass.  G workgroups (one per CU),
+// workgroup g owns the contiguous row block R_g; A and (yhat,y) rows of R_g are
+// read and written by that workgroup only, so they need no inter-workgroup
+// coherence and stay warm in its XCD's L2.  The entries of every batch are
+// pre-sorted on the host per (workgroup, batch, slot) (`erow/eval/sp`), so all
+// entry loads are plain streaming loads at known addresses.
+//
+// Per dependent step the only exchange is the all-gather of the per-slot partial
+// sums: workgroup g stores its (sum dloss*dA, sum dA^2) pairs write-through
+// (agent-scope relaxed atomic stores = global_store sc1) into slab[parity][g][slot],
+// drains them (s_waitcnt vmcnt(0)), and one lane adds 1 to the step's arrival
+// counter; one lane polls that counter with sc1 loads until G arrivals, after
+// which the same wave reads all G slabs with sc1 loads and sums them in fixed
+// order g = 0..G-1 (bitwise identical in every workgroup).  This is the hand-off
+// form "one signalling lane per storing workgroup, counter add / sc1 poll, all
+// stores and loads sc1, one workgroup per CU" of MI355X_MICROARCH.md (Valid forms,
+// first table row).  Every workgroup then runs the scalar chain redundantly and
+// scatter-updates its own rows.  Slabs are double-buffered by step parity: a
+// workgroup can only be two publishes ahead of a reader if it passed the
+// intermediate all-gather, which needs that reader's arrival.
+// Every spin is bounded; on time-out the abort word is set and all workgroups
+// leave the loop (the host reports the failure).
+
+struct PrbArgs {
+    int G;                 // workgroups
+    int nb;                // batches in the sweep
+    const int32_t* bptr;   // [nb+1] batch boundaries into desc
+    const ColDesc* desc;   // columns in visiting order
+    const int32_t* sp;     // [G][nb][65] slot boundaries into erow/eval
+    const uint32_t* lmask; // [G][nb][2] bit q: slot q is "long" in this row block
+    int has_long;          // 0: no long slot anywhere in the schedule (masks not even read)
+    const int32_t* erow;   // entry row ids, sorted by (workgroup, batch, slot, row)
+    double* slab;          // [2][G][64][2]
+    unsigned* abort_flag;  // [1]
+    long long* stamps;     // diagnostic: [G][16] accumulated cycles per phase (8 control-wave,
+                           // 8 worker-wave values), or nullptr
+};
+
+__device__ __forceinline__ void st_agent(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p),
+                       (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+    const unsigned long long u =
+        __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)u);
+}
+
+// ---- tagged-granule exchange ----------------------------------------------------
+// A partial sum travels as ONE naturally aligned 8-byte word: the double with its two
+// lowest mantissa bits replaced by a step tag (relative perturbation <= 2^-51, applied
+// before the value is used anywhere, so every workgroup sums identical numbers).  The
+// data is the flag (MI355X_MICROARCH.md "R2's granule"): one sc1 store publishes, sc1
+// loads poll the word itself; no drain, no counter, no fence.  Slabs are double-buffered
+// by step parity and zeroed before every launch; tag(b) = ((b >> 1) % 3) + 1 is never 0
+// and differs from the tag of the slab's previous occupant (step b - 2).
+__device__ __forceinline__ unsigned long long prb_tag(int b) {
+    return (unsigned long long)(((b >> 1) % 3) + 1);
+}
+__device__ __forceinline__ void prb_store_granule(double* p, double v, unsigned long long tag) {
+    const unsigned long long u =
+        ((unsigned long long)__double_as_longlong(v) & ~3ull) | tag;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), u, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long prb_load_granule(const double* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Worker wave `w` (0..3) sums the granules of workgroups [w*G/4, (w+1)*G/4) for slot
+// `lane` (all loads in flight together, re-swept until every tag matches); the control
+// wave later adds the four quarter sums in order w = 0..3, so the total is the same bit
+// pattern in every workgroup.  Returns false after a bounded number of sweeps.
+template <int NV>
+__device__ __forceinline__ bool prb_collect_quarter(const PrbArgs& a, int b, int w, int lane,
+                                                    int ncols, double* out /* [4][64][2] LDS */) {
+    const double* slab = a.slab + (size_t)(b & 1) * a.G * 64 * 2;
+    const unsigned long long tag = prb_tag(b);
+    const int g0 = (a.G * w) / 4, g1 = (a.G * (w + 1)) / 4;
+    double tot[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) tot[v] = 0.0;
+    bool ok = true;
+    if (lane < ncols) {
+        const double* sl = slab + (size_t)lane * 2;
+        constexpr int GU = 8;  // granule pairs polled together per lane
+        for (int gg = g0; gg < g1; gg += GU) {
+            unsigned long long t[GU][NV];
+            unsigned spins = 0;
+            for (;;) {
+                bool all = true;
+#pragma unroll
+                for (int u = 0; u < GU; ++u)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const bool in = gg + u < g1;
+                        t[u][v] = in ? prb_load_granule(sl + (size_t)(gg + u) * 128 + v) : tag;
+                        all = all && ((t[u][v] & 3ull) == tag);
+                    }
+                if (all) break;
+                if ((++spins & 63u) == 0) {
+                    if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) ||
+                        spins > (1u << 21)) {
+                        __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        ok = false;
+                        break;
+                    }
+                }
+            }
+            if (!ok) break;
+#pragma unroll
+            for (int u = 0; u < GU; ++u)
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    if (gg + u < g1) tot[v] += __longlong_as_double((long long)(t[u][v] & ~3ull));
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[((size_t)w * 64 + lane) * 2 + v] = tot[v];
+    return ok;
+}
+
+// The entries one thread owns in one step: 4 lanes share a slot, each keeps up to
+// PRB_PF entries (row, value) in registers; a slot with more than 4*PRB_PF entries in
+// this row block falls back to a reload loop for the rest.
+constexpr int PRB_PF = 4;
+// A (workgroup, step, slot) segment longer than this is a "long slot" (a very frequent
+// feature): the 4 lanes of the slot skip it and all 256 worker threads stride over it.
+constexpr int kPrbLong = 48;
+template <typename T>
+struct PrbEntries {
+    int e0, e1;
+    int row[PRB_PF];
+    T x[PRB_PF];
+};
+
+__device__ __forceinline__ void prb_load_sp(const PrbArgs& a, int g, int b, int slot, int ncols,
+                                            int& e0, int& e1, unsigned long long& lmask) {
+    e0 = 0;
+    e1 = 0;
+    lmask = 0ull;
+    if (a.has_long) {
+        const uint32_t* lm = a.lmask + ((size_t)g * a.nb + b) * 2;
+        lmask = ((unsigned long long)lm[1] << 32) | (unsigned long long)lm[0];
+    }
+    if (slot < ncols && !((lmask >> slot) & 1ull)) {  // long slots: no per-lane entries
+        const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
+        e0 = spb[slot];
+        e1 = spb[slot + 1];
+    }
+}
+
+// q-th set bit of m (q < popcount(m))
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int q) {
+    for (int t = 0; t < q; ++t) m &= m - 1;
+    return __builtin_ctzll(m);
+}
+
+template <typename T>
+__device__ __forceinline__ void prb_load_entries(const PrbArgs& a, const T* __restrict__ eval,
+                                                 int e0, int e1, int sub, PrbEntries<T>& en) {
+    en.e0 = e0;
+    en.e1 = e1;
+#pragma unroll
+    for (int u = 0; u < PRB_PF; ++u) {
+        const int e = e0 + sub + 4 * u;
+        const bool v = e < e1;
+        en.row[u] = v ? a.erow[e] : 0;
+        en.x[u] = v ? eval[e] : (T)0;
+    }
+}
+
+// Workgroup = 5 wavefronts: wave 0 is the CONTROL wave (publish, poll, chain), waves
+// 1..4 are WORKERS (256 threads = 64 slots x 4 lanes) that own the entries.  Software
+// pipeline of step b: its entries are already in worker registers (loaded during step
+// b-1 from slot bounds loaded during step b-2), so phase 1 starts with the row gathers;
+// the workers issue the next step's streaming loads while the control wave waits for
+// the other workgroups.
+constexpr int kPrbThreads = 320;
+
+template <typename T, int M, int LOSS>
+__global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
+    const Ctl* __restrict__ ctl, PrbArgs a, const T* __restrict__ eval, T* __restrict__ A_all,
+    size_t a_stride, T* __restrict__ yy, const double* __restrict__ pold_sched,
+    double* __restrict__ P, int d, int reg, const double* __restrict__ cache_in, double mu,
+    double beta, double gamma, double eta, double* __restrict__ viol_pos) {
+    T* __restrict__ A = A_all + (size_t)ctl->s * a_stride;
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // sized to pin 1 WG / CU
+    double* sh_delta = dyn_lds + 128;  // [64]
+    double* sh_pold = dyn_lds + 192;   // [64]
+    double* sh_quart = dyn_lds + 256;  // [4][64][2] quarter sums over workgroups
+    int* sh_ok = reinterpret_cast<int*>(dyn_lds + 768);
+    const typename Vec2<T>::type* yy2 = reinterpret_cast<const typename Vec2<T>::type*>(yy);
+    const int g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool control = wave == 0;
+    const int wt = tid - 64;  // worker thread id (negative on the control wave)
+    const int slot = control ? 64 : (wt >> 2), sub = wt & 3;
+    const int s = ctl->s;
+    const double lam = ctl->lam;
+    double* ps = P + (size_t)s * d;
+    double cache[M + 1];
+#pragma unroll
+    for (int t = 0; t <= M; ++t) cache[t] = cache_in[t];
+
+    double* sh_long = dyn_lds + 1024;  // [64][4][2] wave partials of long slots
+    PrbEntries<T> cur, nxt;
+    int c0 = a.bptr[0], c1 = a.bptr[1];
+    int c2 = (a.nb > 1) ? a.bptr[2] : c1;
+    int c3 = (a.nb > 2) ? a.bptr[3] : c2;
+    unsigned long long lm0 = 0ull, lm1 = 0ull;  // long-slot masks of steps b, b+1
+    {
+        int e0, e1;
+        prb_load_sp(a, g, 0, slot, c1 - c0, e0, e1, lm0);
+        prb_load_entries<T>(a, eval, e0, e1, sub, cur);
+    }
+    int ne0 = 0, ne1 = 0;  // slot bounds of step b+1
+    if (a.nb > 1) prb_load_sp(a, g, 1, slot, c2 - c1, ne0, ne1, lm1);
+    double p_slot = (slot < c1 - c0) ? pold_sched[c0 + slot] : 0.0;
+    if (tid == 0) *sh_ok = 1;
+    // diagnostic stamps (only when a.stamps != nullptr): cycles per phase, thread 0
+    const bool stamp = a.stamps != nullptr;
+    long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = stamp ? clock64() : 0;
+#define PRB_STAMP(k)                        \
+    if (stamp && tid == 0) {                \
+        const long long tn = clock64();     \
+        acc[k] += tn - tprev;               \
+        tprev = tn;                         \
+    }
+#define PRB_WSTAMP(k)                       \
+    if (stamp && tid == 64) {               \
+        const long long tn = clock64();     \
+        acc[k] += tn - tprev;               \
+        tprev = tn;                         \
+    }
+
+    for (int b = 0; b < a.nb; ++b) {
+        const int ncols = c1 - c0;
+        const int c4 = (b + 4 <= a.nb) ? a.bptr[b + 4] : c3;  // used two steps from now
+        // ---- phase 1 (workers): gather the rows of the prefetched entries, partial sums
+        // (pcd.py:52-59); A / yhat values stay in registers for phase 3
+        constexpr int AS = Kind<M>::AS;
+        double av[PRB_PF][AS];
+        double yh[PRB_PF], yt[PRB_PF], dlast[PRB_PF];
+        double pl = 0.0;
+        int jl = 0;
+        if (control) {
+            if (lane < ncols) {
+                pl = pold_sched[c0 + lane];
+                if (g == 0) jl = a.desc[c0 + lane].j;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < PRB_PF; ++u) {  // all gathers in flight before any use
+                const size_t i = (size_t)cur.row[u];
+                const typename Vec2<T>::type yv = yy2[i];
+                yh[u] = (double)yv.x;
+                yt[u] = (double)yv.y;
+#pragma unroll
+                for (int t = 0; t < AS; ++t) av[u][t] = (double)A[i * AS + t];
+            }
+            double ag = 0.0, ah = 0.0;
+#pragma unroll
+            for (int u = 0; u < PRB_PF; ++u) {
+                const double dprev = grad_factor<M>(av[u], (double)cur.x[u], p_slot);
+                dlast[u] = dprev;
+                const double dl = dloss_dev(LOSS, yh[u], yt[u]);
+                const bool v = cur.e0 + sub + 4 * u < cur.e1;
+                ag += v ? dl * dprev : 0.0;
+                ah += v ? dprev * dprev : 0.0;
+            }
+            for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {  // rare: long slot
+                const int i = a.erow[e];
+                const double x = (double)eval[e];
+                const typename Vec2<T>::type yv = yy2[i];
+                double a1[AS];
+#pragma unroll
+                for (int t = 0; t < AS; ++t) a1[t] = (double)A[(size_t)i * AS + t];
+                const double dprev = grad_factor<M>(a1, x, p_slot);
+                ag += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * dprev;
+                ah += dprev * dprev;
+            }
+            ag += __shfl_xor(ag, 1, kWave);
+            ah += __shfl_xor(ah, 1, kWave);
+            ag += __shfl_xor(ag, 2, kWave);
+            ah += __shfl_xor(ah, 2, kWave);
+            PRB_WSTAMP(0)  // gather + partial sums
+            // publish this row block's partial sums of the slot (tagged granules).  Slots
+            // beyond the batch are published too (as zeros): every word of a slab is then
+            // rewritten at every use of the buffer, so a reader can never meet a stale
+            // word that happens to carry the current tag.
+            if (sub == 0 && !((lm0 >> slot) & 1ull)) {
+                double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + slot) * 2;
+                const unsigned long long tag = prb_tag(b);
+                prb_store_granule(sl, ag, tag);
+                prb_store_granule(sl + 1, ah, tag);
+            }
+        }
+        // ---- long slots of this row block (rare: very frequent features): the whole
+        // workgroup strides over the slot's entries; one extra barrier, taken by all waves
+        const unsigned long long lmu =
+            ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(lm0 >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)lm0);
+        if (lmu != 0ull) {
+            const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
+            int qi = 0;
+            for (unsigned long long mm = lmu; mm != 0ull; mm &= mm - 1, ++qi) {
+                const int q = __builtin_ctzll(mm);
+                if (!control) {
+                    const int le0 = spb[q], le1 = spb[q + 1];
+                    const double pq = pold_sched[c0 + q];
+                    double lg = 0.0, lh = 0.0;
+                    for (int e = le0 + wt; e < le1; e += 256) {
+                        const int i = a.erow[e];
+                        const double x = (double)eval[e];
+                        const typename Vec2<T>::type yv = yy2[i];
+                        double a1[Kind<M>::AS];
+#pragma unroll
+                        for (int t = 0; t < Kind<M>::AS; ++t)
+                            a1[t] = (double)A[(size_t)i * Kind<M>::AS + t];
+                        const double dprev = grad_factor<M>(a1, x, pq);
+                        lg += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * dprev;
+                        lh += dprev * dprev;
+                    }
+                    lg = wave_sum(lg);
+                    lh = wave_sum(lh);
+                    if (lane == 0) {
+                        sh_long[(qi * 4 + (wave - 1)) * 2] = lg;
+                        sh_long[(qi * 4 + (wave - 1)) * 2 + 1] = lh;
+                    }
+                }
+            }
+            __syncthreads();
+            if (!control && wt < qi) {
+                const int q = nth_set_bit(lmu, wt);
+                double tg = 0.0, th = 0.0;
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    tg += sh_long[(wt * 4 + w4) * 2];
+                    th += sh_long[(wt * 4 + w4) * 2 + 1];
+                }
+                double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + q) * 2;
+                const unsigned long long tag = prb_tag(b);
+                prb_store_granule(sl, tg, tag);
+                prb_store_granule(sl + 1, th, tag);
+            }
+        }
+        PRB_STAMP(0)
+        double p_next = 0.0;
+        int n2e0 = 0, n2e1 = 0;
+        unsigned long long lm2 = 0ull;
+        // slot bounds + long-slot mask of step b+2: issued before the sweep so that the
+        // (scalar) mask load has landed long before the barrier's lgkmcnt(0)
+        if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
+        if (!control) {
+            PRB_WSTAMP(1)  // publish issue
+            const bool ok = prb_collect_quarter<2>(a, b, wave - 1, lane, ncols, sh_quart);
+            if (!ok) *sh_ok = 0;
+            PRB_WSTAMP(2)  // granule sweep until every workgroup's partials are in
+            if (b + 1 < a.nb) {
+                // prefetch (after the exchange: vmcnt retires in order, so streaming loads
+                // issued earlier would delay every granule check): entries of step b+1
+                // (bounds already in registers), bounds of b+2
+                prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt);
+                if (slot < c2 - c1) p_next = pold_sched[c1 + slot];
+            }
+        }
+        // B3: quarter sums in LDS.  Raw barrier: only LDS traffic must have landed; the
+        // prefetch loads just issued stay in flight across it (a __syncthreads() would
+        // add s_waitcnt vmcnt(0) and expose their HBM latency on every step).
+        PRB_WSTAMP(3)  // prefetch issue
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        PRB_STAMP(3)
+        PRB_WSTAMP(4)  // B3
+        if (!*sh_ok) break;
+        if (control) {
+            double tot[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+                tot[v] = ((sh_quart[(0 * 64 + lane) * 2 + v] + sh_quart[(1 * 64 + lane) * 2 + v]) +
+                          sh_quart[(2 * 64 + lane) * 2 + v]) +
+                         sh_quart[(3 * 64 + lane) * 2 + v];
+            const bool valid = lane < ncols;
+            const double res = pcd_chain_lanes<M>(reg, lane, ncols - 1, valid, pl, tot[0], tot[1],
+                                                  lam, mu, beta, gamma, eta, cache);
+            const double dl = valid ? (pl - res) : 0.0;
+            sh_delta[lane] = dl;
+            sh_pold[lane] = pl;
+            if (g == 0 && valid) {
+                ps[jl] = res;
+                viol_pos[c0 + lane] = fabs(dl);  // by position; folded into viol_col later
+            }
+            PRB_STAMP(4)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B4: deltas in LDS
+        PRB_STAMP(5)
+        PRB_WSTAMP(5)  // waiting for the control wave's chain
+        // ---- phase 3 (workers): scatter-update of the own rows (pcd.py:124-133)
+        if (slot < ncols) {
+            const double upd = sh_delta[slot];
+            if (upd != 0.0) {
+                const double p_old = sh_pold[slot];
+#pragma unroll
+                for (int u = 0; u < PRB_PF; ++u) {
+                    if (cur.e0 + sub + 4 * u < cur.e1) {
+                        const size_t i = (size_t)cur.row[u];
+                        const double x = (double)cur.x[u];
+                        if constexpr (M == 0) {  // pcd_all.py:92-98
+                            double yn = yh[u] - lam * av[u][0];
+                            double an = av[u][0] / (1.0 + x * p_old);
+                            an *= 1.0 + x * (p_old - upd);
+                            yn += lam * an;
+                            A[i] = (T)an;
+                            yy[2 * i] = (T)yn;
+                        } else {
+                            double dprev = x;
+#pragma unroll
+                            for (int t = 1; t < M; ++t) {
+                                const double a1 = av[u][t - 1];
+                                const double dcur = x * (a1 - p_old * dprev);
+                                A[i * (M - 1) + (t - 1)] = (T)(a1 - upd * dprev);
+                                dprev = dcur;
+                            }
+                            yy[2 * i] = (T)(yh[u] - lam * upd * dlast[u]);
+                        }
+                    }
+                }
+                for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4)
+                    pcd_sync_entry<T, M>((size_t)a.erow[e], (double)eval[e], p_old, upd, lam, A,
+                                         yy);
+            }
+        }
+        if (lmu != 0ull && !control) {  // long slots: every worker thread scatters
+            const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
+            for (unsigned long long mm = lmu; mm != 0ull; mm &= mm - 1) {
+                const int q = __builtin_ctzll(mm);
+                const double upd = sh_delta[q];
+                if (upd != 0.0) {
+                    const double p_old = sh_pold[q];
+                    const int le0 = spb[q], le1 = spb[q + 1];
+                    for (int e = le0 + wt; e < le1; e += 256)
+                        pcd_sync_entry<T, M>((size_t)a.erow[e], (double)eval[e], p_old, upd, lam,
+                                             A, yy);
+                }
+            }
+        }
+        cur = nxt;
+        p_slot = p_next;
+        ne0 = n2e0;
+        ne1 = n2e1;
+        lm0 = lm1;
+        lm1 = lm2;
+        c0 = c1;
+        c1 = c2;
+        c2 = c3;
+        c3 = c4;
+        PRB_WSTAMP(6)  // scatter issue
+        __syncthreads();  // B5: rows move between slots from step to step
+        PRB_STAMP(6)
+        PRB_WSTAMP(7)  // B5 (stores acknowledged)
+    }
+#undef PRB_STAMP
+#undef PRB_WSTAMP
+    if (stamp && (tid == 0 || tid == 64)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a.stamps[(size_t)g * 16 + (tid == 64 ? 8 : 0) + q] = acc[q];
+    }
+}
+
+// cd_linear._cd_linear_epoch (optimizer/cd_linear.py:8-33) as one persistent launch:
+// same row-block ownership, entry stream and tagged-granule exchange as pcd_prb_kernel,
+// one value per slot; the update has no regularizer, so the control wave's "chain" is
+// lane-parallel.  w_sched / cn_sched are w and col_norm_sq in visiting order (w as of the
+// epoch start: workgroup 0 writes the new w[j] while others may still read the old one).
+template <typename T, int LOSS>
+__global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
+    PrbArgs a, const T* __restrict__ eval, T* __restrict__ yy,
+    const double* __restrict__ w_sched, const double* __restrict__ cn_sched,
+    double* __restrict__ w, double alpha, double mu, double* __restrict__ viol_pos) {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    double* sh_delta = dyn_lds + 128;  // [64]
+    double* sh_quart = dyn_lds + 256;  // [4][64][2]
+    int* sh_ok = reinterpret_cast<int*>(dyn_lds + 768);
+    const typename Vec2<T>::type* yy2 = reinterpret_cast<const typename Vec2<T>::type*>(yy);
+    const int g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool control = wave == 0;
+    const int wt = tid - 64;
+    const int slot = control ? 64 : (wt >> 2), sub = wt & 3;
+    double* sh_long = dyn_lds + 1024;  // [64][4][2]
+    PrbEntries<T> cur, nxt;
+    int c0 = a.bptr[0], c1 = a.bptr[1];
+    int c2 = (a.nb > 1) ? a.bptr[2] : c1;
+    int c3 = (a.nb > 2) ? a.bptr[3] : c2;
+    unsigned long long lm0 = 0ull, lm1 = 0ull;
+    {
+        int e0, e1;
+        prb_load_sp(a, g, 0, slot, c1 - c0, e0, e1, lm0);
+        prb_load_entries<T>(a, eval, e0, e1, sub, cur);
+    }
+    int ne0 = 0, ne1 = 0;
+    if (a.nb > 1) prb_load_sp(a, g, 1, slot, c2 - c1, ne0, ne1, lm1);
+    if (tid == 0) *sh_ok = 1;
+    for (int b = 0; b < a.nb; ++b) {
+        const int ncols = c1 - c0;
+        const int c4 = (b + 4 <= a.nb) ? a.bptr[b + 4] : c3;
+        double yh[PRB_PF];
+        double wl = 0.0, cnl = 0.0;
+        int jl = 0;
+        int n2e0 = 0, n2e1 = 0;
+        unsigned long long lm2 = 0ull;
+        const unsigned long long lmu =
+            ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(lm0 >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)lm0);
+        if (lmu != 0ull) {  // long slots first: whole-workgroup partial sums (see pcd_prb_kernel)
+            const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
+            int qi = 0;
+            for (unsigned long long mm = lmu; mm != 0ull; mm &= mm - 1, ++qi) {
+                const int q = __builtin_ctzll(mm);
+                if (!control) {
+                    const int le0 = spb[q], le1 = spb[q + 1];
+                    double lg = 0.0;
+                    for (int e = le0 + wt; e < le1; e += 256) {
+                        const typename Vec2<T>::type yv = yy2[(size_t)a.erow[e]];
+                        lg += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * (double)eval[e];
+                    }
+                    lg = wave_sum(lg);
+                    if (lane == 0) sh_long[(qi * 4 + (wave - 1)) * 2] = lg;
+                }
+            }
+            __syncthreads();
+            if (!control && wt < qi) {
+                const int q = nth_set_bit(lmu, wt);
+                double tg = 0.0;
+                for (int w4 = 0; w4 < 4; ++w4) tg += sh_long[(wt * 4 + w4) * 2];
+                double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + q) * 2;
+                prb_store_granule(sl, tg, prb_tag(b));
+            }
+        }
+        if (control) {
+            if (lane < ncols) {
+                wl = w_sched[c0 + lane];
+                cnl = cn_sched[c0 + lane];
+                if (g == 0) jl = a.desc[c0 + lane].j;
+            }
+        } else {
+            double yt[PRB_PF];
+#pragma unroll
+            for (int u = 0; u < PRB_PF; ++u) {
+                const typename Vec2<T>::type yv = yy2[(size_t)cur.row[u]];
+                yh[u] = (double)yv.x;
+                yt[u] = (double)yv.y;
+            }
+            double ag = 0.0;
+#pragma unroll
+            for (int u = 0; u < PRB_PF; ++u) {
+                const bool v = cur.e0 + sub + 4 * u < cur.e1;
+                ag += v ? dloss_dev(LOSS, yh[u], yt[u]) * (double)cur.x[u] : 0.0;
+            }
+            for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {
+                const typename Vec2<T>::type yv = yy2[(size_t)a.erow[e]];
+                ag += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * (double)eval[e];
+            }
+            ag += __shfl_xor(ag, 1, kWave);
+            ag += __shfl_xor(ag, 2, kWave);
+            if (sub == 0 && !((lm0 >> slot) & 1ull)) {
+                double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + slot) * 2;
+                prb_store_granule(sl, ag, prb_tag(b));
+            }
+            if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
+            const bool ok = prb_collect_quarter<1>(a, b, wave - 1, lane, ncols, sh_quart);
+            if (!ok) *sh_ok = 0;
+            if (b + 1 < a.nb) {
+                prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt);
+            }
+        }
+        if (control && b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // quarter sums in LDS
+        if (!*sh_ok) break;
+        if (control) {
+            const double tot = ((sh_quart[(0 * 64 + lane) * 2] + sh_quart[(1 * 64 + lane) * 2]) +
+                                sh_quart[(2 * 64 + lane) * 2]) +
+                               sh_quart[(3 * 64 + lane) * 2];
+            const bool valid = lane < ncols;
+            double upd = tot;           // cd_linear.py:19-24
+            upd += alpha * wl;
+            const double inv = mu * cnl + alpha;
+            upd /= inv;
+            if (!valid) upd = 0.0;
+            sh_delta[lane] = upd;
+            if (g == 0 && valid) {
+                w[jl] = wl - upd;
+                viol_pos[c0 + lane] = fabs(upd);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // updates in LDS
+        if (slot < ncols) {
+            const double upd = sh_delta[slot];
+            if (upd != 0.0) {
+#pragma unroll
+                for (int u = 0; u < PRB_PF; ++u)
+                    if (cur.e0 + sub + 4 * u < cur.e1)
+                        yy[2 * (size_t)cur.row[u]] = (T)(yh[u] - upd * (double)cur.x[u]);
+                for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {
+                    const size_t i = (size_t)a.erow[e];
+                    yy[2 * i] = (T)((double)yy[2 * i] - upd * (double)eval[e]);
+                }
+            }
+        }
+        if (lmu != 0ull && !control) {
+            const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
+            for (unsigned long long mm = lmu; mm != 0ull; mm &= mm - 1) {
+                const int q = __builtin_ctzll(mm);
+                const double upd = sh_delta[q];
+                if (upd != 0.0) {
+                    const int le0 = spb[q], le1 = spb[q + 1];
+                    for (int e = le0 + wt; e < le1; e += 256) {
+                        const size_t i = (size_t)a.erow[e];
+                        yy[2 * i] = (T)((double)yy[2 * i] - upd * (double)eval[e]);
+                    }
+                }
+            }
+        }
+        cur = nxt;
+        ne0 = n2e0;
+        ne1 = n2e1;
+        lm0 = lm1;
+        lm1 = lm2;
+        c0 = c1;
+        c1 = c2;
+        c2 = c3;
+        c3 = c4;
+        __syncthreads();
+    }
+}
+
+// out[pos] = v[desc[pos].j]
+__global__ void gather_sched_kernel(int d, const ColDesc* __restrict__ desc,
+                                    const double* __restrict__ v, double* __restrict__ out) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < d) out[pos] = v[desc[pos].j];
+}
+
+// viol_col[desc[pos].j] += viol_pos[pos]   (sum_viol bookkeeping of the persistent pass)
+__global__ void fold_viol_kernel(int d, const ColDesc* __restrict__ desc,
+                                 const double* __restrict__ viol_pos,
+                                 double* __restrict__ viol_col) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < d) viol_col[desc[pos].j] += viol_pos[pos];
+}
+
+// in visiting order: out[pos] = P[s, desc[pos].j]
+__global__ void snapshot_row_kernel(const Ctl* __restrict__ ctl, const double* __restrict__ P,
+                                    int d, const ColDesc* __restrict__ desc,
+                                    double* __restrict__ out) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < d) out[pos] = P[(size_t)ctl->s * d + desc[pos].j];
+}
+
+// erow/eval = cidx/cval gathered through the host-built entry permutation
+template <typename T>
+__global__ void prb_gather_kernel(int64_t nnz, const int32_t* __restrict__ src,
+                                  const int32_t* __restrict__ cidx, const T* __restrict__ cval,
+                                  int32_t* __restrict__ erow, T* __restrict__ eval) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) {
+        const int32_t q = src[e];
+        erow[e] = cidx[q];
+        eval[e] = cval[q];
+    }
+}
+
+
+}  // namespace spfm

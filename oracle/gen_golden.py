@@ -27,6 +27,7 @@ Fixture families:
   g6  anova_kernel / poly_predict, degree 2,3,4, sparse and dense
   g7  API behaviours (n_iter_ semantics, stale P_ in pbcd callbacks, messages)
   g8  all-subsets model: the reference's own test cells + sparse trajectories
+  g9  psgd solver: the reference's own test grid, prox operators, sparse trajectories
 """
 import contextlib
 import io
@@ -613,7 +614,148 @@ def gen_g8():
     save("g8_all_subsets.npz", **out)
 
 
+# --------------------------------------------------------------------- g9
+def fit_psgd_verbose(est, X, y):
+    """fit() with verbose=True; returns the per-epoch mean losses printed by _fit_psgd."""
+    est.set_params(verbose=True)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        est.fit(X, y)
+    vals = []
+    for line in buf.getvalue().splitlines():
+        if line.startswith("Epoch"):
+            vals.append(float(line.split()[-1]))
+    return np.array(vals)
+
+
+def gen_g9():
+    """psgd solver.
+      cells  the reference's own test grid (tests/test_psgd.py:240-366): estimator.fit on
+             the RandomState(1) data, all degree x batch_size x learning_rate x
+             fit_linear x loss x regularizer combinations (gamma = 0 as in the reference)
+      prox   regularizer.prox on seeded arrays for the strengths of tests/test_prox.py:54,69
+      traj   sparse 300 x 60 problem with gamma > 0: per-epoch mean loss, it_, final P_/w_
+    """
+    from itertools import product
+    from sparsepoly.regularizer import L1, L21, SquaredL12, SquaredL21
+
+    out = {}
+    # ---- cells
+    rng = np.random.RandomState(1)
+    n_components, n_features, n_samples = 5, 4, 50
+    X = rng.randn(n_samples, n_features)
+    P = rng.randn(n_components, n_features)
+    lams = rng.randn(n_components)
+    out["X"] = X
+    names = []
+    for degree in (2, 3, 4):
+        y_reg = poly_predict(X, P, lams, kernel="anova", degree=degree)
+        out["y|deg%d" % degree] = y_reg
+        for batch_size, lr, fit_linear, loss, regname in product(
+                [1, 5, 8, n_samples, "auto"], ["constant", "optimal"], [True, False],
+                ["squared", "squared_hinge", "logistic"], ["l1", "l21", "squaredl12",
+                                                           "squaredl21"]):
+            kw = dict(degree=degree, n_components=n_components, fit_lower=None,
+                      fit_linear=fit_linear, alpha=1e-3, beta=1e-3, gamma=0.0,
+                      regularizer=regname, learning_rate=lr, eta0=0.01, warm_start=False,
+                      tol=1e-3, max_iter=10, random_state=0, shuffle=False, solver="psgd",
+                      batch_size=batch_size)
+            if loss == "squared":
+                est = SparseFactorizationMachineRegressor(**kw)
+                y = y_reg
+            else:
+                est = SparseFactorizationMachineClassifier(loss=loss, **kw)
+                y = np.sign(y_reg)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                est.fit(X, y)
+            key = "deg%d|%s|%s|%d|%s|%s" % (degree, batch_size, lr, fit_linear, loss, regname)
+            names.append(key)
+            out["P|" + key] = est.P_
+            out["w|" + key] = est.w_
+            out["n_iter|" + key] = np.array([est.n_iter_, est.it_])
+    out["cells"] = np.array(names)
+
+    # ---- prox
+    prng = np.random.RandomState(33)
+    arr = 10 * (prng.rand(150, 12) * 2 - 1)       # (n_features, n_components)
+    arr[7] = 0.0                                  # an all-zero row
+    arr[9, 3] = 0.0
+    arr[20:23] *= 1e-3                            # small-norm rows (l21 leaves them unchanged)
+    out["prox_in"] = arr
+    strengths = [0.0, 0.0001, 0.001, 0.01, 0.1, 1, 10]
+    out["prox_strengths"] = np.array(strengths)
+    for regname, cls in (("l1", L1), ("l21", L21), ("squaredl12", SquaredL12),
+                         ("squaredl21", SquaredL21)):
+        for si, st in enumerate(strengths):
+            reg = cls()
+            reg.init_cache_psgd(2, arr.shape[0], arr.shape[1])
+            Pq = np.array(arr)
+            with warnings.catch_warnings(), np.errstate(all="ignore"):
+                warnings.simplefilter("ignore")
+                reg.prox(Pq, st, 2)
+            out["prox|%s|%d" % (regname, si)] = Pq
+
+    # ---- trajectories on a sparse problem
+    Xs, ys = small_problem()
+    n, d = Xs.shape
+    out.update({"X_data": Xs.data, "X_indices": Xs.indices, "X_indptr": Xs.indptr,
+                "X_shape": np.array(Xs.shape), "ys": ys})
+    tnames = []
+    tcases = [
+        # tag, reg, degree, k, fit_lower, lr, batch, shuffle, gamma, power_t
+        ("l1", "l1", 2, 8, "explicit", "optimal", "auto", False, 1e-2, 1.0),
+        ("l21", "l21", 2, 8, "explicit", "constant", 16, False, 3e-2, 1.0),
+        ("sq12", "squaredl12", 2, 8, "explicit", "optimal", 32, False, 1e-2, 1.0),
+        ("sq21", "squaredl21", 2, 8, "explicit", "invscaling", 25, False, 1e-2, 0.5),
+        ("l1d3", "l1", 3, 6, "explicit", "pegasos", 20, False, 1e-3, 1.0),
+        ("sq12d3", "squaredl12", 3, 6, None, "optimal", 300, False, 1e-2, 1.0),
+        ("l21sh", "l21", 2, 8, "explicit", "optimal", 7, True, 3e-2, 0.75),
+        ("sq21sh", "squaredl21", 3, 5, "explicit", "constant", 1, True, 1e-3, 1.0),
+    ]
+    for tag, regname, degree, k, fit_lower, lr, batch, shuffle, gamma, power_t in tcases:
+        n_orders = degree - 1 if fit_lower == "explicit" else 1
+        P0 = 0.1 * np.random.RandomState(0).randn(n_orders, k, d)
+        lam = np.sign(np.random.RandomState(5).randn(k))
+        # pegasos uses eta = 1 / (beta * it): needs a large beta to be stable
+        alpha, beta = (20.0, 20.0) if lr == "pegasos" else (1e-2, 0.1)
+        for loss in ("squared", "squared_hinge", "logistic"):
+            yy = ys if loss == "squared" else np.where(ys > np.median(ys), 1.0, -1.0)
+            kw = dict(degree=degree, n_components=k, fit_lower=fit_lower, fit_linear=True,
+                      alpha=alpha, beta=beta, gamma=gamma, regularizer=regname,
+                      learning_rate=lr, eta0=0.05, power_t=power_t, warm_start=True, tol=-1.0,
+                      n_iter_no_change=1000, max_iter=4, random_state=3, shuffle=shuffle,
+                      solver="psgd", batch_size=batch)
+            if loss == "squared":
+                est = SparseFactorizationMachineRegressor(**kw)
+            else:
+                est = SparseFactorizationMachineClassifier(loss=loss, **kw)
+            est.P_ = np.array(P0)
+            est.w_ = np.zeros(d)
+            est.lams_ = np.array(lam)
+            losses = fit_psgd_verbose(est, Xs, yy)
+            key = "%s|%s" % (tag, loss)
+            tnames.append(key)
+            out["tmeta|" + key] = np.array(json.dumps(dict(
+                regularizer=regname, degree=degree, k=k, fit_lower=fit_lower,
+                learning_rate=lr, batch_size=batch, shuffle=shuffle, gamma=gamma,
+                power_t=power_t, loss=loss, alpha=alpha, beta=beta, eta0=0.05, max_iter=4,
+                random_state=3)))
+            out["tP0|" + key] = P0
+            out["tlams|" + key] = lam
+            out["tloss|" + key] = losses
+            out["tP|" + key] = est.P_
+            out["tw|" + key] = est.w_
+            out["tit|" + key] = np.array([est.n_iter_, est.it_])
+            assert np.isfinite(est.P_).all() and np.isfinite(losses).all(), key
+            print(key, "loss", losses, "nnz(P)=%.2f" % np.mean(est.P_ != 0),
+                  "|P|max=%.3g" % np.abs(est.P_).max())
+    out["tcases"] = np.array(tnames)
+    save("g9_psgd.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for g in which:
         globals()["gen_" + g]()

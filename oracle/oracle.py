@@ -145,6 +145,19 @@ def lib():
     L.spo_anova_predict_csr.argtypes = [
         C.c_int64, _lp, _ip, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp,
     ]
+    L.spo_prox_squaredl12.restype = None
+    L.spo_prox_squaredl12.argtypes = [_dp, C.c_int64, C.c_int64, C.c_double]
+    L.spo_reg_prox.restype = C.c_int
+    L.spo_reg_prox.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_double]
+    L.spo_psgd_get_eta.restype = None
+    L.spo_psgd_get_eta.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   C.c_int64, _dp, _dp]
+    L.spo_psgd_epoch.restype = C.c_double
+    L.spo_psgd_epoch.argtypes = [
+        _dp, _dp, _dp, C.c_int, C.c_int, C.c_int64, C.c_int, _lp, _ip, _dp, _dp, C.c_int,
+        C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _ip, C.c_int, C.c_double,
+        C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int64),
+    ]
     _lib = L
     return L
 
@@ -319,6 +332,52 @@ def pbcd_all_epoch(P, X, y, y_pred, lams, beta, gamma, eta, regularizer, loss, A
     )
 
 
+LEARNING_RATE = {"constant": 0, "optimal": 1, "pegasos": 2, "invscaling": 3}
+
+
+class CSR(object):
+    """Row-major view used by psgd (reference: dataset.py get_dataset(X, "c"))."""
+
+    def __init__(self, X):
+        Xr = sp.csr_matrix(X, dtype=np.float64)
+        Xr.sum_duplicates()
+        Xr.sort_indices()
+        self.n, self.d = Xr.shape
+        self.indptr = np.ascontiguousarray(Xr.indptr, dtype=np.int64)
+        self.indices = np.ascontiguousarray(Xr.indices, dtype=np.int32)
+        self.data = np.ascontiguousarray(Xr.data, dtype=np.float64)
+        self.nnz = int(self.indptr[-1])
+
+
+def reg_prox(name, P, strength):
+    """regularizer.prox(P, strength, degree) on P (d, k) in place (l1.py:50, l21.py:43,
+    squaredl12.py:66, squaredl21.py:63)."""
+    assert P.flags.c_contiguous and P.dtype == np.float64
+    rc = lib().spo_reg_prox(REGULARIZERS[name], _d(P), P.shape[0], P.shape[1], float(strength))
+    if rc:
+        raise AttributeError("%s has no prox" % name)
+
+
+def prox_squaredl12(p, strength):
+    """regularizer/utils.py:27-70 on a contiguous vector, in place."""
+    assert p.flags.c_contiguous and p.dtype == np.float64
+    lib().spo_prox_squaredl12(_d(p), p.size, 1, float(strength))
+
+
+def psgd_epoch(P, w, X, y, lams, degree, alpha, beta, gamma, regularizer, loss,
+               indices_samples, fit_linear, eta0, learning_rate, power_t, batch_size, it):
+    """optimizer/psgd.py:125-199.  P (n_orders, d, k); X a CSR view.  Returns (sum_loss, it)."""
+    idx = np.ascontiguousarray(indices_samples, dtype=np.int32)
+    itc = C.c_int64(int(it))
+    sl = lib().spo_psgd_epoch(
+        _d(P), _d(w), _d(lams), P.shape[0], P.shape[2], X.n, X.d, _l(X.indptr), _i(X.indices),
+        _d(X.data), _d(y), LOSSES[loss], REGULARIZERS[regularizer], int(degree), float(alpha),
+        float(beta), float(gamma), _i(idx), int(bool(fit_linear)), float(eta0),
+        LEARNING_RATE[learning_rate] if isinstance(learning_rate, str) else int(learning_rate),
+        float(power_t), int(batch_size), C.byref(itc))
+    return sl, itc.value
+
+
 def all_subsets_predict(X, P, lams):
     """kernels.py:117-137,140-153 (kernel='all-subsets'): sum_s lams[s] prod_j (1 + x_ij p_sj)."""
     Xr = sp.csr_matrix(X, dtype=np.float64)
@@ -428,7 +487,8 @@ class OracleFM(object):
                  regularizer="squaredl12", alpha=1, beta=1, gamma=1, mean=False, tol=1e-6,
                  fit_lower="explicit", fit_linear=True, init_lambdas="ones", max_iter=100,
                  shuffle=False, eta0=1.0, random_state=None, feature_order=None,
-                 component_order=None, callback=None, n_calls=10):
+                 component_order=None, callback=None, n_calls=10, batch_size="auto",
+                 learning_rate="optimal", power_t=1.0, n_iter_no_change=5):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -473,7 +533,10 @@ class OracleFM(object):
             col_norm_sq = np.einsum("ij,ij->j", np.asarray(X, float), np.asarray(X, float))
         self.history = []
         self.y_pred_ = y_pred
-        if self.solver == "pcd":
+        if self.solver == "psgd":
+            self.it_ = 1
+            conv, self.n_iter_ = self._fit_psgd(CSR(X), y, rng)
+        elif self.solver == "pcd":
             conv, self.n_iter_ = self._fit_pcd(ds, y, y_pred, col_norm_sq, reg, rng)
         elif self.solver == "pbcd":
             conv, self.n_iter_ = self._fit_pbcd(ds, y, y_pred, col_norm_sq, reg, rng)
@@ -524,6 +587,39 @@ class OracleFM(object):
                 converged = True
                 break
         return converged, it
+
+    def _fit_psgd(self, X, y, rng):
+        """sparse_factorization_machines.py:94-173"""
+        n, d = X.n, X.d
+        idx = np.arange(n, dtype=np.int32)
+        bs = int(n * d / X.nnz) if self.batch_size == "auto" else int(self.batch_size)
+        if self.learning_rate not in LEARNING_RATE:
+            raise ValueError("learning_rate %s is not supported." % self.learning_rate)
+        P = np.ascontiguousarray(self.P_.swapaxes(1, 2))
+        best, noimp, converged, epoch = np.inf, 0, False, 0
+        for epoch in range(self.max_iter):
+            if self.shuffle:
+                rng.shuffle(idx)
+            sl, self.it_ = psgd_epoch(P, self.w_, X, y, self.lams_, self.degree, self.alpha,
+                                      self.beta, self.gamma, self.regularizer, self.loss, idx,
+                                      self.fit_linear, self.eta0, self.learning_rate,
+                                      self.power_t, bs, self.it_)
+            if (self.callback is not None) and epoch % self.n_calls == 0:
+                if self.callback(self) is not None:
+                    break
+            sl /= n
+            self.history.append((sl, self.it_))
+            if sl > (best - self.tol):
+                noimp += 1
+            else:
+                noimp = 0
+            if sl < best:
+                best = sl
+            if noimp >= self.n_iter_no_change:
+                converged = True
+                break
+        self.P_[:, :, :] = np.array(P.swapaxes(1, 2))
+        return converged, epoch
 
     def _fit_pbcd(self, X, y, y_pred, col_norm_sq, reg, rng):
         n, d = X.n, X.d

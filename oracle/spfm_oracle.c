@@ -833,3 +833,216 @@ void spo_anova_predict_csr(int64_t n, const int64_t* indptr, const int32_t* indi
         out_accumulate[i] += acc;
     }
 }
+
+/* ------------------------------------------------------------------ psgd */
+
+/* sparsepoly/regularizer/utils.py:27-70 (prox_squaredl12).  The reference finds
+ * the support of the prox of strength * (sum_i |p_i|)^2 with a randomised-pivot
+ * selection; the support {i : |p_i| >= tau} and S = sum of its |p_i| are unique,
+ * so this restatement finds them with a descending sort (deterministic; S differs
+ * from the reference's only in summation order) and applies the same final lines
+ * :69-70:  S /= 1 + 2*strength*theta;  soft_thresholding(p, 2*strength*S). */
+static int cmp_desc(const void* a, const void* b) {
+    const double x = *(const double*)a, y = *(const double*)b;
+    return (x < y) - (x > y);
+}
+void spo_prox_squaredl12(double* p, int64_t n, int64_t stride, double strength) {
+    double* a = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; ++i) a[i] = fabs(p[i * stride]);
+    qsort(a, (size_t)n, sizeof(double), cmp_desc);
+    double S = 0.0, run = 0.0;
+    int64_t theta = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        run += a[i];
+        /* utils.py:54-55: pivot >= 2*strength*(S + S_Gi) / (1 + 2*strength*(theta + n_greater)) */
+        const double cond = 2 * strength * run / (1.0 + 2.0 * strength * (double)(i + 1));
+        if (a[i] >= cond) {
+            S = run;
+            theta = i + 1;
+        } else {
+            break;
+        }
+    }
+    free(a);
+    S /= 1.0 + 2.0 * strength * (double)theta;
+    const double thr = 2 * strength * S;
+    for (int64_t i = 0; i < n; ++i) { /* utils.py:8-9 soft_thresholding */
+        const double v = p[i * stride];
+        const double m = fabs(v) - thr;
+        const double sg = (v > 0) - (v < 0);
+        p[i * stride] = sg * (m > 0.0 ? m : 0.0);
+    }
+}
+
+/* regularizer.prox(P, strength, degree) on P (d, k) row-major, with the default
+ * `transpose` of each class (base.py:27-34 constructs them without arguments):
+ *   l1         l1.py:50-51
+ *   l21        l21.py:43-48   (rows with norm <= strength are left UNCHANGED:
+ *                              their norm is replaced by inf, so the factor is 1)
+ *   squaredl12 squaredl12.py:66-75 (transpose=True: one prox per component column)
+ *   squaredl21 squaredl21.py:63-74 (row norms, prox of the norm vector, rescale) */
+int spo_reg_prox(int kind, double* P, int d, int k, double strength) {
+    if (kind == SPO_REG_L1) {
+        for (size_t e = 0; e < (size_t)d * k; ++e) {
+            const double v = P[e];
+            const double m = fabs(v) - strength;
+            const double sg = (v > 0) - (v < 0);
+            P[e] = sg * (m > 0.0 ? m : 0.0);
+        }
+        return 0;
+    }
+    if (kind == SPO_REG_L21) {
+        for (int j = 0; j < d; ++j) {
+            double* pj = P + (size_t)j * k;
+            double q = 0.0;
+            for (int s = 0; s < k; ++s) q += fabs(pj[s]) * fabs(pj[s]);
+            double nr = sqrt(q);
+            if (nr <= strength) nr = INFINITY;
+            const double f = 1.0 - strength / nr;
+            for (int s = 0; s < k; ++s) pj[s] *= f;
+        }
+        return 0;
+    }
+    if (kind == SPO_REG_SQUAREDL12) {
+        for (int s = 0; s < k; ++s) spo_prox_squaredl12(P + s, d, k, strength);
+        return 0;
+    }
+    if (kind == SPO_REG_SQUAREDL21) {
+        double* norms = (double*)malloc(sizeof(double) * (size_t)d);
+        for (int j = 0; j < d; ++j) {
+            double* pj = P + (size_t)j * k;
+            double q = 0.0;
+            for (int s = 0; s < k; ++s) q += fabs(pj[s]) * fabs(pj[s]);
+            norms[j] = sqrt(q);
+            if (norms[j] > 0)
+                for (int s = 0; s < k; ++s) pj[s] /= norms[j];
+        }
+        spo_prox_squaredl12(norms, d, 1, strength);
+        for (int j = 0; j < d; ++j) {
+            double* pj = P + (size_t)j * k;
+            for (int s = 0; s < k; ++s) pj[s] *= norms[j];
+        }
+        free(norms);
+        return 0;
+    }
+    return -1; /* omegati / omegacs define no prox (psgd unsupported) */
+}
+
+/* sparsepoly/optimizer/psgd.py:9-22 */
+void spo_psgd_get_eta(int learning_rate, double eta0, double alpha, double beta,
+                      double power_t, int64_t it, double* eta_P, double* eta_w) {
+    if (learning_rate == 0) {
+        *eta_P = eta0;
+        *eta_w = eta0;
+    } else if (learning_rate == 1) {
+        const double eta_it = eta0 * (double)it;
+        *eta_P = eta0 / pow(1.0 + eta_it * beta, power_t);
+        *eta_w = eta0 / pow(1.0 + eta_it * alpha, power_t);
+    } else if (learning_rate == 2) {
+        *eta_P = 1.0 / (beta * (double)it);
+        *eta_w = 1.0 / (alpha * (double)it);
+    } else {
+        const double eta = eta0 / pow((double)it, power_t);
+        *eta_P = eta;
+        *eta_w = eta;
+    }
+}
+
+/* sparsepoly/optimizer/psgd.py:125-199 (psgd_epoch) with its helpers :25-122.
+ * CSR input (rows): indptr int64[n+1], indices int32, data f64.
+ * P (n_orders, d, k) row-major (the reference's "copy for fast training",
+ * sparse_factorization_machines.py:113); w (d); order o has degree `degree - o`.
+ * Returns sum_loss; *it is advanced once per parameter update. */
+double spo_psgd_epoch(double* P, double* w, const double* lams, int n_orders, int k,
+                      int64_t n, int d, const int64_t* indptr, const int32_t* indices,
+                      const double* data, const double* y, int loss, int reg, int degree,
+                      double alpha, double beta, double gamma,
+                      const int32_t* indices_samples, int fit_linear, double eta0,
+                      int learning_rate, double power_t, int64_t batch_size, int64_t* it) {
+    const size_t np_ = (size_t)n_orders * d * k;
+    double* grad_P = (double*)calloc(np_, sizeof(double));
+    double* grad_w = (double*)calloc((size_t)d, sizeof(double));
+    double* A = (double*)malloc(sizeof(double) * (size_t)n_orders * (degree + 1) * k);
+    double* dA = (double*)malloc(sizeof(double) * (size_t)degree * k);
+    double sum_loss = 0.0;
+    int64_t b = 0;
+    for (int64_t ii = 0; ii < n; ++ii) {
+        const int64_t i = indices_samples[ii];
+        const int64_t lo = indptr[i], hi = indptr[i + 1];
+        /* _pred :47-57 */
+        double y_pred = 0.0;
+        for (int64_t jj = lo; jj < hi; ++jj) y_pred += data[jj] * w[indices[jj]];
+        for (int o = 0; o < n_orders; ++o) {
+            const int deg = degree - o;
+            double* Ao = A + (size_t)o * (degree + 1) * k;
+            const double* Po = P + (size_t)o * d * k;
+            for (int s = 0; s < k; ++s) Ao[s] = 1.0;
+            for (int t = 1; t <= degree; ++t)
+                for (int s = 0; s < k; ++s) Ao[(size_t)t * k + s] = 0.0;
+            for (int64_t jj = lo; jj < hi; ++jj) { /* _anova :34-44 */
+                const double* pj = Po + (size_t)indices[jj] * k;
+                const double x = data[jj];
+                for (int t = 0; t < deg; ++t)
+                    for (int s = 0; s < k; ++s)
+                        Ao[(size_t)(deg - t) * k + s] += Ao[(size_t)(deg - t - 1) * k + s] * x * pj[s];
+            }
+            double dot = 0.0;
+            for (int s = 0; s < k; ++s) dot += lams[s] * Ao[(size_t)deg * k + s];
+            y_pred += dot;
+        }
+        sum_loss += spo_loss(loss, y_pred, y[i]);
+        /* _update_grads :60-91 */
+        const double dL = spo_dloss(loss, y_pred, y[i]);
+        if (fit_linear)
+            for (int64_t jj = lo; jj < hi; ++jj) grad_w[indices[jj]] += dL * data[jj];
+        for (int o = 0; o < n_orders; ++o) {
+            const int deg = degree - o;
+            const double* Ao = A + (size_t)o * (degree + 1) * k;
+            const double* Po = P + (size_t)o * d * k;
+            double* Go = grad_P + (size_t)o * d * k;
+            for (int64_t jj = lo; jj < hi; ++jj) {
+                const int j = indices[jj];
+                const double x = data[jj];
+                const double* pj = Po + (size_t)j * k;
+                for (int s = 0; s < k; ++s) dA[s] = x; /* _grad_anova :25-31 */
+                for (int t = 1; t < deg; ++t)
+                    for (int s = 0; s < k; ++s)
+                        dA[(size_t)t * k + s] =
+                            x * (Ao[(size_t)t * k + s] - pj[s] * dA[(size_t)(t - 1) * k + s]);
+                for (int s = 0; s < k; ++s)
+                    Go[(size_t)j * k + s] += dL * lams[s] * dA[(size_t)(deg - 1) * k + s];
+            }
+        }
+        b += 1;
+        if (b == batch_size || ii == n - 1) { /* :177-198 */
+            double eta_P, eta_w;
+            spo_psgd_get_eta(learning_rate, eta0, alpha, beta, power_t, *it, &eta_P, &eta_w);
+            /* _update_params :94-122 */
+            if (fit_linear) {
+                const double cw = eta_w / (double)b;
+                for (int j = 0; j < d; ++j) {
+                    grad_w[j] *= cw;
+                    w[j] -= grad_w[j];
+                    w[j] /= 1 + eta_w * alpha;
+                }
+            }
+            const double cp = eta_P / (double)b;
+            for (size_t e = 0; e < np_; ++e) {
+                grad_P[e] *= cp;
+                P[e] -= grad_P[e];
+                P[e] /= 1.0 + eta_P * beta;
+            }
+            for (int o = 0; o < n_orders; ++o)
+                spo_reg_prox(reg, P + (size_t)o * d * k, d, k, gamma * eta_P / (1 + eta_P * beta));
+            memset(grad_P, 0, sizeof(double) * np_);
+            memset(grad_w, 0, sizeof(double) * (size_t)d);
+            b = 0;
+            *it += 1;
+        }
+    }
+    free(grad_P);
+    free(grad_w);
+    free(A);
+    free(dA);
+    return sum_loss;
+}

@@ -344,3 +344,76 @@ def test_g8_all_subsets_kernel(oracle):
     z = load_golden("g8_all_subsets.npz")
     got = oracle.all_subsets_predict(z["X"], z["P_true"], z["lams_true"])
     np.testing.assert_allclose(got, z["K"] @ z["lams_true"], rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------ g9: psgd
+def _g9_groups():
+    """The 720 reference test cells, grouped by (degree, loss, regularizer) so the suite
+    stays small: each test checks its 20 batch_size x learning_rate x fit_linear cells."""
+    cells = [str(c) for c in load_golden("g9_psgd.npz")["cells"]]
+    groups = {}
+    for c in cells:
+        deg, bs, lr, fl, loss, reg = c.split("|")
+        groups.setdefault("%s|%s|%s" % (deg, loss, reg), []).append(c)
+    return groups
+
+
+@pytest.mark.parametrize("group", sorted(_g9_groups()))
+def test_g9_psgd_reference_test_cells(oracle, group):
+    """Replicas of reference tests/test_psgd.py:240-366 (fit on RandomState(1) data)."""
+    z = load_golden("g9_psgd.npz")
+    X = z["X"]
+    for cell in _g9_groups()[group]:
+        deg, bs, lr, fl, loss, regname = cell.split("|")
+        degree = int(deg[3:])
+        y = z["y|deg%d" % degree]
+        if loss != "squared":
+            y = np.sign(y)
+        fm = oracle.OracleFM(degree=degree, loss=loss, n_components=5, solver="psgd",
+                             regularizer=regname, alpha=1e-3, beta=1e-3, gamma=0.0, tol=1e-3,
+                             fit_lower=None, fit_linear=bool(int(fl)), max_iter=10,
+                             random_state=0, learning_rate=lr, eta0=0.01,
+                             batch_size=bs if bs == "auto" else int(bs))
+        fm.fit(X, y)
+        np.testing.assert_allclose(fm.P_, z["P|" + cell], rtol=0, atol=TOL, err_msg=cell)
+        np.testing.assert_allclose(fm.w_, z["w|" + cell], rtol=0, atol=TOL, err_msg=cell)
+        assert [fm.n_iter_, fm.it_] == [int(v) for v in z["n_iter|" + cell]], cell
+
+
+@pytest.mark.parametrize("regname", ["l1", "l21", "squaredl12", "squaredl21"])
+def test_g9_prox_operators(oracle, regname):
+    """regularizer.prox (l1.py:50, l21.py:43-48, squaredl12.py:66-75, squaredl21.py:63-74)
+    at the strengths of the reference's tests/test_prox.py:54,69 (+ 0)."""
+    z = load_golden("g9_psgd.npz")
+    for si, st in enumerate(z["prox_strengths"]):
+        P = np.array(z["prox_in"])
+        oracle.reg_prox(regname, P, float(st))
+        want = z["prox|%s|%d" % (regname, si)]
+        np.testing.assert_allclose(P, want, rtol=1e-13, atol=1e-13, err_msg=str(st))
+        assert np.array_equal(P == 0, want == 0), st  # identical support
+
+
+def _g9_tcases():
+    return [str(c) for c in load_golden("g9_psgd.npz")["tcases"]]
+
+
+@pytest.mark.parametrize("case", _g9_tcases())
+def test_g9_psgd_sparse_trajectories(oracle, case):
+    z = load_golden("g9_psgd.npz")
+    m = json.loads(str(z["tmeta|" + case]))
+    import scipy.sparse as sp
+    X = sp.csr_matrix((z["X_data"], z["X_indices"], z["X_indptr"]), shape=tuple(z["X_shape"]))
+    ys = z["ys"]
+    y = ys if m["loss"] == "squared" else np.where(ys > np.median(ys), 1.0, -1.0)
+    fm = oracle.OracleFM(degree=m["degree"], loss=m["loss"], n_components=m["k"],
+                         solver="psgd", regularizer=m["regularizer"], alpha=m["alpha"],
+                         beta=m["beta"], gamma=m["gamma"], tol=-1.0, fit_lower=m["fit_lower"],
+                         fit_linear=True, max_iter=m["max_iter"], shuffle=m["shuffle"],
+                         random_state=m["random_state"], learning_rate=m["learning_rate"],
+                         eta0=m["eta0"], power_t=m["power_t"], batch_size=m["batch_size"],
+                         n_iter_no_change=1000)
+    fm.fit(X, y, P_init=z["tP0|" + case], lams_init=z["tlams|" + case])
+    np.testing.assert_allclose([h[0] for h in fm.history], z["tloss|" + case], rtol=1e-11)
+    np.testing.assert_allclose(fm.P_, z["tP|" + case], rtol=0, atol=TOL)
+    np.testing.assert_allclose(fm.w_, z["tw|" + case], rtol=0, atol=TOL)
+    assert [fm.n_iter_, fm.it_] == [int(v) for v in z["tit|" + case]]

@@ -56,6 +56,7 @@ typedef struct spfm_engine* spfm_handle;
 
 #define SPFM_SOLVER_PCD 0
 #define SPFM_SOLVER_PBCD 1
+#define SPFM_SOLVER_PSGD 2
 
 /* coordinate schedules (spfm_set_schedule) */
 #define SPFM_SCHED_EXACT 0   /* keep the given order; batch = maximal run of row-disjoint columns */
@@ -166,6 +167,22 @@ int spfm_pcd_epoch(spfm_handle h, int order_idx, int degree, double beta, double
 /* pbcd.pbcd_epoch (optimizer/pbcd.py:82-148) on P[order_idx] */
 int spfm_pbcd_epoch(spfm_handle h, int order_idx, int degree, double beta, double gamma,
                     double eta, double* viol);
+
+/* psgd.psgd_epoch (optimizer/psgd.py:125-199): one pass over indices_samples (a
+ * permutation of 0..n_samples-1; sparse_factorization_machines.py:98,124-125) in
+ * minibatches of batch_size rows (the last one may be shorter, psgd.py:177).  Updates
+ * every order of P (order o has degree `degree - o`, psgd.py:84-85,120-122) and w.
+ *   learning_rate  0 constant | 1 optimal | 2 pegasos | 3 invscaling (psgd.py:9-22,
+ *                  sparse_factorization_machines.py:17 LEARNING_RATE)
+ *   it             in/out: the reference's self.it_ (starts at 1; +1 per parameter update)
+ *   sum_loss       out: sum over samples of loss(y_pred_i, y_i) at visiting time
+ * Requires spfm_configure(h, SPFM_SOLVER_PSGD, loss, reg, degree) with reg in {l1, l21,
+ * squaredl12, squaredl21}; no schedule is needed.  The training-time y_pred vector
+ * (spfm_get_y_pred / spfm_loss_sum) is not maintained by this solver.  Single GPU. */
+int spfm_psgd_epoch(spfm_handle h, int degree, double alpha, double beta, double gamma,
+                    double eta0, int learning_rate, double power_t, int64_t batch_size,
+                    const int32_t* indices_samples, int64_t n_samples, int fit_linear,
+                    int64_t* it, double* sum_loss);
 
 /* -- multi-GPU (one process per GPU, RCCL over xGMI) ---------------------------
  * Rows are sharded; the column partial sums of every step are all-reduced

@@ -16,7 +16,8 @@ SPFM_OK, SPFM_ERR_INVALID, SPFM_ERR_RUNTIME, SPFM_ERR_UNSUPPORTED = 0, -1, -2, -
 DTYPES = {"f32": 0, "f64": 1}
 LOSSES = {"squared": 0, "squared_hinge": 1, "logistic": 2}
 REGULARIZERS = {"l1": 0, "l21": 1, "squaredl12": 2, "squaredl21": 3, "omegati": 4, "omegacs": 5}
-SOLVERS = {"pcd": 0, "pbcd": 1}
+SOLVERS = {"pcd": 0, "pbcd": 1, "psgd": 2}
+LEARNING_RATE = {"constant": 0, "optimal": 1, "pegasos": 2, "invscaling": 3}
 SCHEDULES = {"exact": 0, "colored": 1}
 
 # every symbol include/spfm.h declares (checked by tests/test_capi_symbols.py)
@@ -26,7 +27,7 @@ SYMBOLS = [
     "spfm_loss_sum", "spfm_predict_csr", "spfm_set_schedule", "spfm_set_schedule_raw",
     "spfm_get_schedule", "spfm_schedule_build",
     "spfm_cd_linear_epoch",
-    "spfm_pcd_epoch", "spfm_pbcd_epoch", "spfm_comm_unique_id", "spfm_comm_init",
+    "spfm_pcd_epoch", "spfm_pbcd_epoch", "spfm_psgd_epoch", "spfm_comm_unique_id", "spfm_comm_init",
     "spfm_profile_enable", "spfm_profile_get", "spfm_profile_reset", "spfm_set_use_graph",
     "spfm_set_option", "spfm_get_option", "spfm_debug_prb_stamps",
 ]
@@ -74,6 +75,9 @@ def load():
     L.spfm_pcd_epoch.argtypes = [_h, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _ip,
                                  C.c_int, _dp]
     L.spfm_pbcd_epoch.argtypes = [_h, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _dp]
+    L.spfm_psgd_epoch.argtypes = [_h, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                  C.c_int, C.c_double, C.c_int64, _ip, C.c_int64, C.c_int, _lp,
+                                  _dp]
     L.spfm_comm_unique_id.argtypes = [C.c_char_p]
     L.spfm_comm_init.argtypes = [_h, C.c_char_p, C.c_int, C.c_int]
     L.spfm_profile_enable.argtypes = [_h, C.c_int]

@@ -168,6 +168,10 @@ struct spfm_engine {
     DevBuf part, delta, pold, viol_col, scalar, ctl, comp_order, pred_tmp, partial, pb_scal;
     double* h_scalar = nullptr;  // pinned
 
+    // psgd (minibatch solver): gradient accumulators, sample order, Michelot state
+    DevBuf sg_gradP, sg_gradw, sg_samples, sg_part, sg_cond, sg_thr, sg_theta, sg_done,
+        sg_norms;
+
     // graphs
     bool use_graph = true;
     bool fuse_chain = true;  // fused chain+sync kernel for batches of <= 64 columns
@@ -486,8 +490,9 @@ struct spfm_engine {
             FAIL(SPFM_ERR_INVALID, "configure: set data and parameters first");
         if (loss_ < 0 || loss_ > 2) FAIL(SPFM_ERR_INVALID, "Loss function not supported.");
         if (reg_ < 0 || reg_ > 5) FAIL(SPFM_ERR_INVALID, "Regularizer not supported.");
-        if (solver_ != SPFM_SOLVER_PCD && solver_ != SPFM_SOLVER_PBCD)
+        if (solver_ != SPFM_SOLVER_PCD && solver_ != SPFM_SOLVER_PBCD && solver_ != SPFM_SOLVER_PSGD)
             FAIL(SPFM_ERR_INVALID, "Solver is not supported.");
+        if (solver_ == SPFM_SOLVER_PSGD) return configure_psgd(loss_, reg_, top_degree_);
         const bool all_subsets = top_degree_ == -1;  // regularizers are called with degree = -1
         if (!all_subsets && top_degree_ < 2)
             FAIL(SPFM_ERR_UNSUPPORTED, "degree must be >= 2 (factorization machine) or -1 (all-subsets)");
@@ -1274,6 +1279,187 @@ struct spfm_engine {
         if (rc) return rc;
         return epoch_epilogue(viol);
     }
+
+    // ================================================================== psgd
+    // regularizer.init_cache_psgd exists for l1 / l21 / squaredl12 / squaredl21 only
+    // (reference regularizer/*.py); psgd has no all-subsets variant.
+    int configure_psgd(int loss_, int reg_, int top_degree_) {
+        if (reg_ != SPFM_REG_L1 && reg_ != SPFM_REG_L21 && reg_ != SPFM_REG_SQUAREDL12 &&
+            reg_ != SPFM_REG_SQUAREDL21)
+            FAIL(SPFM_ERR_INVALID, "this regularizer cannot be used with solver='psgd'");
+        if (top_degree_ < 2 || top_degree_ > SPFM_MAX_DEGREE)
+            FAIL(SPFM_ERR_UNSUPPORTED, "psgd: degree must be in 2..6");
+        if (top_degree_ - (n_orders - 1) < 1)
+            FAIL(SPFM_ERR_INVALID, "psgd: more parameter orders than degrees");
+        if (k > 64 * kPsgdMaxC) FAIL(SPFM_ERR_UNSUPPORTED, "psgd: n_components > 256 not supported");
+        solver = SPFM_SOLVER_PSGD;
+        loss = loss_;
+        reg = reg_;
+        top_degree = top_degree_;
+        clear_graphs();
+        const size_t np = (size_t)n_orders * k * d;
+        const size_t V = (size_t)n_orders * k;
+        HIPC(sg_gradP.alloc(sizeof(double) * np));
+        HIPC(sg_gradw.alloc(sizeof(double) * (size_t)d));
+        HIPC(sg_samples.alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1)));
+        HIPC(sg_part.alloc(sizeof(double) * 2 * V * kPsgdNB));
+        HIPC(sg_cond.alloc(sizeof(double) * V));
+        HIPC(sg_thr.alloc(sizeof(double) * V));
+        HIPC(sg_theta.alloc(sizeof(double) * V));
+        HIPC(sg_done.alloc(sizeof(int) * 4));
+        HIPC(sg_norms.alloc(sizeof(double) * (size_t)n_orders * d));
+        HIPC(hipMemsetAsync(sg_gradP.p, 0, sizeof(double) * np, stream));
+        HIPC(hipMemsetAsync(sg_gradw.p, 0, sizeof(double) * (size_t)d, stream));
+        HIPC(hipMemsetAsync(sg_done.p, 0, sizeof(int) * 4, stream));
+        HIPC(scalar.alloc(sizeof(double) * 8));
+        if (!h_scalar) HIPC(hipHostMalloc((void**)&h_scalar, sizeof(double) * 8));
+        HIPC(hipStreamSynchronize(stream));
+        configured = true;
+        return SPFM_OK;
+    }
+
+    // psgd.py:9-22
+    static void psgd_eta(int lr, double eta0, double alpha, double beta, double power_t,
+                         int64_t it, double* eta_P, double* eta_w) {
+        if (lr == 0) {
+            *eta_P = eta0;
+            *eta_w = eta0;
+        } else if (lr == 1) {
+            const double eta_it = eta0 * (double)it;
+            *eta_P = eta0 / std::pow(1.0 + eta_it * beta, power_t);
+            *eta_w = eta0 / std::pow(1.0 + eta_it * alpha, power_t);
+        } else if (lr == 2) {
+            *eta_P = 1.0 / (beta * (double)it);
+            *eta_w = 1.0 / (alpha * (double)it);
+        } else {
+            const double eta = eta0 / std::pow((double)it, power_t);
+            *eta_P = eta;
+            *eta_w = eta;
+        }
+    }
+
+    template <typename T, int L>
+    int psgd_epoch_tl(int degree, double alpha, double beta, double gamma, double eta0, int lr,
+                      double power_t, int64_t batch_size, int fit_linear, int64_t* it) {
+        const int V = (reg == SPFM_REG_SQUAREDL12) ? n_orders * k : n_orders;
+        const bool mich = (reg == SPFM_REG_SQUAREDL12 || reg == SPFM_REG_SQUAREDL21);
+        constexpr int gpb = kBlock / L;
+        const int nb_dense = (int)std::min<int64_t>(kPsgdNB, cdiv(d, gpb));
+        int* h_done = reinterpret_cast<int*>(h_scalar + 4);
+        for (int64_t pos = 0; pos < n; pos += batch_size) {
+            const int B = (int)std::min<int64_t>(batch_size, n - pos);
+            prof_begin(0, 0);
+            hipLaunchKernelGGL((psgd_grad_kernel<T, L>), dim3(cdiv(B, gpb)), dim3(kBlock), 0, stream,
+                               sg_samples.as<int32_t>() + pos, B, rptr.as<int64_t>(),
+                               ridx.as<int32_t>(), rval.as<T>(), yy.as<T>(), Pt.as<double>(),
+                               w.as<double>(), lams.as<double>(), n_orders, k, d, degree, loss,
+                               fit_linear, sg_gradP.as<double>(), sg_gradw.as<double>(),
+                               pred_tmp.as<double>() + pos);
+            prof_end(0);
+            double eta_P, eta_w;
+            psgd_eta(lr, eta0, alpha, beta, power_t, *it, &eta_P, &eta_w);
+            const double strength = gamma * eta_P / (1 + eta_P * beta);
+            prof_begin(1, 0);
+            hipLaunchKernelGGL((psgd_update_kernel<L>), dim3(nb_dense), dim3(kBlock), 0, stream,
+                               Pt.as<double>(), sg_gradP.as<double>(), w.as<double>(),
+                               sg_gradw.as<double>(), n_orders, k, d, reg, eta_P / (double)B,
+                               1.0 + eta_P * beta, strength, fit_linear, eta_w / (double)B,
+                               1 + eta_w * alpha, sg_norms.as<double>(), sg_part.as<double>(), V,
+                               sg_theta.as<double>(), sg_done.as<int>());
+            prof_end(1);
+            if (mich) {
+                prof_begin(2, 0);
+                hipLaunchKernelGGL(psgd_mich_finish_kernel, dim3(1), dim3(kBlock), 0, stream,
+                                   sg_part.as<double>(), nb_dense, V, strength,
+                                   sg_cond.as<double>(), sg_thr.as<double>(),
+                                   sg_theta.as<double>(), sg_done.as<int>());
+                // the support shrinks monotonically, so this terminates (<= d sweeps; a
+                // handful in practice); the fixed point is checked on the host per chunk
+                for (int guard = 0;; ++guard) {
+                    for (int sweep = 0; sweep < 6; ++sweep) {
+                        hipLaunchKernelGGL((psgd_mich_reduce_kernel<L>), dim3(nb_dense),
+                                           dim3(kBlock), 0, stream, Pt.as<double>(),
+                                           sg_norms.as<double>(), n_orders, k, d, reg,
+                                           sg_cond.as<double>(), sg_part.as<double>(), V,
+                                           sg_done.as<int>());
+                        hipLaunchKernelGGL(psgd_mich_finish_kernel, dim3(1), dim3(kBlock), 0,
+                                           stream, sg_part.as<double>(), nb_dense, V, strength,
+                                           sg_cond.as<double>(), sg_thr.as<double>(),
+                                           sg_theta.as<double>(), sg_done.as<int>());
+                    }
+                    HIPC(hipMemcpyAsync(h_done, sg_done.p, sizeof(int), hipMemcpyDeviceToHost,
+                                        stream));
+                    HIPC(hipStreamSynchronize(stream));
+                    if (*h_done) break;
+                    if (guard > d) FAIL(SPFM_ERR_RUNTIME, "psgd: prox support search did not settle");
+                }
+                hipLaunchKernelGGL((psgd_mich_apply_kernel<L>), dim3(nb_dense), dim3(kBlock), 0,
+                                   stream, Pt.as<double>(), sg_norms.as<double>(), n_orders, k, d,
+                                   reg, sg_thr.as<double>());
+                prof_end(2);
+            }
+            *it += 1;
+        }
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+
+    // optimizer/psgd.py:125-199: one pass over indices_samples
+    int psgd_epoch(int degree, double alpha, double beta, double gamma, double eta0, int lr,
+                   double power_t, int64_t batch_size, const int32_t* indices_samples,
+                   int64_t n_samples, int fit_linear, int64_t* it, double* sum_loss) {
+        if (!have_data || !have_params || !configured)
+            FAIL(SPFM_ERR_INVALID, "epoch: data, parameters and configuration are required");
+        if (solver != SPFM_SOLVER_PSGD) FAIL(SPFM_ERR_INVALID, "engine is not configured for psgd");
+        if (comm) FAIL(SPFM_ERR_UNSUPPORTED, "psgd: multi-GPU is not supported");
+        if (degree != top_degree) FAIL(SPFM_ERR_INVALID, "psgd: degree differs from configure()");
+        if (!indices_samples || !it || n_samples != n)
+            FAIL(SPFM_ERR_INVALID, "psgd: indices_samples must list every sample once");
+        if (batch_size < 1) FAIL(SPFM_ERR_INVALID, "psgd: batch_size must be >= 1");
+        if (lr < 0 || lr > 3) FAIL(SPFM_ERR_INVALID, "psgd: learning_rate is not supported.");
+        if (*it < 1) FAIL(SPFM_ERR_INVALID, "psgd: it must be >= 1");
+        {
+            std::vector<char> seen((size_t)n, 0);
+            for (int64_t q = 0; q < n; ++q) {
+                const int i = indices_samples[q];
+                if (i < 0 || i >= n || seen[(size_t)i])
+                    FAIL(SPFM_ERR_INVALID, "psgd: indices_samples is not a permutation");
+                seen[(size_t)i] = 1;
+            }
+        }
+        if (n == 0) {
+            if (sum_loss) *sum_loss = 0.0;
+            return SPFM_OK;
+        }
+        int rc = ensure_pt();
+        if (rc) return rc;
+        p_valid = false;
+        HIPC(hipMemcpyAsync(sg_samples.p, indices_samples, sizeof(int32_t) * (size_t)n,
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipStreamSynchronize(stream));  // caller may reuse indices_samples
+#define SPFM_PSGD_GO(T, L)                                                                    \
+    rc = psgd_epoch_tl<T, L>(degree, alpha, beta, gamma, eta0, lr, power_t, batch_size,        \
+                             fit_linear, it)
+        if (dtype == SPFM_F32) {
+            if (k <= 16) SPFM_PSGD_GO(float, 16);
+            else if (k <= 32) SPFM_PSGD_GO(float, 32);
+            else SPFM_PSGD_GO(float, 64);
+        } else {
+            if (k <= 16) SPFM_PSGD_GO(double, 16);
+            else if (k <= 32) SPFM_PSGD_GO(double, 32);
+            else SPFM_PSGD_GO(double, 64);
+        }
+#undef SPFM_PSGD_GO
+        if (rc) return rc;
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(kBlock), 0, stream,
+                           pred_tmp.as<double>(), (int)n, scalar.as<double>());
+        HIPC(hipGetLastError());
+        HIPC(hipMemcpyAsync(h_scalar, scalar.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPC(hipStreamSynchronize(stream));
+        prof_collect();
+        if (sum_loss) *sum_loss = h_scalar[0];
+        return SPFM_OK;
+    }
 };
 
 // ======================================================================= C ABI
@@ -1468,6 +1654,15 @@ int spfm_pbcd_epoch(spfm_handle h, int order_idx, int degree, double beta, doubl
                     double eta, double* viol) {
     GUARD(h);
     return h->pbcd_epoch(order_idx, degree, beta, gamma, eta, viol);
+}
+
+int spfm_psgd_epoch(spfm_handle h, int degree, double alpha, double beta, double gamma,
+                    double eta0, int learning_rate, double power_t, int64_t batch_size,
+                    const int32_t* indices_samples, int64_t n_samples, int fit_linear,
+                    int64_t* it, double* sum_loss) {
+    GUARD(h);
+    return h->psgd_epoch(degree, alpha, beta, gamma, eta0, learning_rate, power_t, batch_size,
+                         indices_samples, n_samples, fit_linear, it, sum_loss);
 }
 
 int spfm_comm_unique_id(char* id128) {

@@ -10,6 +10,9 @@
 //     kernel; kernel boundaries on one stream are the only inter-workgroup
 //     synchronisation and the launch sequence is replayed from a hipGraph.
 //
+// The minibatch solver (psgd, spfm_psgd.hip.h) is throughput-bound instead: rows of a
+// batch in parallel, then dense HBM passes over P for the step and the prox.
+//
 // Storage type T (float|double): X values, A caches, (yhat,y).  Everything that
 // is reduced or fed to the prox is float64.
 #pragma once
@@ -19,3 +22,4 @@
 #include "spfm_linear.hip.h"
 #include "spfm_pbcd.hip.h"
 #include "spfm_predict.hip.h"
+#include "spfm_psgd.hip.h"

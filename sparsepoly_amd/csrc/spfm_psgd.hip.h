@@ -1,0 +1,361 @@
+// spfm_psgd.hip.h -- minibatch proximal SGD (reference optimizer/psgd.py:125-199)
+// Part of the gfx950 device code of the sparse-FM solvers; see spfm_kernels.hip.h.
+//
+// Unlike pcd/pbcd this solver is throughput-bound: one minibatch is
+//   psgd_grad_kernel    rows of the batch in parallel (one L-lane group per row, lane =
+//                       component): ANOVA DP, prediction, dloss, gradient scatter with
+//                       hardware f64 atomics into grad_P (n_orders, d, k) / grad_w (d)
+//   psgd_update_kernel  one dense HBM pass over P: SGD step, shrink, grad reset and -- for
+//                       l1 / l21 -- the prox, fused (psgd.py:94-122)
+// and, for squaredl12 / squaredl21, whose prox needs the support of a whole vector
+// (regularizer/utils.py:27-70), a few psgd_mich_* passes: the reference's randomised
+// pivot search is replaced by the monotone fixed-point iteration
+//   G <- {i : |p_i| >= tau(G)},  tau(G) = 2 c S_G / (1 + 2 c |G|)
+// started from G = everything.  tau only grows, G only shrinks, and the fixed point is
+// the same support the reference finds; each sweep is one coalesced read of P.
+#pragma once
+#include "spfm_common.hip.h"
+
+namespace spfm {
+
+constexpr int kPsgdNB = 256;   // workgroups of the dense passes (partials per vector)
+constexpr int kPsgdMaxC = 4;   // component chunks per lane (k <= 4 * 64)
+
+// _anova (psgd.py:34-44) for one lane's component; a[0..deg]
+template <typename T>
+__device__ __forceinline__ void psgd_anova(double* a, int deg, int64_t lo, int64_t hi,
+                                           const int32_t* __restrict__ ridx,
+                                           const T* __restrict__ rval,
+                                           const double* __restrict__ Pcol /* Pt + o*d*k + s */,
+                                           int k, bool act) {
+    a[0] = 1.0;
+#pragma unroll
+    for (int t = 1; t <= kMaxDegree; ++t) a[t] = 0.0;
+    for (int64_t e = lo; e < hi; e += 4) {
+        double x[4], p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = e + u < hi;
+            const int j = in ? ridx[e + u] : 0;
+            x[u] = in ? (double)rval[e + u] : 0.0;
+            p[u] = (in && act) ? Pcol[(size_t)j * k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int t = kMaxDegree; t >= 1; --t)
+                if (t <= deg) a[t] += a[t - 1] * x[u] * p[u];
+        }
+    }
+}
+
+// One L-lane group per row of the minibatch.
+template <typename T, int L>
+__global__ __launch_bounds__(kBlock) void psgd_grad_kernel(
+    const int32_t* __restrict__ samples, int B, const int64_t* __restrict__ rptr,
+    const int32_t* __restrict__ ridx, const T* __restrict__ rval, const T* __restrict__ yy,
+    const double* __restrict__ Pt, const double* __restrict__ w,
+    const double* __restrict__ lams, int n_orders, int k, int d, int degree, int loss,
+    int fit_linear, double* __restrict__ grad_P, double* __restrict__ grad_w,
+    double* __restrict__ loss_row) {
+    constexpr int gpb = kBlock / L;
+    const int grp = threadIdx.x / L, ln = threadIdx.x % L;
+    const int r = blockIdx.x * gpb + grp;
+    if (r >= B) return;  // no block-level synchronisation below
+    const int i = samples[r];
+    const int64_t lo = rptr[i], hi = rptr[i + 1];
+    const int C = (k + L - 1) / L;
+    const bool keep = (n_orders == 1 && C == 1);
+    double a[kMaxDegree + 1];
+    // _pred (psgd.py:47-57)
+    double yp = 0.0;
+    for (int64_t e = lo + ln; e < hi; e += L) yp += (double)rval[e] * w[ridx[e]];
+    for (int o = 0; o < n_orders; ++o) {
+        const int deg = degree - o;
+        for (int c = 0; c < C; ++c) {
+            const int s = c * L + ln;
+            const bool act = s < k;
+            psgd_anova<T>(a, deg, lo, hi, ridx, rval, Pt + (size_t)o * d * k + (act ? s : 0), k,
+                          act);
+            double top = 0.0;
+#pragma unroll
+            for (int t = 2; t <= kMaxDegree; ++t)
+                if (t == deg) top = a[t];
+            if (deg == 1) top = a[1];
+            if (act) yp += lams[s] * top;
+        }
+    }
+    yp = group_sum(yp, L);
+    const double yi = (double)yy[2 * (size_t)i + 1];
+    const double dL = dloss_dev(loss, yp, yi);
+    if (ln == 0) loss_row[r] = loss_dev(loss, yp, yi);
+    // _update_grads (psgd.py:60-91)
+    if (fit_linear)
+        for (int64_t e = lo + ln; e < hi; e += L)
+            unsafeAtomicAdd(&grad_w[ridx[e]], dL * (double)rval[e]);
+    for (int o = 0; o < n_orders; ++o) {
+        const int deg = degree - o;
+        for (int c = 0; c < C; ++c) {
+            const int s = c * L + ln;
+            const bool act = s < k;
+            const double* Pcol = Pt + (size_t)o * d * k + (act ? s : 0);
+            if (!keep) psgd_anova<T>(a, deg, lo, hi, ridx, rval, Pcol, k, act);
+            if (!act) continue;
+            const double dl = dL * lams[s];
+            double* Gcol = grad_P + (size_t)o * d * k + s;
+            for (int64_t e = lo; e < hi; e += 4) {
+                int j[4];
+                double x[4], p[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = e + u < hi;
+                    j[u] = in ? ridx[e + u] : -1;
+                    x[u] = in ? (double)rval[e + u] : 0.0;
+                    p[u] = in ? Pcol[(size_t)j[u] * k] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (j[u] < 0) continue;
+                    double dprev = x[u];  // _grad_anova (psgd.py:25-31)
+#pragma unroll
+                    for (int t = 1; t < kMaxDegree; ++t)
+                        if (t < deg) dprev = x[u] * (a[t] - p[u] * dprev);
+                    unsafeAtomicAdd(&Gcol[(size_t)j[u] * k], dl * dprev);
+                }
+            }
+        }
+    }
+}
+
+// soft_thresholding (regularizer/utils.py:8-9)
+__device__ __forceinline__ double soft_thr(double v, double y) {
+    const double m = fabs(v) - y;
+    const double sg = (double)((v > 0) - (v < 0));
+    return sg * (m > 0.0 ? m : 0.0);
+}
+
+// _update_params (psgd.py:94-122): SGD step + shrink + grad reset on every row of
+// P (n_orders, d, k), fused with the prox for l1 / l21.  For squaredl12 / squaredl21 the
+// pass also emits the first Michelot partials part[block][v] = (sum |.|, count) with
+// v = o*k + s (squaredl12) or v = o (squaredl21, over the row norms it stores).
+template <int L>
+__global__ __launch_bounds__(kBlock) void psgd_update_kernel(
+    double* __restrict__ Pt, double* __restrict__ grad_P, double* __restrict__ w,
+    double* __restrict__ grad_w, int n_orders, int k, int d, int reg, double cp, double denp,
+    double strength, int fit_linear, double cw, double denw, double* __restrict__ norms,
+    double* __restrict__ part, int V, double* __restrict__ theta_prev,
+    int* __restrict__ done) {
+    constexpr int gpb = kBlock / L;
+    __shared__ double red[2][kBlock];
+    const int grp = threadIdx.x / L, ln = threadIdx.x % L;
+    const int C = (k + L - 1) / L;
+    if (fit_linear) {
+        for (int j = blockIdx.x * kBlock + threadIdx.x; j < d; j += gridDim.x * kBlock) {
+            const double g = grad_w[j] * cw;
+            w[j] = (w[j] - g) / denw;
+            grad_w[j] = 0.0;
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (int v = threadIdx.x; v < V; v += kBlock) theta_prev[v] = -1.0;
+        if (threadIdx.x == 0) *done = 0;
+    }
+    for (int o = 0; o < n_orders; ++o) {
+        double acc[kPsgdMaxC] = {0, 0, 0, 0};
+        double cnt = 0.0;
+        for (int j = blockIdx.x * gpb + grp; j < d; j += gridDim.x * gpb) {
+            const size_t base = ((size_t)o * d + j) * k;
+            double p[kPsgdMaxC];
+            double q = 0.0;
+#pragma unroll
+            for (int c = 0; c < kPsgdMaxC; ++c) {
+                const int s = c * L + ln;
+                p[c] = 0.0;
+                if (c < C && s < k) {
+                    const double g = grad_P[base + s] * cp;
+                    grad_P[base + s] = 0.0;
+                    p[c] = (Pt[base + s] - g) / denp;
+                    q += fabs(p[c]) * fabs(p[c]);
+                }
+            }
+            if (reg == REG_L1) {
+#pragma unroll
+                for (int c = 0; c < kPsgdMaxC; ++c) p[c] = soft_thr(p[c], strength);
+            } else if (reg == REG_L21) {  // l21.py:43-48
+                double nr = sqrt(group_sum(q, L));
+                if (nr <= strength) nr = INFINITY;
+                const double f = 1.0 - strength / nr;
+#pragma unroll
+                for (int c = 0; c < kPsgdMaxC; ++c) p[c] *= f;
+            } else if (reg == REG_SQL12) {
+#pragma unroll
+                for (int c = 0; c < kPsgdMaxC; ++c) acc[c] += fabs(p[c]);
+                cnt += 1.0;
+            } else {  // REG_SQL21: squaredl21.py:66
+                const double nr = sqrt(group_sum(q, L));
+                if (ln == 0) norms[(size_t)o * d + j] = nr;
+                acc[0] += nr;
+                cnt += 1.0;
+            }
+#pragma unroll
+            for (int c = 0; c < kPsgdMaxC; ++c) {
+                const int s = c * L + ln;
+                if (c < C && s < k) Pt[base + s] = p[c];
+            }
+        }
+        if (reg == REG_SQL12) {
+            for (int c = 0; c < C; ++c) {
+                __syncthreads();
+                red[0][threadIdx.x] = acc[c];
+                red[1][threadIdx.x] = cnt;
+                __syncthreads();
+                const int s = c * L + ln;
+                if (grp == 0 && s < k) {
+                    double sa = 0, sc = 0;
+                    for (int g = 0; g < gpb; ++g) {
+                        sa += red[0][g * L + ln];
+                        sc += red[1][g * L + ln];
+                    }
+                    double* dst = part + ((size_t)blockIdx.x * V + (size_t)o * k + s) * 2;
+                    dst[0] = sa;
+                    dst[1] = sc;
+                }
+            }
+        } else if (reg == REG_SQL21) {
+            __syncthreads();
+            red[0][threadIdx.x] = acc[0];
+            red[1][threadIdx.x] = cnt;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double sa = 0, sc = 0;
+                for (int g = 0; g < gpb; ++g) {
+                    sa += red[0][g * L];
+                    sc += red[1][g * L];
+                }
+                double* dst = part + ((size_t)blockIdx.x * V + o) * 2;
+                dst[0] = sa;
+                dst[1] = sc;
+            }
+        }
+    }
+}
+
+// One workgroup: fold the partials of every vector in fixed order, derive the next
+// threshold, detect the fixed point (support size unchanged for every vector).
+//   cond  = 2 c S / (1 + 2 c theta)     (utils.py:54, the membership test)
+//   thr   = 2 c (S / (1 + 2 c theta))   (utils.py:69-70, the final soft threshold)
+__global__ __launch_bounds__(kBlock) void psgd_mich_finish_kernel(
+    const double* __restrict__ part, int NB, int V, double strength, double* __restrict__ cond,
+    double* __restrict__ thr, double* __restrict__ theta_prev, int* __restrict__ done) {
+    if (*done) return;
+    int all = 1;
+    for (int v = threadIdx.x; v < V; v += kBlock) {
+        double S = 0, th = 0;
+        for (int b = 0; b < NB; ++b) {
+            S += part[((size_t)b * V + v) * 2];
+            th += part[((size_t)b * V + v) * 2 + 1];
+        }
+        const double den = 1.0 + 2.0 * strength * th;
+        cond[v] = 2 * strength * S / den;
+        thr[v] = 2 * strength * (S / den);
+        if (th != theta_prev[v]) all = 0;
+        theta_prev[v] = th;
+    }
+    all = __syncthreads_and(all);
+    if (threadIdx.x == 0 && all) *done = 1;
+}
+
+// One Michelot sweep: partial (sum, count) of the entries with |.| >= cond[v].
+template <int L>
+__global__ __launch_bounds__(kBlock) void psgd_mich_reduce_kernel(
+    const double* __restrict__ Pt, const double* __restrict__ norms, int n_orders, int k, int d,
+    int reg, const double* __restrict__ cond, double* __restrict__ part, int V,
+    const int* __restrict__ done) {
+    if (*done) return;
+    constexpr int gpb = kBlock / L;
+    __shared__ double red[2][kBlock];
+    const int grp = threadIdx.x / L, ln = threadIdx.x % L;
+    const int C = (k + L - 1) / L;
+    for (int o = 0; o < n_orders; ++o) {
+        if (reg == REG_SQL12) {
+            for (int c = 0; c < C; ++c) {
+                const int s = c * L + ln;
+                const bool act = s < k;
+                const double cv = act ? cond[(size_t)o * k + s] : 0.0;
+                double sa = 0, sc = 0;
+                if (act)
+                    for (int j = blockIdx.x * gpb + grp; j < d; j += gridDim.x * gpb) {
+                        const double a = fabs(Pt[((size_t)o * d + j) * k + s]);
+                        if (a >= cv) {
+                            sa += a;
+                            sc += 1.0;
+                        }
+                    }
+                __syncthreads();
+                red[0][threadIdx.x] = sa;
+                red[1][threadIdx.x] = sc;
+                __syncthreads();
+                if (grp == 0 && act) {
+                    double ta = 0, tc = 0;
+                    for (int g = 0; g < gpb; ++g) {
+                        ta += red[0][g * L + ln];
+                        tc += red[1][g * L + ln];
+                    }
+                    double* dst = part + ((size_t)blockIdx.x * V + (size_t)o * k + s) * 2;
+                    dst[0] = ta;
+                    dst[1] = tc;
+                }
+            }
+        } else {
+            const double cv = cond[o];
+            double sa = 0, sc = 0;
+            for (int j = blockIdx.x * kBlock + threadIdx.x; j < d; j += gridDim.x * kBlock) {
+                const double a = norms[(size_t)o * d + j];
+                if (a >= cv) {
+                    sa += a;
+                    sc += 1.0;
+                }
+            }
+            __shared__ double r2[16];
+            block_sum2(sa, sc, r2);
+            if (threadIdx.x == 0) {
+                double* dst = part + ((size_t)blockIdx.x * V + o) * 2;
+                dst[0] = sa;
+                dst[1] = sc;
+            }
+        }
+    }
+}
+
+// Final soft threshold (squaredl12.py:73-75 / squaredl21.py:67-74).
+template <int L>
+__global__ __launch_bounds__(kBlock) void psgd_mich_apply_kernel(
+    double* __restrict__ Pt, const double* __restrict__ norms, int n_orders, int k, int d,
+    int reg, const double* __restrict__ thr) {
+    constexpr int gpb = kBlock / L;
+    const int grp = threadIdx.x / L, ln = threadIdx.x % L;
+    const int C = (k + L - 1) / L;
+    for (int o = 0; o < n_orders; ++o)
+        for (int j = blockIdx.x * gpb + grp; j < d; j += gridDim.x * gpb) {
+            const size_t base = ((size_t)o * d + j) * k;
+            double nr = 0, nn = 0;
+            if (reg == REG_SQL21) {
+                nr = norms[(size_t)o * d + j];
+                nn = soft_thr(nr, thr[o]);
+            }
+            for (int c = 0; c < C; ++c) {
+                const int s = c * L + ln;
+                if (s >= k) continue;
+                double p = Pt[base + s];
+                if (reg == REG_SQL12) {
+                    p = soft_thr(p, thr[(size_t)o * k + s]);
+                } else {
+                    if (nr > 0) p /= nr;
+                    p *= nn;
+                }
+                Pt[base + s] = p;
+            }
+        }
+}
+
+}  // namespace spfm

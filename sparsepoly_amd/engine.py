@@ -229,6 +229,20 @@ class HipEngine(object):
             C.byref(v)))
         return v.value
 
+    def psgd_epoch(self, degree, alpha, beta, gamma, eta0, learning_rate, power_t, batch_size,
+                   indices_samples, fit_linear, it):
+        """``psgd.psgd_epoch`` (optimizer/psgd.py:125-199).  Returns (sum_loss, it)."""
+        idx = np.ascontiguousarray(indices_samples, dtype=np.int32)
+        itc = C.c_int64(int(it))
+        sl = C.c_double()
+        lr = (_capi.LEARNING_RATE[learning_rate] if isinstance(learning_rate, str)
+              else int(learning_rate))
+        self._check(self._lib.spfm_psgd_epoch(
+            self._h, int(degree), float(alpha), float(beta), float(gamma), float(eta0), lr,
+            float(power_t), int(batch_size), idx.ctypes.data_as(_capi._ip), idx.size,
+            int(bool(fit_linear)), C.byref(itc), C.byref(sl)))
+        return sl.value, itc.value
+
     # ------------------------------------------------------------- multi-GPU
     @staticmethod
     def comm_unique_id():

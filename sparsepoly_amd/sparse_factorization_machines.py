@@ -2,11 +2,11 @@
 
 Drop-in for ``sparsepoly.SparseFactorizationMachine{Regressor,Classifier}``
 (reference ``sparsepoly/sparse_factorization_machines.py``) for
-``solver in {'pcd', 'pbcd'}``: same constructor keywords in the same order with
+``solver in {'pcd', 'pbcd', 'psgd'}``: same constructor keywords in the same order with
 the same defaults, same fitted attributes (``P_ (n_orders, k, d)``, ``w_``,
 ``lams_``, ``n_iter_`` = 0-based index of the last iteration), same warnings and
-error types.  The epoch loops below restate ``_fit_pcd`` (:175-258) and
-``_fit_pbcd`` (:260-353); each reference epoch-function call is one call through
+error types.  The epoch loops below restate ``_fit_pcd`` (:175-258),
+``_fit_pbcd`` (:260-353) and ``_fit_psgd`` (:94-173); each reference epoch-function call is one call through
 the C ABI (``include/spfm.h``) into hand-written HIP kernels.  There is no CPU
 path: without the HIP library or a GPU, ``fit``/``predict`` raise.
 
@@ -229,6 +229,52 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         self._sync_params(engine)
         return converged, it
 
+    def _fit_psgd(self, engine, n_samples, n_features, nnz, rng):
+        """Restates _fit_psgd, sparse_factorization_machines.py:94-173.  Like pbcd the
+        reference trains a transposed copy of P_ (:113) and writes it back after the loop
+        (:172), while w_ is updated in place: callbacks see the initial P_ and the live w_."""
+        from ._capi import LEARNING_RATE
+
+        indices_samples = np.arange(n_samples, dtype=np.int32)
+        converged = False
+        no_improvement_count = 0
+        best_loss = np.inf
+        if self.batch_size == "auto":
+            batch_size = int(n_samples * n_features / nnz)
+        else:
+            batch_size = self.batch_size
+        if self.learning_rate not in LEARNING_RATE:
+            msg = f"learning_rate {self.learning_rate} is not supported."
+            msg += f" Choose from {LEARNING_RATE}."
+            raise ValueError(msg)
+        epoch = 0
+        for epoch in range(self.max_iter):
+            if self.shuffle:
+                rng.shuffle(indices_samples)
+            sum_loss, self.it_ = engine.psgd_epoch(
+                self.degree, self.alpha, self.beta, self.gamma, self.eta0, self.learning_rate,
+                self.power_t, batch_size, indices_samples, self.fit_linear, self.it_)
+            if (self.callback is not None) and epoch % self.n_calls == 0:
+                self._sync_params(engine, with_P=False)
+                if self.callback(self) is not None:
+                    break
+            sum_loss /= n_samples
+            if self.verbose:
+                print(f"Epoch {epoch+1} loss {sum_loss}")
+            if sum_loss > (best_loss - self.tol):
+                no_improvement_count += 1
+            else:
+                no_improvement_count = 0
+            if sum_loss < best_loss:
+                best_loss = sum_loss
+            if no_improvement_count >= self.n_iter_no_change:
+                if self.verbose:
+                    print(f"Converged at iteration {epoch+1}")
+                converged = True
+                break
+        self._sync_params(engine)
+        return converged, epoch
+
     # ---------------------------------------------------------------------- fit
     def fit(self, X, y):
         """Fit factorization machine to training data
@@ -270,14 +316,14 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         if np.unique(np.abs(self.lams_)) != np.array([1.0]):
             raise ValueError("Lambdas must be +1 or -1.")
 
-        if self.solver not in ("pcd", "pbcd"):
-            if self.solver == "psgd":
-                raise NotImplementedError(
-                    "solver='psgd' is outside the MI355X hot path (pcd / pbcd); "
-                    "see DESIGN.md, out of scope."
-                )
+        if self.solver not in ("pcd", "pbcd", "psgd"):
             msg = f"Solver {self.solver} is not supported."
             raise ValueError(msg)
+        if self.solver == "psgd":
+            if self.distributed:
+                raise ValueError("solver='psgd' runs on one GPU (distributed=False).")
+            if not (self.warm_start and hasattr(self, "it_")):
+                self.it_ = 1  # :411-412
         if not isinstance(self.schedule, Schedule) and self.schedule not in ("exact", "colored"):
             raise ValueError("schedule must be 'exact', 'colored' or a Schedule object.")
         if isinstance(self.schedule, Schedule) and self.shuffle:
@@ -302,6 +348,12 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
             engine.set_params(self.P_, self.w_, self.lams_)
             # regularizer.init_cache_pcd / init_cache_pbcd (:194, :282), incl. their errors
             engine.configure(self.solver, self.loss, self.regularizer, self.degree)
+            if self.solver == "psgd":
+                # X.count_nonzero() (dataset.py:32,84): stored entries, n*d when dense
+                nnz = X.nnz if sp.issparse(X) else n_samples * n_features
+                converged, self.n_iter_ = self._fit_psgd(engine, n_samples, n_features,
+                                                         nnz, rng)
+                return self._finish_fit(converged)
             # y_pred = self._get_output(X) (:408)
             engine.init_pred(self.degree, self.fit_linear, self._add_lower_deg2())
             if self.solver == "pcd":
@@ -315,7 +367,9 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 self.schedule_ = engine.get_schedule(self.schedule)
         finally:
             engine.close()
+        return self._finish_fit(converged)
 
+    def _finish_fit(self, converged):
         if not converged:
             warnings.warn("Objective did not converge. Increase max_iter.")
         return self

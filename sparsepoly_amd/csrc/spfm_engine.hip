@@ -170,7 +170,7 @@ struct spfm_engine {
 
     // psgd (minibatch solver): gradient accumulators, sample order, Michelot state
     DevBuf sg_gradP, sg_gradw, sg_samples, sg_part, sg_cond, sg_thr, sg_theta, sg_done,
-        sg_norms;
+        sg_norms, sg_conv;
 
     // graphs
     bool use_graph = true;
@@ -1307,7 +1307,9 @@ struct spfm_engine {
         HIPC(sg_thr.alloc(sizeof(double) * V));
         HIPC(sg_theta.alloc(sizeof(double) * V));
         HIPC(sg_done.alloc(sizeof(int) * 4));
+        HIPC(sg_conv.alloc(sizeof(int) * V));
         HIPC(sg_norms.alloc(sizeof(double) * (size_t)n_orders * d));
+        HIPC(hipMemsetAsync(sg_cond.p, 0, sizeof(double) * V, stream));  // first prox: G = all
         HIPC(hipMemsetAsync(sg_gradP.p, 0, sizeof(double) * np, stream));
         HIPC(hipMemsetAsync(sg_gradw.p, 0, sizeof(double) * (size_t)d, stream));
         HIPC(hipMemsetAsync(sg_done.p, 0, sizeof(int) * 4, stream));
@@ -1341,10 +1343,19 @@ struct spfm_engine {
     template <typename T, int L>
     int psgd_epoch_tl(int degree, double alpha, double beta, double gamma, double eta0, int lr,
                       double power_t, int64_t batch_size, int fit_linear, int64_t* it) {
-        const int V = (reg == SPFM_REG_SQUAREDL12) ? n_orders * k : n_orders;
         const bool mich = (reg == SPFM_REG_SQUAREDL12 || reg == SPFM_REG_SQUAREDL21);
         constexpr int gpb = kBlock / L;
         const int nb_dense = (int)std::min<int64_t>(kPsgdNB, cdiv(d, gpb));
+        MichState ms;
+        ms.part = sg_part.as<double>();
+        ms.cond = sg_cond.as<double>();
+        ms.thr = sg_thr.as<double>();
+        ms.theta = sg_theta.as<double>();
+        ms.conv = sg_conv.as<int>();
+        ms.done = sg_done.as<int>();
+        ms.V = (reg == SPFM_REG_SQUAREDL12) ? n_orders * k : n_orders;
+        ms.NB = nb_dense;
+        const int nb_fin = cdiv(ms.V, kBlock / kWave);
         int* h_done = reinterpret_cast<int*>(h_scalar + 4);
         for (int64_t pos = 0; pos < n; pos += batch_size) {
             const int B = (int)std::min<int64_t>(batch_size, n - pos);
@@ -1364,29 +1375,24 @@ struct spfm_engine {
                                Pt.as<double>(), sg_gradP.as<double>(), w.as<double>(),
                                sg_gradw.as<double>(), n_orders, k, d, reg, eta_P / (double)B,
                                1.0 + eta_P * beta, strength, fit_linear, eta_w / (double)B,
-                               1 + eta_w * alpha, sg_norms.as<double>(), sg_part.as<double>(), V,
-                               sg_theta.as<double>(), sg_done.as<int>());
+                               1 + eta_w * alpha, sg_norms.as<double>(), ms);
             prof_end(1);
             if (mich) {
                 prof_begin(2, 0);
-                hipLaunchKernelGGL(psgd_mich_finish_kernel, dim3(1), dim3(kBlock), 0, stream,
-                                   sg_part.as<double>(), nb_dense, V, strength,
-                                   sg_cond.as<double>(), sg_thr.as<double>(),
-                                   sg_theta.as<double>(), sg_done.as<int>());
-                // the support shrinks monotonically, so this terminates (<= d sweeps; a
-                // handful in practice); the fixed point is checked on the host per chunk
+                hipLaunchKernelGGL(psgd_mich_finish_kernel, dim3(nb_fin), dim3(kBlock), 0, stream,
+                                   ms, strength);
+                // the iteration is monotone after the first sweep, so it terminates (<= d
+                // sweeps; 2-4 with the warm start); the host looks at the flag per chunk
                 for (int guard = 0;; ++guard) {
-                    for (int sweep = 0; sweep < 6; ++sweep) {
+                    for (int sweep = 0; sweep < 2; ++sweep) {
                         hipLaunchKernelGGL((psgd_mich_reduce_kernel<L>), dim3(nb_dense),
                                            dim3(kBlock), 0, stream, Pt.as<double>(),
-                                           sg_norms.as<double>(), n_orders, k, d, reg,
-                                           sg_cond.as<double>(), sg_part.as<double>(), V,
-                                           sg_done.as<int>());
-                        hipLaunchKernelGGL(psgd_mich_finish_kernel, dim3(1), dim3(kBlock), 0,
-                                           stream, sg_part.as<double>(), nb_dense, V, strength,
-                                           sg_cond.as<double>(), sg_thr.as<double>(),
-                                           sg_theta.as<double>(), sg_done.as<int>());
+                                           sg_norms.as<double>(), n_orders, k, d, reg, ms);
+                        hipLaunchKernelGGL(psgd_mich_finish_kernel, dim3(nb_fin), dim3(kBlock),
+                                           0, stream, ms, strength);
                     }
+                    hipLaunchKernelGGL(psgd_mich_check_kernel, dim3(1), dim3(kBlock), 0, stream,
+                                       ms);
                     HIPC(hipMemcpyAsync(h_done, sg_done.p, sizeof(int), hipMemcpyDeviceToHost,
                                         stream));
                     HIPC(hipStreamSynchronize(stream));

@@ -11,19 +11,22 @@
 // (regularizer/utils.py:27-70), a few psgd_mich_* passes: the reference's randomised
 // pivot search is replaced by the monotone fixed-point iteration
 //   G <- {i : |p_i| >= tau(G)},  tau(G) = 2 c S_G / (1 + 2 c |G|)
-// started from G = everything.  tau only grows, G only shrinks, and the fixed point is
-// the same support the reference finds; each sweep is one coalesced read of P.
+// which is monotone from any start and ends at the same support the reference finds; each
+// sweep is one coalesced read of P, and consecutive minibatches warm-start each other.
 #pragma once
 #include "spfm_common.hip.h"
 
 namespace spfm {
 
-constexpr int kPsgdNB = 256;   // workgroups of the dense passes (partials per vector)
+constexpr int kPsgdNB = 1024;  // workgroups of the dense passes (partials per vector)
 constexpr int kPsgdMaxC = 4;   // component chunks per lane (k <= 4 * 64)
+constexpr int kPsgdSB = 16;    // row entries whose P loads are in flight together
 
-// _anova (psgd.py:34-44) for one lane's component; a[0..deg]
-template <typename T>
-__device__ __forceinline__ void psgd_anova(double* a, int deg, int64_t lo, int64_t hi,
+// _anova (psgd.py:34-44) for one lane's component; a[0..deg].  The L lanes of the group
+// first load one tile of L (column, value) pairs, then broadcast them lane by lane so
+// that the kPsgdSB dependent P loads of a sub-batch are issued back to back.
+template <typename T, int L>
+__device__ __forceinline__ void psgd_anova(double* a, int deg, int64_t lo, int64_t hi, int ln,
                                            const int32_t* __restrict__ ridx,
                                            const T* __restrict__ rval,
                                            const double* __restrict__ Pcol /* Pt + o*d*k + s */,
@@ -31,20 +34,25 @@ __device__ __forceinline__ void psgd_anova(double* a, int deg, int64_t lo, int64
     a[0] = 1.0;
 #pragma unroll
     for (int t = 1; t <= kMaxDegree; ++t) a[t] = 0.0;
-    for (int64_t e = lo; e < hi; e += 4) {
-        double x[4], p[4];
+    for (int64_t tb = lo; tb < hi; tb += L) {
+        const bool in = tb + ln < hi;
+        const int jl = in ? ridx[tb + ln] : 0;
+        const double xl = in ? (double)rval[tb + ln] : 0.0;
+        const int cnt = (int)((hi - tb < L) ? (hi - tb) : L);
+        for (int u0 = 0; u0 < cnt; u0 += kPsgdSB) {
+            double x[kPsgdSB], p[kPsgdSB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool in = e + u < hi;
-            const int j = in ? ridx[e + u] : 0;
-            x[u] = in ? (double)rval[e + u] : 0.0;
-            p[u] = (in && act) ? Pcol[(size_t)j * k] : 0.0;
-        }
+            for (int u = 0; u < kPsgdSB; ++u) {
+                const int j = __shfl(jl, u0 + u, L);
+                x[u] = __shfl(xl, u0 + u, L);  // 0 beyond the row: the update is a no-op
+                p[u] = act ? Pcol[(size_t)j * k] : 0.0;
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kPsgdSB; ++u) {
 #pragma unroll
-            for (int t = kMaxDegree; t >= 1; --t)
-                if (t <= deg) a[t] += a[t - 1] * x[u] * p[u];
+                for (int t = kMaxDegree; t >= 1; --t)
+                    if (t <= deg) a[t] += a[t - 1] * x[u] * p[u];
+            }
         }
     }
 }
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void psgd_grad_kernel(
     constexpr int gpb = kBlock / L;
     const int grp = threadIdx.x / L, ln = threadIdx.x % L;
     const int r = blockIdx.x * gpb + grp;
-    if (r >= B) return;  // no block-level synchronisation below
+    if (r >= B) return;  // whole groups leave; no block-level synchronisation below
     const int i = samples[r];
     const int64_t lo = rptr[i], hi = rptr[i + 1];
     const int C = (k + L - 1) / L;
@@ -75,13 +83,12 @@ __global__ __launch_bounds__(kBlock) void psgd_grad_kernel(
         for (int c = 0; c < C; ++c) {
             const int s = c * L + ln;
             const bool act = s < k;
-            psgd_anova<T>(a, deg, lo, hi, ridx, rval, Pt + (size_t)o * d * k + (act ? s : 0), k,
-                          act);
-            double top = 0.0;
+            psgd_anova<T, L>(a, deg, lo, hi, ln, ridx, rval,
+                             Pt + (size_t)o * d * k + (act ? s : 0), k, act);
+            double top = a[1];
 #pragma unroll
             for (int t = 2; t <= kMaxDegree; ++t)
                 if (t == deg) top = a[t];
-            if (deg == 1) top = a[1];
             if (act) yp += lams[s] * top;
         }
     }
@@ -99,28 +106,32 @@ __global__ __launch_bounds__(kBlock) void psgd_grad_kernel(
             const int s = c * L + ln;
             const bool act = s < k;
             const double* Pcol = Pt + (size_t)o * d * k + (act ? s : 0);
-            if (!keep) psgd_anova<T>(a, deg, lo, hi, ridx, rval, Pcol, k, act);
-            if (!act) continue;
-            const double dl = dL * lams[s];
-            double* Gcol = grad_P + (size_t)o * d * k + s;
-            for (int64_t e = lo; e < hi; e += 4) {
-                int j[4];
-                double x[4], p[4];
+            if (!keep) psgd_anova<T, L>(a, deg, lo, hi, ln, ridx, rval, Pcol, k, act);
+            const double dl = act ? dL * lams[s] : 0.0;
+            double* Gcol = grad_P + (size_t)o * d * k + (act ? s : 0);
+            for (int64_t tb = lo; tb < hi; tb += L) {
+                const bool in = tb + ln < hi;
+                const int jl = in ? ridx[tb + ln] : 0;
+                const double xl = in ? (double)rval[tb + ln] : 0.0;
+                const int cnt = (int)((hi - tb < L) ? (hi - tb) : L);
+                for (int u0 = 0; u0 < cnt; u0 += kPsgdSB) {
+                    int j[kPsgdSB];
+                    double x[kPsgdSB], p[kPsgdSB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool in = e + u < hi;
-                    j[u] = in ? ridx[e + u] : -1;
-                    x[u] = in ? (double)rval[e + u] : 0.0;
-                    p[u] = in ? Pcol[(size_t)j[u] * k] : 0.0;
-                }
+                    for (int u = 0; u < kPsgdSB; ++u) {
+                        j[u] = __shfl(jl, u0 + u, L);
+                        x[u] = __shfl(xl, u0 + u, L);
+                        p[u] = act ? Pcol[(size_t)j[u] * k] : 0.0;
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (j[u] < 0) continue;
-                    double dprev = x[u];  // _grad_anova (psgd.py:25-31)
+                    for (int u = 0; u < kPsgdSB; ++u) {
+                        double dprev = x[u];  // _grad_anova (psgd.py:25-31)
 #pragma unroll
-                    for (int t = 1; t < kMaxDegree; ++t)
-                        if (t < deg) dprev = x[u] * (a[t] - p[u] * dprev);
-                    unsafeAtomicAdd(&Gcol[(size_t)j[u] * k], dl * dprev);
+                        for (int t = 1; t < kMaxDegree; ++t)
+                            if (t < deg) dprev = x[u] * (a[t] - p[u] * dprev);
+                        if (act && u0 + u < cnt)
+                            unsafeAtomicAdd(&Gcol[(size_t)j[u] * k], dl * dprev);
+                    }
                 }
             }
         }
@@ -134,17 +145,42 @@ __device__ __forceinline__ double soft_thr(double v, double y) {
     return sg * (m > 0.0 ? m : 0.0);
 }
 
+// Michelot state of one prox (all on the device):
+//   part   [V][NB][2]  per-workgroup partial (sum |.|, count) of the entries >= cond[v]
+//   cond   [V]         current membership threshold 2 c S / (1 + 2 c theta)  (utils.py:54)
+//   thr    [V]         final soft threshold 2 c (S / (1 + 2 c theta))        (utils.py:69-70)
+//   theta  [V]         support size of the previous sweep (-1 = none yet)
+//   conv   [V]         1 once the support of vector v stopped changing
+// cond persists from one minibatch to the next as a warm start: for ANY guess g the set
+// {|p| >= g} yields tau <= tau*, after which the iteration is monotone again.
+struct MichState {
+    double* part;
+    double* cond;
+    double* thr;
+    double* theta;
+    int* conv;
+    int* done;
+    int V;
+    int NB;
+};
+
+__device__ __forceinline__ bool mich_all_converged(const MichState& ms) {
+    int all = 1;
+    for (int v = threadIdx.x; v < ms.V; v += kBlock)
+        if (!ms.conv[v]) all = 0;
+    return __syncthreads_and(all) != 0;
+}
+
 // _update_params (psgd.py:94-122): SGD step + shrink + grad reset on every row of
 // P (n_orders, d, k), fused with the prox for l1 / l21.  For squaredl12 / squaredl21 the
-// pass also emits the first Michelot partials part[block][v] = (sum |.|, count) with
-// v = o*k + s (squaredl12) or v = o (squaredl21, over the row norms it stores).
+// pass also emits the first Michelot partials with v = o*k + s (squaredl12) or v = o
+// (squaredl21, over the row norms it stores), measured against the warm-start cond.
 template <int L>
 __global__ __launch_bounds__(kBlock) void psgd_update_kernel(
     double* __restrict__ Pt, double* __restrict__ grad_P, double* __restrict__ w,
     double* __restrict__ grad_w, int n_orders, int k, int d, int reg, double cp, double denp,
     double strength, int fit_linear, double cw, double denw, double* __restrict__ norms,
-    double* __restrict__ part, int V, double* __restrict__ theta_prev,
-    int* __restrict__ done) {
+    MichState ms) {
     constexpr int gpb = kBlock / L;
     __shared__ double red[2][kBlock];
     const int grp = threadIdx.x / L, ln = threadIdx.x % L;
@@ -156,13 +192,24 @@ __global__ __launch_bounds__(kBlock) void psgd_update_kernel(
             grad_w[j] = 0.0;
         }
     }
-    if (blockIdx.x == 0) {
-        for (int v = threadIdx.x; v < V; v += kBlock) theta_prev[v] = -1.0;
-        if (threadIdx.x == 0) *done = 0;
+    const bool mich = (reg == REG_SQL12 || reg == REG_SQL21);
+    if (mich && blockIdx.x == 0) {
+        for (int v = threadIdx.x; v < ms.V; v += kBlock) {
+            ms.theta[v] = -1.0;
+            ms.conv[v] = 0;
+        }
+        if (threadIdx.x == 0) *ms.done = 0;
     }
     for (int o = 0; o < n_orders; ++o) {
-        double acc[kPsgdMaxC] = {0, 0, 0, 0};
-        double cnt = 0.0;
+        double acc[kPsgdMaxC] = {0, 0, 0, 0}, cnt[kPsgdMaxC] = {0, 0, 0, 0};
+        double cv[kPsgdMaxC] = {0, 0, 0, 0};
+        if (reg == REG_SQL12) {
+#pragma unroll
+            for (int c = 0; c < kPsgdMaxC; ++c)
+                if (c < C && c * L + ln < k) cv[c] = ms.cond[(size_t)o * k + c * L + ln];
+        } else if (reg == REG_SQL21) {
+            cv[0] = ms.cond[o];
+        }
         for (int j = blockIdx.x * gpb + grp; j < d; j += gridDim.x * gpb) {
             const size_t base = ((size_t)o * d + j) * k;
             double p[kPsgdMaxC];
@@ -189,13 +236,20 @@ __global__ __launch_bounds__(kBlock) void psgd_update_kernel(
                 for (int c = 0; c < kPsgdMaxC; ++c) p[c] *= f;
             } else if (reg == REG_SQL12) {
 #pragma unroll
-                for (int c = 0; c < kPsgdMaxC; ++c) acc[c] += fabs(p[c]);
-                cnt += 1.0;
+                for (int c = 0; c < kPsgdMaxC; ++c) {
+                    const double a = fabs(p[c]);
+                    if (a >= cv[c]) {
+                        acc[c] += a;
+                        cnt[c] += 1.0;
+                    }
+                }
             } else {  // REG_SQL21: squaredl21.py:66
                 const double nr = sqrt(group_sum(q, L));
                 if (ln == 0) norms[(size_t)o * d + j] = nr;
-                acc[0] += nr;
-                cnt += 1.0;
+                if (nr >= cv[0]) {
+                    acc[0] += nr;
+                    cnt[0] += 1.0;
+                }
             }
 #pragma unroll
             for (int c = 0; c < kPsgdMaxC; ++c) {
@@ -207,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void psgd_update_kernel(
             for (int c = 0; c < C; ++c) {
                 __syncthreads();
                 red[0][threadIdx.x] = acc[c];
-                red[1][threadIdx.x] = cnt;
+                red[1][threadIdx.x] = cnt[c];
                 __syncthreads();
                 const int s = c * L + ln;
                 if (grp == 0 && s < k) {
@@ -216,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void psgd_update_kernel(
                         sa += red[0][g * L + ln];
                         sc += red[1][g * L + ln];
                     }
-                    double* dst = part + ((size_t)blockIdx.x * V + (size_t)o * k + s) * 2;
+                    double* dst = ms.part + (((size_t)o * k + s) * ms.NB + blockIdx.x) * 2;
                     dst[0] = sa;
                     dst[1] = sc;
                 }
@@ -224,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void psgd_update_kernel(
         } else if (reg == REG_SQL21) {
             __syncthreads();
             red[0][threadIdx.x] = acc[0];
-            red[1][threadIdx.x] = cnt;
+            red[1][threadIdx.x] = cnt[0];
             __syncthreads();
             if (threadIdx.x == 0) {
                 double sa = 0, sc = 0;
@@ -232,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void psgd_update_kernel(
                     sa += red[0][g * L];
                     sc += red[1][g * L];
                 }
-                double* dst = part + ((size_t)blockIdx.x * V + o) * 2;
+                double* dst = ms.part + ((size_t)o * ms.NB + blockIdx.x) * 2;
                 dst[0] = sa;
                 dst[1] = sc;
             }
@@ -240,38 +294,34 @@ __global__ __launch_bounds__(kBlock) void psgd_update_kernel(
     }
 }
 
-// One workgroup: fold the partials of every vector in fixed order, derive the next
-// threshold, detect the fixed point (support size unchanged for every vector).
-//   cond  = 2 c S / (1 + 2 c theta)     (utils.py:54, the membership test)
-//   thr   = 2 c (S / (1 + 2 c theta))   (utils.py:69-70, the final soft threshold)
-__global__ __launch_bounds__(kBlock) void psgd_mich_finish_kernel(
-    const double* __restrict__ part, int NB, int V, double strength, double* __restrict__ cond,
-    double* __restrict__ thr, double* __restrict__ theta_prev, int* __restrict__ done) {
-    if (*done) return;
-    int all = 1;
-    for (int v = threadIdx.x; v < V; v += kBlock) {
-        double S = 0, th = 0;
-        for (int b = 0; b < NB; ++b) {
-            S += part[((size_t)b * V + v) * 2];
-            th += part[((size_t)b * V + v) * 2 + 1];
-        }
-        const double den = 1.0 + 2.0 * strength * th;
-        cond[v] = 2 * strength * S / den;
-        thr[v] = 2 * strength * (S / den);
-        if (th != theta_prev[v]) all = 0;
-        theta_prev[v] = th;
+// One wave per vector: fold its NB partials in fixed order, derive the next thresholds,
+// mark the vector converged when its support size did not change.
+__global__ __launch_bounds__(kBlock) void psgd_mich_finish_kernel(MichState ms, double strength) {
+    const int v = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (v >= ms.V || ms.conv[v]) return;
+    double S = 0, th = 0;
+    for (int b = lane; b < ms.NB; b += kWave) {
+        S += ms.part[((size_t)v * ms.NB + b) * 2];
+        th += ms.part[((size_t)v * ms.NB + b) * 2 + 1];
     }
-    all = __syncthreads_and(all);
-    if (threadIdx.x == 0 && all) *done = 1;
+    S = wave_sum(S);
+    th = wave_sum(th);
+    if (lane == 0) {
+        const double den = 1.0 + 2.0 * strength * th;
+        ms.cond[v] = 2 * strength * S / den;
+        ms.thr[v] = 2 * strength * (S / den);
+        if (th == ms.theta[v]) ms.conv[v] = 1;
+        ms.theta[v] = th;
+    }
 }
 
 // One Michelot sweep: partial (sum, count) of the entries with |.| >= cond[v].
 template <int L>
 __global__ __launch_bounds__(kBlock) void psgd_mich_reduce_kernel(
     const double* __restrict__ Pt, const double* __restrict__ norms, int n_orders, int k, int d,
-    int reg, const double* __restrict__ cond, double* __restrict__ part, int V,
-    const int* __restrict__ done) {
-    if (*done) return;
+    int reg, MichState ms) {
+    if (mich_all_converged(ms)) return;
     constexpr int gpb = kBlock / L;
     __shared__ double red[2][kBlock];
     const int grp = threadIdx.x / L, ln = threadIdx.x % L;
@@ -280,8 +330,8 @@ __global__ __launch_bounds__(kBlock) void psgd_mich_reduce_kernel(
         if (reg == REG_SQL12) {
             for (int c = 0; c < C; ++c) {
                 const int s = c * L + ln;
-                const bool act = s < k;
-                const double cv = act ? cond[(size_t)o * k + s] : 0.0;
+                const bool act = s < k && !ms.conv[(size_t)o * k + s];
+                const double cv = act ? ms.cond[(size_t)o * k + s] : 0.0;
                 double sa = 0, sc = 0;
                 if (act)
                     for (int j = blockIdx.x * gpb + grp; j < d; j += gridDim.x * gpb) {
@@ -301,13 +351,14 @@ __global__ __launch_bounds__(kBlock) void psgd_mich_reduce_kernel(
                         ta += red[0][g * L + ln];
                         tc += red[1][g * L + ln];
                     }
-                    double* dst = part + ((size_t)blockIdx.x * V + (size_t)o * k + s) * 2;
+                    double* dst = ms.part + (((size_t)o * k + s) * ms.NB + blockIdx.x) * 2;
                     dst[0] = ta;
                     dst[1] = tc;
                 }
             }
         } else {
-            const double cv = cond[o];
+            if (ms.conv[o]) continue;
+            const double cv = ms.cond[o];
             double sa = 0, sc = 0;
             for (int j = blockIdx.x * kBlock + threadIdx.x; j < d; j += gridDim.x * kBlock) {
                 const double a = norms[(size_t)o * d + j];
@@ -319,12 +370,18 @@ __global__ __launch_bounds__(kBlock) void psgd_mich_reduce_kernel(
             __shared__ double r2[16];
             block_sum2(sa, sc, r2);
             if (threadIdx.x == 0) {
-                double* dst = part + ((size_t)blockIdx.x * V + o) * 2;
+                double* dst = ms.part + ((size_t)o * ms.NB + blockIdx.x) * 2;
                 dst[0] = sa;
                 dst[1] = sc;
             }
         }
     }
+}
+
+// done <- every vector converged (read by the host between chunks of sweeps)
+__global__ __launch_bounds__(kBlock) void psgd_mich_check_kernel(MichState ms) {
+    const bool all = mich_all_converged(ms);
+    if (threadIdx.x == 0) *ms.done = all ? 1 : 0;
 }
 
 // Final soft threshold (squaredl12.py:73-75 / squaredl21.py:67-74).

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspfm_hip.so")
+LIB_PATH = os.environ.get("SPFM_HIP_LIB") or os.path.join(_HERE, "lib", "libspfm_hip.so")
 
 SPFM_OK, SPFM_ERR_INVALID, SPFM_ERR_RUNTIME, SPFM_ERR_UNSUPPORTED = 0, -1, -2, -3
 DTYPES = {"f32": 0, "f64": 1}

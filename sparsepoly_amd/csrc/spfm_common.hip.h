@@ -162,5 +162,18 @@ __global__ __launch_bounds__(kBlock) void reduce_sum_kernel(const double* __rest
     if (threadIdx.x == 0) out[0] = a;
 }
 
+// first stage of a long deterministic sum: out[block] = sum of the block's contiguous
+// slice of v (fixed slicing and fixed order inside => reproducible)
+__global__ __launch_bounds__(kBlock) void reduce_partial_kernel(const double* __restrict__ v,
+                                                                 int64_t n,
+                                                                 double* __restrict__ out) {
+    __shared__ double red[16];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = per * blockIdx.x, hi = (lo + per < n) ? lo + per : n;
+    double a = 0, b = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) a += v[i];
+    block_sum2(a, b, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
 
 }  // namespace spfm

@@ -1457,8 +1457,10 @@ struct spfm_engine {
         }
 #undef SPFM_PSGD_GO
         if (rc) return rc;
+        hipLaunchKernelGGL(reduce_partial_kernel, dim3(256), dim3(kBlock), 0, stream,
+                           pred_tmp.as<double>(), n, partial.as<double>());
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(kBlock), 0, stream,
-                           pred_tmp.as<double>(), (int)n, scalar.as<double>());
+                           partial.as<double>(), 256, scalar.as<double>());
         HIPC(hipGetLastError());
         HIPC(hipMemcpyAsync(h_scalar, scalar.p, sizeof(double), hipMemcpyDeviceToHost, stream));
         HIPC(hipStreamSynchronize(stream));

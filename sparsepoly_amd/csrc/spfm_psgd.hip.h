@@ -20,41 +20,73 @@ namespace spfm {
 
 constexpr int kPsgdNB = 1024;  // workgroups of the dense passes (partials per vector)
 constexpr int kPsgdMaxC = 4;   // component chunks per lane (k <= 4 * 64)
-constexpr int kPsgdSB = 16;    // row entries whose P loads are in flight together
+constexpr int kPsgdRC = 64;    // row entries per chunk: all their P loads are in flight together
 
-// _anova (psgd.py:34-44) for one lane's component; a[0..deg].  The L lanes of the group
-// first load one tile of L (column, value) pairs, then broadcast them lane by lane so
-// that the kPsgdSB dependent P loads of a sub-batch are issued back to back.
+// One chunk (<= kPsgdRC entries) of a row, spread over the L lanes of its group: lane ln
+// holds entry tb + t*L + ln in slot t.  Entries are broadcast with group shuffles, so the
+// dependent P loads of the whole chunk are issued back to back (one round trip) and stay
+// in registers for the gradient pass.  With one wave per SIMD resident (a minibatch is only
+// ~1000 waves) registers are free and memory round trips are the whole cost.
 template <typename T, int L>
-__device__ __forceinline__ void psgd_anova(double* a, int deg, int64_t lo, int64_t hi, int ln,
-                                           const int32_t* __restrict__ ridx,
-                                           const T* __restrict__ rval,
-                                           const double* __restrict__ Pcol /* Pt + o*d*k + s */,
-                                           int k, bool act) {
+struct PsgdChunk {
+    static constexpr int NT = kPsgdRC / L;
+    int jl[NT];
+    double xl[NT];
+    double p[kPsgdRC];
+    int cnt;
+
+    __device__ __forceinline__ void load_entries(int64_t tb, int64_t hi, int ln,
+                                                 const int32_t* __restrict__ ridx,
+                                                 const T* __restrict__ rval) {
+        cnt = (int)((hi - tb < kPsgdRC) ? (hi - tb) : kPsgdRC);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int64_t e = tb + t * L + ln;
+            const bool in = e < hi;
+            jl[t] = in ? ridx[e] : 0;
+            xl[t] = in ? (double)rval[e] : 0.0;  // 0 beyond the row: every update is a no-op
+        }
+    }
+    __device__ __forceinline__ int col(int u) const { return __shfl(jl[u / L], u % L, L); }
+    __device__ __forceinline__ double val(int u) const { return __shfl(xl[u / L], u % L, L); }
+
+    __device__ __forceinline__ void load_p(const double* __restrict__ Pcol, int k, bool act) {
+#pragma unroll
+        for (int u = 0; u < kPsgdRC; ++u) {
+            const int j = col(u);
+            p[u] = (act && u < cnt) ? Pcol[(size_t)j * k] : 0.0;
+        }
+    }
+    // _anova (psgd.py:34-44) over this chunk, continuing a[]
+    __device__ __forceinline__ void dp(double* a, int deg) const {
+#pragma unroll
+        for (int u = 0; u < kPsgdRC; ++u) {
+            const double x = val(u);
+#pragma unroll
+            for (int t = kMaxDegree; t >= 1; --t)
+                if (t <= deg) a[t] += a[t - 1] * x * p[u];
+        }
+    }
+    // _grad_anova + the scatter of _update_grads (psgd.py:25-31, :86-91)
+    __device__ __forceinline__ void grad(const double* a, int deg, double dl,
+                                         double* __restrict__ Gcol, int k, bool act) const {
+#pragma unroll
+        for (int u = 0; u < kPsgdRC; ++u) {
+            const int j = col(u);
+            const double x = val(u);
+            double dprev = x;
+#pragma unroll
+            for (int t = 1; t < kMaxDegree; ++t)
+                if (t < deg) dprev = x * (a[t] - p[u] * dprev);
+            if (act && u < cnt) unsafeAtomicAdd(&Gcol[(size_t)j * k], dl * dprev);
+        }
+    }
+};
+
+__device__ __forceinline__ void psgd_a_init(double* a) {
     a[0] = 1.0;
 #pragma unroll
     for (int t = 1; t <= kMaxDegree; ++t) a[t] = 0.0;
-    for (int64_t tb = lo; tb < hi; tb += L) {
-        const bool in = tb + ln < hi;
-        const int jl = in ? ridx[tb + ln] : 0;
-        const double xl = in ? (double)rval[tb + ln] : 0.0;
-        const int cnt = (int)((hi - tb < L) ? (hi - tb) : L);
-        for (int u0 = 0; u0 < cnt; u0 += kPsgdSB) {
-            double x[kPsgdSB], p[kPsgdSB];
-#pragma unroll
-            for (int u = 0; u < kPsgdSB; ++u) {
-                const int j = __shfl(jl, u0 + u, L);
-                x[u] = __shfl(xl, u0 + u, L);  // 0 beyond the row: the update is a no-op
-                p[u] = act ? Pcol[(size_t)j * k] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < kPsgdSB; ++u) {
-#pragma unroll
-                for (int t = kMaxDegree; t >= 1; --t)
-                    if (t <= deg) a[t] += a[t - 1] * x[u] * p[u];
-            }
-        }
-    }
 }
 
 // One L-lane group per row of the minibatch.
@@ -73,8 +105,12 @@ __global__ __launch_bounds__(kBlock) void psgd_grad_kernel(
     const int i = samples[r];
     const int64_t lo = rptr[i], hi = rptr[i + 1];
     const int C = (k + L - 1) / L;
-    const bool keep = (n_orders == 1 && C == 1);
+    // the common shape (one order, k <= L, row fits one chunk) keeps its chunk -- entries
+    // and P values -- in registers between the prediction and the gradient pass
+    const bool keep = (n_orders == 1 && C == 1 && hi - lo <= kPsgdRC);
+    PsgdChunk<T, L> ch;
     double a[kMaxDegree + 1];
+    const double yi = (double)yy[2 * (size_t)i + 1];
     // _pred (psgd.py:47-57)
     double yp = 0.0;
     for (int64_t e = lo + ln; e < hi; e += L) yp += (double)rval[e] * w[ridx[e]];
@@ -83,8 +119,13 @@ __global__ __launch_bounds__(kBlock) void psgd_grad_kernel(
         for (int c = 0; c < C; ++c) {
             const int s = c * L + ln;
             const bool act = s < k;
-            psgd_anova<T, L>(a, deg, lo, hi, ln, ridx, rval,
-                             Pt + (size_t)o * d * k + (act ? s : 0), k, act);
+            const double* Pcol = Pt + (size_t)o * d * k + (act ? s : 0);
+            psgd_a_init(a);
+            for (int64_t tb = lo; tb < hi; tb += kPsgdRC) {
+                ch.load_entries(tb, hi, ln, ridx, rval);
+                ch.load_p(Pcol, k, act);
+                ch.dp(a, deg);
+            }
             double top = a[1];
 #pragma unroll
             for (int t = 2; t <= kMaxDegree; ++t)
@@ -93,46 +134,36 @@ __global__ __launch_bounds__(kBlock) void psgd_grad_kernel(
         }
     }
     yp = group_sum(yp, L);
-    const double yi = (double)yy[2 * (size_t)i + 1];
     const double dL = dloss_dev(loss, yp, yi);
     if (ln == 0) loss_row[r] = loss_dev(loss, yp, yi);
     // _update_grads (psgd.py:60-91)
     if (fit_linear)
         for (int64_t e = lo + ln; e < hi; e += L)
             unsafeAtomicAdd(&grad_w[ridx[e]], dL * (double)rval[e]);
+    if (keep) {
+        if (hi == lo) return;  // empty row: the chunk was never loaded
+        const bool act = ln < k;
+        ch.grad(a, degree, act ? dL * lams[ln] : 0.0, grad_P + (act ? ln : 0), k, act);
+        return;
+    }
     for (int o = 0; o < n_orders; ++o) {
         const int deg = degree - o;
         for (int c = 0; c < C; ++c) {
             const int s = c * L + ln;
             const bool act = s < k;
             const double* Pcol = Pt + (size_t)o * d * k + (act ? s : 0);
-            if (!keep) psgd_anova<T, L>(a, deg, lo, hi, ln, ridx, rval, Pcol, k, act);
-            const double dl = act ? dL * lams[s] : 0.0;
             double* Gcol = grad_P + (size_t)o * d * k + (act ? s : 0);
-            for (int64_t tb = lo; tb < hi; tb += L) {
-                const bool in = tb + ln < hi;
-                const int jl = in ? ridx[tb + ln] : 0;
-                const double xl = in ? (double)rval[tb + ln] : 0.0;
-                const int cnt = (int)((hi - tb < L) ? (hi - tb) : L);
-                for (int u0 = 0; u0 < cnt; u0 += kPsgdSB) {
-                    int j[kPsgdSB];
-                    double x[kPsgdSB], p[kPsgdSB];
-#pragma unroll
-                    for (int u = 0; u < kPsgdSB; ++u) {
-                        j[u] = __shfl(jl, u0 + u, L);
-                        x[u] = __shfl(xl, u0 + u, L);
-                        p[u] = act ? Pcol[(size_t)j[u] * k] : 0.0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < kPsgdSB; ++u) {
-                        double dprev = x[u];  // _grad_anova (psgd.py:25-31)
-#pragma unroll
-                        for (int t = 1; t < kMaxDegree; ++t)
-                            if (t < deg) dprev = x[u] * (a[t] - p[u] * dprev);
-                        if (act && u0 + u < cnt)
-                            unsafeAtomicAdd(&Gcol[(size_t)j[u] * k], dl * dprev);
-                    }
-                }
+            const double dl = act ? dL * lams[s] : 0.0;
+            psgd_a_init(a);
+            for (int64_t tb = lo; tb < hi; tb += kPsgdRC) {
+                ch.load_entries(tb, hi, ln, ridx, rval);
+                ch.load_p(Pcol, k, act);
+                ch.dp(a, deg);
+            }
+            for (int64_t tb = lo; tb < hi; tb += kPsgdRC) {
+                ch.load_entries(tb, hi, ln, ridx, rval);
+                ch.load_p(Pcol, k, act);
+                ch.grad(a, deg, dl, Gcol, k, act);
             }
         }
     }

@@ -33,6 +33,25 @@ nnz = Xc.nnz
 batch = int(os.environ.get("SPFM_BENCH_BATCH", int(n * d / nnz)))
 nb = -(-n // batch)
 GAMMA = {"l1": 1e-3, "l21": 1e-3, "squaredl12": 1e-6, "squaredl21": 1e-6}
+cpu = None
+if os.environ.get("SPFM_CPU", "0") == "1":
+    # bounded CPU baseline: the oracle (single thread, f64) on the first `nbc` minibatches
+    # of the same matrix with the full-width P, scaled to one epoch
+    from oracle import oracle as orc
+
+    orc.build()
+    nbc = int(os.environ.get("SPFM_CPU_BATCHES", 8))
+    Xs = X.tocsr()[: nbc * batch]
+    Xo = orc.CSR(Xs)
+    Po = np.ascontiguousarray((0.01 * np.random.RandomState(0).randn(1, k, d)).swapaxes(1, 2))
+    wo = np.zeros(d)
+    cpu = {}
+    for reg in regs:
+        t0 = time.perf_counter()
+        orc.psgd_epoch(Po.copy(), wo.copy(), Xo, y[: nbc * batch], np.ones(k), 2, 1e-3, 1e-3,
+                       GAMMA[reg], reg, "squared", np.arange(nbc * batch, dtype=np.int32), True,
+                       0.01, "optimal", 1.0, batch, 1)
+        cpu[reg] = (time.perf_counter() - t0) * nb / nbc
 for reg in regs:
     eng = HipEngine(0, "f32")
     eng.set_data(Xc, y)
@@ -70,5 +89,9 @@ for reg in regs:
                alg_GB_per_epoch=round((b_grad + b_upd) / 1e9, 2),
                mean_loss=[round(float(v), 6) for v in losses],
                nonzero_frac_P=round(float((eng.get_params()[0] != 0).mean()), 4))
+    if cpu:
+        out["cpu_oracle_s_per_epoch"] = round(cpu[reg], 2)
+        out["cpu_sample"] = "%d of %d minibatches, 1 thread, scaled" % (nbc, nb)
+        out["gpu_over_cpu"] = round(cpu[reg] / dt, 1)
     print(json.dumps(out), flush=True)
     eng.close()

@@ -209,9 +209,11 @@ int spfm_set_use_graph(spfm_handle h, int on);
  * applies to the next spfm_set_schedule), "persistent" (0/1: one persistent launch
  * per pcd component pass, single GPU; caps steps at 64 columns), "prb_groups"
  * (workgroups of the persistent pass), "prb_long" (entries of one column in one row
- * block above which the whole workgroup, not 4 lanes, processes it), "prb_stamps"
- * (diagnostic phase timers).  They change how a sweep is cut into
- * launches, never the arithmetic of a given coordinate order. */
+ * block above which the whole workgroup, not 4 lanes, processes it), "prb_exchange"
+ * (per-step exchange of the persistent pass: 0 = every workgroup sweeps all partial
+ * sums, the default; 1 = one owner workgroup per column adds them and publishes the
+ * total), "prb_stamps" (diagnostic phase timers).  They change how a sweep is cut into
+ * launches and in which order partial sums are added, never the coordinate order. */
 int spfm_set_option(spfm_handle h, const char* key, int value);
 /* read back a tunable, or the derived "persistent_active" (1 if the next pcd epoch
  * will use the persistent pass: option on, single GPU, steps of <= 64 columns) */

@@ -180,6 +180,7 @@ struct spfm_engine {
     // persistent row-block pass (single GPU, pcd): one launch per component pass
     bool persistent = true;
     int prb_G = 64;
+    int prb_xmode = 0;  // granule exchange: 0 flat all-to-all sweep, 1 owner reduce
     bool prb_ready = false;
     int prb_has_long = 0;
     int prb_long = kPrbLong;  // entries per (workgroup, step, slot) above which a slot is "long"
@@ -984,7 +985,7 @@ struct spfm_engine {
         HIPC(prb_sp.alloc(sizeof(int32_t) * sp.size()));
         HIPC(prb_erow.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
         HIPC(prb_eval.alloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1)));
-        HIPC(prb_slab.alloc(sizeof(double) * 2 * (size_t)prb_G * 64 * 2));
+        HIPC(prb_slab.alloc(sizeof(double) * 2 * ((size_t)prb_G + 1) * 64 * 2));
         HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
         HIPC(prow_old.alloc(sizeof(double) * (size_t)d));
         HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
@@ -1022,6 +1023,7 @@ struct spfm_engine {
         a.has_long = prb_has_long;
         a.erow = prb_erow.as<int32_t>();
         a.slab = prb_slab.as<double>();
+        a.xmode = prb_xmode;
         a.abort_flag = prb_abort.as<unsigned>();
         a.stamps = prb_stamp_on ? prb_stamps.as<long long>() : nullptr;
         return a;
@@ -1753,6 +1755,12 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->prb_ready = false;
     } else if (k == "prb_stamps") {
         h->prb_stamp_on = value != 0;
+    } else if (k == "prb_exchange") {
+        if (value != 0 && value != 1) {
+            h->err = "prb_exchange must be 0 (flat sweep) or 1 (owner reduce)";
+            return SPFM_ERR_INVALID;
+        }
+        h->prb_xmode = value;
     } else if (k == "prb_groups") {
         if (value < 1) {
             h->err = "prb_groups must be >= 1";
@@ -1782,6 +1790,7 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "max_batch") *value = h->max_batch_opt;
     else if (k == "persistent") *value = h->persistent;
     else if (k == "prb_groups") *value = h->prb_G;
+    else if (k == "prb_exchange") *value = h->prb_xmode;
     else if (k == "persistent_active") *value = h->have_schedule && h->prb_usable();
     else {
         h->err = "unknown option: " + k;

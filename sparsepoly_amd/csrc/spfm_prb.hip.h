@@ -41,7 +41,8 @@ struct PrbArgs {
     const uint32_t* lmask; // [G][nb][2] bit q: slot q is "long" in this row block
     int has_long;          // 0: no long slot anywhere in the schedule (masks not even read)
     const int32_t* erow;   // entry row ids, sorted by (workgroup, batch, slot, row)
-    double* slab;          // [2][G][64][2]
+    double* slab;          // [2][G][64][2] partial sums, then [2][64][2] totals (xmode 1)
+    int xmode;             // exchange: 0 = every workgroup sweeps all slabs; 1 = owner reduce
     unsigned* abort_flag;  // [1]
     long long* stamps;     // diagnostic: [G][16] accumulated cycles per phase (8 control-wave,
                            // 8 worker-wave values), or nullptr
@@ -81,10 +82,100 @@ __device__ __forceinline__ unsigned long long prb_load_granule(const double* p) 
                              __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Poll NV adjacent granules until all carry `tag`; bounded, sets the abort word on time-out.
+template <int NV>
+__device__ __forceinline__ bool prb_poll(const PrbArgs& a, const double* p,
+                                         unsigned long long tag, double* out) {
+    unsigned long long t[NV];
+    unsigned spins = 0;
+    for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            t[v] = prb_load_granule(p + v);
+            all = all && ((t[v] & 3ull) == tag);
+        }
+        if (all) break;
+        if ((++spins & 63u) == 0) {
+            if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                spins > (1u << 21)) {
+                __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[v] = __longlong_as_double((long long)(t[v] & ~3ull));
+    return true;
+}
+
+// Owner-reduce exchange (xmode 1), executed by the control wave.  Slot q belongs to
+// workgroup q % G: its control wave gathers the G partials of the slot (lane = source
+// workgroup), adds them in a fixed butterfly order and publishes ONE total granule per
+// value; then every control wave reads the <= 64 totals (lane = slot).  Two dependent
+// fabric hops, but 2 x 64 granule loads per workgroup and step instead of G x 64: the flat
+// sweep is bound by the number of uncached fabric transactions, not by their latency.
+// Every owner publishes every step (unused slots carry zeros), so a total word is always
+// rewritten before its tag value comes round again.
+template <int NV>
+__device__ __forceinline__ bool prb_owner_exchange(const PrbArgs& a, int b, int g, int lane,
+                                                   int ncols, double* tot) {
+    const double* slabA = a.slab + (size_t)(b & 1) * a.G * 64 * 2;
+    double* slabB = a.slab + (size_t)2 * a.G * 64 * 2 + (size_t)(b & 1) * 64 * 2;
+    const unsigned long long tag = prb_tag(b);
+    bool ok = true;
+    for (int q = g; q < 64; q += a.G) {
+        double acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+        for (int src = lane; src < a.G; src += 64) {
+            double val[NV];
+            if (!prb_poll<NV>(a, slabA + ((size_t)src * 64 + q) * 2, tag, val)) ok = false;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] += ok ? val[v] : 0.0;
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = wave_sum(acc[v]);
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) prb_store_granule(slabB + (size_t)q * 2 + v, acc[v], tag);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) tot[v] = 0.0;
+    if (lane < ncols) {
+        if (!prb_poll<NV>(a, slabB + (size_t)lane * 2, tag, tot)) ok = false;
+    }
+    return __all(ok) != 0;
+}
+
 // Worker wave `w` (0..3) sums the granules of workgroups [w*G/4, (w+1)*G/4) for slot
 // `lane` (all loads in flight together, re-swept until every tag matches); the control
 // wave later adds the four quarter sums in order w = 0..3, so the total is the same bit
 // pattern in every workgroup.  Returns false after a bounded number of sweeps.
+typedef unsigned __attribute__((ext_vector_type(4))) prb_u4;
+
+// Eight 16-byte agent-scope loads (one granule PAIR each) issued back to back, then one
+// wait.  A pair is two independently tagged 8-byte words, so a torn 16-byte read is
+// harmless; the wide load halves the number of cache-line requests of the sweep, which is
+// bound by the CU's request rate (every granule line is fetched uncached through sc1).
+__device__ __forceinline__ void prb_load_pairs8(const double* const* p, prb_u4* r) {
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\t"
+        "global_load_dwordx4 %1, %9, off sc1\n\t"
+        "global_load_dwordx4 %2, %10, off sc1\n\t"
+        "global_load_dwordx4 %3, %11, off sc1\n\t"
+        "global_load_dwordx4 %4, %12, off sc1\n\t"
+        "global_load_dwordx4 %5, %13, off sc1\n\t"
+        "global_load_dwordx4 %6, %14, off sc1\n\t"
+        "global_load_dwordx4 %7, %15, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]),
+          "=&v"(r[6]), "=&v"(r[7])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+        : "memory");
+}
+
 template <int NV>
 __device__ __forceinline__ bool prb_collect_quarter(const PrbArgs& a, int b, int w, int lane,
                                                     int ncols, double* out /* [4][64][2] LDS */) {
@@ -103,14 +194,29 @@ __device__ __forceinline__ bool prb_collect_quarter(const PrbArgs& a, int b, int
             unsigned spins = 0;
             for (;;) {
                 bool all = true;
+                if constexpr (NV == 2) {
+                    const double* ptr[GU];
+                    prb_u4 r[GU];
 #pragma unroll
-                for (int u = 0; u < GU; ++u)
+                    for (int u = 0; u < GU; ++u)  // beyond the part: re-read its last pair
+                        ptr[u] = sl + (size_t)((gg + u < g1) ? gg + u : g1 - 1) * 128;
+                    prb_load_pairs8(ptr, r);
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        const bool in = gg + u < g1;
-                        t[u][v] = in ? prb_load_granule(sl + (size_t)(gg + u) * 128 + v) : tag;
-                        all = all && ((t[u][v] & 3ull) == tag);
+                    for (int u = 0; u < GU; ++u) {
+                        t[u][0] = ((unsigned long long)r[u].y << 32) | r[u].x;
+                        t[u][1] = ((unsigned long long)r[u].w << 32) | r[u].z;
+                        all = all && ((t[u][0] & 3ull) == tag) && ((t[u][1] & 3ull) == tag);
                     }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < GU; ++u)
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) {
+                            const bool in = gg + u < g1;
+                            t[u][v] = in ? prb_load_granule(sl + (size_t)(gg + u) * 128 + v) : tag;
+                            all = all && ((t[u][v] & 3ull) == tag);
+                        }
+                }
                 if (all) break;
                 if ((++spins & 63u) == 0) {
                     if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED,
@@ -370,8 +476,10 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
         if (!control) {
             PRB_WSTAMP(1)  // publish issue
-            const bool ok = prb_collect_quarter<2>(a, b, wave - 1, lane, ncols, sh_quart);
-            if (!ok) *sh_ok = 0;
+            if (a.xmode == 0) {
+                const bool ok = prb_collect_quarter<2>(a, b, wave - 1, lane, ncols, sh_quart);
+                if (!ok) *sh_ok = 0;
+            }
             PRB_WSTAMP(2)  // granule sweep until every workgroup's partials are in
             if (b + 1 < a.nb) {
                 // prefetch (after the exchange: vmcnt retires in order, so streaming loads
@@ -385,17 +493,23 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         // prefetch loads just issued stay in flight across it (a __syncthreads() would
         // add s_waitcnt vmcnt(0) and expose their HBM latency on every step).
         PRB_WSTAMP(3)  // prefetch issue
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (a.xmode == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!*sh_ok) break;
+        }
         PRB_STAMP(3)
         PRB_WSTAMP(4)  // B3
-        if (!*sh_ok) break;
         if (control) {
             double tot[2];
+            if (a.xmode == 0) {
 #pragma unroll
-            for (int v = 0; v < 2; ++v)
-                tot[v] = ((sh_quart[(0 * 64 + lane) * 2 + v] + sh_quart[(1 * 64 + lane) * 2 + v]) +
-                          sh_quart[(2 * 64 + lane) * 2 + v]) +
-                         sh_quart[(3 * 64 + lane) * 2 + v];
+                for (int v = 0; v < 2; ++v)
+                    tot[v] = ((sh_quart[(0 * 64 + lane) * 2 + v] + sh_quart[(1 * 64 + lane) * 2 + v]) +
+                              sh_quart[(2 * 64 + lane) * 2 + v]) +
+                             sh_quart[(3 * 64 + lane) * 2 + v];
+            } else if (!prb_owner_exchange<2>(a, b, g, lane, ncols, tot)) {
+                *sh_ok = 0;
+            }
             const bool valid = lane < ncols;
             const double res = pcd_chain_lanes<M>(reg, lane, ncols - 1, valid, pl, tot[0], tot[1],
                                                   lam, mu, beta, gamma, eta, cache);
@@ -409,6 +523,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             PRB_STAMP(4)
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B4: deltas in LDS
+        if (a.xmode != 0 && !*sh_ok) break;
         PRB_STAMP(5)
         PRB_WSTAMP(5)  // waiting for the control wave's chain
         // ---- phase 3 (workers): scatter-update of the own rows (pcd.py:124-133)
@@ -584,19 +699,28 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 prb_store_granule(sl, ag, prb_tag(b));
             }
             if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
-            const bool ok = prb_collect_quarter<1>(a, b, wave - 1, lane, ncols, sh_quart);
-            if (!ok) *sh_ok = 0;
+            if (a.xmode == 0) {
+                const bool ok = prb_collect_quarter<1>(a, b, wave - 1, lane, ncols, sh_quart);
+                if (!ok) *sh_ok = 0;
+            }
             if (b + 1 < a.nb) {
                 prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt);
             }
         }
         if (control && b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // quarter sums in LDS
-        if (!*sh_ok) break;
+        if (a.xmode == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // quarter sums in LDS
+            if (!*sh_ok) break;
+        }
         if (control) {
-            const double tot = ((sh_quart[(0 * 64 + lane) * 2] + sh_quart[(1 * 64 + lane) * 2]) +
-                                sh_quart[(2 * 64 + lane) * 2]) +
-                               sh_quart[(3 * 64 + lane) * 2];
+            double tot;
+            if (a.xmode == 0) {
+                tot = ((sh_quart[(0 * 64 + lane) * 2] + sh_quart[(1 * 64 + lane) * 2]) +
+                       sh_quart[(2 * 64 + lane) * 2]) +
+                      sh_quart[(3 * 64 + lane) * 2];
+            } else if (!prb_owner_exchange<1>(a, b, g, lane, ncols, &tot)) {
+                *sh_ok = 0;
+            }
             const bool valid = lane < ncols;
             double upd = tot;           // cd_linear.py:19-24
             upd += alpha * wl;
@@ -610,6 +734,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // updates in LDS
+        if (a.xmode != 0 && !*sh_ok) break;
         if (slot < ncols) {
             const double upd = sh_delta[slot];
             if (upd != 0.0) {

@@ -217,23 +217,43 @@ __global__ __launch_bounds__(kBlock) void pcd_grad_kernel(
 // lanes before the first mismatch are then provably right, so each round fixes at
 // least one more column and the fixed point is exactly the sequential result (up to
 // the rounding of composed vs. step-by-step affine evaluation, ~1e-16 relative).
-__device__ __forceinline__ void affine_scan_inclusive(double& al, double& be, int lane) {
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const double oa = __shfl_up(al, o, kWave);
-        const double ob = __shfl_up(be, o, kWave);
-        if (lane >= o) {  // mine after other: x -> al*(oa*x + ob) + be
-            be = al * ob + be;
-            al = al * oa;
-        }
-    }
+// Lane movement for the scan uses DPP (data-parallel primitives: the operand of a VALU
+// move is taken from another lane, ~one issue cycle) instead of ds_bpermute-based
+// __shfl_up (an LDS-crossbar round trip per step): the chain is on the critical path of
+// every dependent step.  gfx9/CDNA controls: row_shr:n (within rows of 16 lanes),
+// row_bcast:15 / row_bcast:31 (last lane of a row / of the lower half to the following
+// rows), wave_shr:1.  A lane without a valid source keeps `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_d(double old, double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// one scan step: compose the map of the lanes in front (identity where there is none)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void affine_scan_step(double& al, double& be) {
+    const double oa = dpp_move_d<CTRL, ROW_MASK>(1.0, al);
+    const double ob = dpp_move_d<CTRL, ROW_MASK>(0.0, be);
+    be = al * ob + be;  // mine after other: x -> al*(oa*x + ob) + be
+    al = al * oa;
+}
+
+__device__ __forceinline__ void affine_scan_inclusive(double& al, double& be, int /*lane*/) {
+    affine_scan_step<0x111, 0xf>(al, be);  // row_shr:1
+    affine_scan_step<0x112, 0xf>(al, be);  // row_shr:2
+    affine_scan_step<0x114, 0xf>(al, be);  // row_shr:4
+    affine_scan_step<0x118, 0xf>(al, be);  // row_shr:8   -> every row of 16 is scanned
+    affine_scan_step<0x142, 0xa>(al, be);  // row_bcast:15 into rows 1 and 3
+    affine_scan_step<0x143, 0xc>(al, be);  // row_bcast:31 into rows 2 and 3
 }
 
 // value of the cache in front of column `lane` given c0 and the inclusive scan
-__device__ __forceinline__ double affine_before(double al_inc, double be_inc, double c0, int lane) {
-    const double pa = __shfl_up(al_inc, 1, kWave);
-    const double pb = __shfl_up(be_inc, 1, kWave);
-    return (lane == 0) ? c0 : (pa * c0 + pb);
+__device__ __forceinline__ double affine_before(double al_inc, double be_inc, double c0, int /*lane*/) {
+    const double pa = dpp_move_d<0x138, 0xf>(0.0, al_inc);  // wave_shr:1; lane 0: x -> c0
+    const double pb = dpp_move_d<0x138, 0xf>(c0, be_inc);
+    return pa * c0 + pb;
 }
 
 // Second half of pcd._update (optimizer/pcd.py:61-68) for up to 64 columns held one

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/spfm.h"
@@ -181,6 +182,8 @@ struct spfm_engine {
     bool persistent = true;
     int prb_G = 64;
     int prb_xmode = 0;  // granule exchange: 0 flat all-to-all sweep, 1 owner reduce
+    bool prb_lds = true;  // keep the row block (A, residual) in LDS when it fits (f32, squared)
+    int prb_lds_active = 0;  // what the last pcd pass actually used
     bool prb_ready = false;
     int prb_has_long = 0;
     int prb_long = kPrbLong;  // entries per (workgroup, step, slot) above which a slot is "long"
@@ -1024,6 +1027,8 @@ struct spfm_engine {
         a.erow = prb_erow.as<int32_t>();
         a.slab = prb_slab.as<double>();
         a.xmode = prb_xmode;
+        a.rows_per = (int)std::max<int64_t>((n + prb_G - 1) / prb_G, 1);
+        a.n_rows = (int)n;
         a.abort_flag = prb_abort.as<unsigned>();
         a.stamps = prb_stamp_on ? prb_stamps.as<long long>() : nullptr;
         return a;
@@ -1037,7 +1042,23 @@ struct spfm_engine {
         double* Po = P.as<double>() + (size_t)order_idx * k * d;
         Ctl* c = ctl.as<Ctl>();
         double* cb = cache.as<double>();
-        HIPC(hipFuncSetAttribute((const void*)pcd_prb_kernel<T, M, LOSS>,
+        // row block resident in LDS (8 bytes per row) when the variant exists and fits
+        constexpr bool can_lr = std::is_same<T, float>::value && LOSS == LOSS_SQUARED &&
+                                Kind<M>::AS == 1;
+        const PrbArgs pa = prb_args();
+        int lds_max = 0;
+        HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+        const size_t lds_lr = sizeof(double) * kPrbLdsFixed + (size_t)pa.rows_per * 8;
+        const bool use_lr = can_lr && prb_lds && lds_lr <= (size_t)lds_max;
+        const size_t lds_bytes = use_lr ? std::max(lds_lr, kPrbLds) : kPrbLds;
+        prb_lds_active = use_lr;
+        if constexpr (can_lr) {
+            if (use_lr)
+                HIPC(hipFuncSetAttribute((const void*)pcd_prb_kernel<T, M, LOSS, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_bytes));
+        }
+        HIPC(hipFuncSetAttribute((const void*)pcd_prb_kernel<T, M, LOSS, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrbLds));
         hipLaunchKernelGGL(begin_pass_kernel, dim3(1), dim3(64), 0, stream, c,
                            comp_order.as<int32_t>(), lams.as<double>());
@@ -1048,10 +1069,22 @@ struct spfm_engine {
                            d_desc.as<ColDesc>(), prow_old.as<double>());
         HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));  // tag 0 = "not yet"
         prof_begin(0, nnz);
-        hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS>), dim3(prb_G), dim3(kPrbThreads), kPrbLds,
-                           stream, c, prb_args(), prb_eval.as<T>(), A.as<T>(),
-                           (size_t)n * Kind<M>::AS, yy.as<T>(), prow_old.as<double>(), Po, d, reg, cb,
-                           mu, beta, gamma, eta, prb_viol.as<double>());
+        bool launched = false;
+        if constexpr (can_lr) {
+            if (use_lr) {
+                hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, true>), dim3(prb_G),
+                                   dim3(kPrbThreads), lds_bytes, stream, c, pa, prb_eval.as<T>(),
+                                   A.as<T>(), (size_t)n * Kind<M>::AS, yy.as<T>(),
+                                   prow_old.as<double>(), Po, d, reg, cb, mu, beta, gamma, eta,
+                                   prb_viol.as<double>());
+                launched = true;
+            }
+        }
+        if (!launched)
+            hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, false>), dim3(prb_G), dim3(kPrbThreads),
+                               kPrbLds, stream, c, pa, prb_eval.as<T>(), A.as<T>(),
+                               (size_t)n * Kind<M>::AS, yy.as<T>(), prow_old.as<double>(), Po, d,
+                               reg, cb, mu, beta, gamma, eta, prb_viol.as<double>());
         prof_end(0);
         hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
                            d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());
@@ -1755,6 +1788,8 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->prb_ready = false;
     } else if (k == "prb_stamps") {
         h->prb_stamp_on = value != 0;
+    } else if (k == "prb_lds") {
+        h->prb_lds = value != 0;
     } else if (k == "prb_exchange") {
         if (value != 0 && value != 1) {
             h->err = "prb_exchange must be 0 (flat sweep) or 1 (owner reduce)";
@@ -1791,6 +1826,8 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "persistent") *value = h->persistent;
     else if (k == "prb_groups") *value = h->prb_G;
     else if (k == "prb_exchange") *value = h->prb_xmode;
+    else if (k == "prb_lds") *value = h->prb_lds;
+    else if (k == "prb_lds_active") *value = h->prb_lds_active;
     else if (k == "persistent_active") *value = h->have_schedule && h->prb_usable();
     else {
         h->err = "unknown option: " + k;

@@ -469,6 +469,26 @@ __device__ __forceinline__ void pcd_sync_entry(size_t i, double x, double p_old,
     yy[2 * i] = (T)(yh - lam * upd * dprev);
 }
 
+// the same update on a row block held in LDS as (A[i], r_i = yhat_i - y_i); one cache
+// value per row (M == 2 or all-subsets)
+template <typename T, int M>
+__device__ __forceinline__ void pcd_sync_entry_lds(int il, double x, double p_old, double upd,
+                                                   double lam, T* lds_a, T* lds_r) {
+    const double a0 = (double)lds_a[il];
+    double yh = (double)lds_r[il];
+    if constexpr (M == 0) {
+        yh -= lam * a0;
+        double a1 = a0 / (1.0 + x * p_old);
+        a1 *= 1.0 + x * (p_old - upd);
+        yh += lam * a1;
+        lds_a[il] = (T)a1;
+        lds_r[il] = (T)yh;
+    } else {
+        lds_a[il] = (T)(a0 - upd * x);
+        lds_r[il] = (T)(yh - lam * upd * (x * (a0 - p_old * x)));
+    }
+}
+
 template <typename T, int M>
 __global__ __launch_bounds__(kBlock) void pcd_sync_kernel(
     const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc,

@@ -43,6 +43,8 @@ struct PrbArgs {
     const int32_t* erow;   // entry row ids, sorted by (workgroup, batch, slot, row)
     double* slab;          // [2][G][64][2] partial sums, then [2][64][2] totals (xmode 1)
     int xmode;             // exchange: 0 = every workgroup sweeps all slabs; 1 = owner reduce
+    int rows_per;          // rows per workgroup (row block g = [g*rows_per, (g+1)*rows_per))
+    int n_rows;            // n_samples
     unsigned* abort_flag;  // [1]
     long long* stamps;     // diagnostic: [G][16] accumulated cycles per phase (8 control-wave,
                            // 8 worker-wave values), or nullptr
@@ -280,14 +282,15 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int q) {
 
 template <typename T>
 __device__ __forceinline__ void prb_load_entries(const PrbArgs& a, const T* __restrict__ eval,
-                                                 int e0, int e1, int sub, PrbEntries<T>& en) {
+                                                 int e0, int e1, int sub, PrbEntries<T>& en,
+                                                 int pad_row = 0) {
     en.e0 = e0;
     en.e1 = e1;
 #pragma unroll
     for (int u = 0; u < PRB_PF; ++u) {
         const int e = e0 + sub + 4 * u;
         const bool v = e < e1;
-        en.row[u] = v ? a.erow[e] : 0;
+        en.row[u] = v ? a.erow[e] : pad_row;  // padding reads a valid row of this block
         en.x[u] = v ? eval[e] : (T)0;
     }
 }
@@ -299,8 +302,17 @@ __device__ __forceinline__ void prb_load_entries(const PrbArgs& a, const T* __re
 // the workers issue the next step's streaming loads while the control wave waits for
 // the other workgroups.
 constexpr int kPrbThreads = 320;
+constexpr int kPrbLdsFixed = 1536;  // doubles of fixed LDS (control data, part sums, long slots)
 
-template <typename T, int M, int LOSS>
+// LR = row state resident in LDS (float storage, squared loss, one cache value per row:
+// M == 2 or the all-subsets model): the workgroup keeps A[i] and the residual
+// r_i = yhat_i - y_i of its rows in LDS for the whole pass (8 bytes per row; 125 KB at
+// 15 625 rows), so the per-step gather and scatter are LDS accesses instead of L2 round
+// trips and the end-of-step barrier no longer waits for store acknowledgements.  dloss of
+// the squared loss is the residual itself, so the kernel runs unchanged with
+// (yhat, y) := (r, 0); the block is loaded at the start and written back (yhat = r + y)
+// at the end of the launch.
+template <typename T, int M, int LOSS, bool LR>
 __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     const Ctl* __restrict__ ctl, PrbArgs a, const T* __restrict__ eval, T* __restrict__ A_all,
     size_t a_stride, T* __restrict__ yy, const double* __restrict__ pold_sched,
@@ -326,6 +338,20 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     for (int t = 0; t <= M; ++t) cache[t] = cache_in[t];
 
     double* sh_long = dyn_lds + 1024;  // [64][4][2] wave partials of long slots
+    static_assert(!LR || (Kind<M>::AS == 1 && LOSS == LOSS_SQUARED && sizeof(T) == 4),
+                  "LDS-resident rows: float storage, squared loss, one cache value per row");
+    const int row0 = LR ? g * a.rows_per : 0;
+    T* lds_a = reinterpret_cast<T*>(dyn_lds + kPrbLdsFixed);  // [rows_per] A[i]
+    T* lds_r = lds_a + a.rows_per;                             // [rows_per] yhat_i - y_i
+    if constexpr (LR) {
+        const int nr = min(a.rows_per, a.n_rows - row0);
+        for (int il = tid; il < nr; il += kPrbThreads) {
+            const typename Vec2<T>::type yv = yy2[(size_t)(row0 + il)];
+            lds_a[il] = A[(size_t)(row0 + il)];
+            lds_r[il] = (T)((double)yv.x - (double)yv.y);
+        }
+        __syncthreads();
+    }
     PrbEntries<T> cur, nxt;
     int c0 = a.bptr[0], c1 = a.bptr[1];
     int c2 = (a.nb > 1) ? a.bptr[2] : c1;
@@ -334,7 +360,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     {
         int e0, e1;
         prb_load_sp(a, g, 0, slot, c1 - c0, e0, e1, lm0);
-        prb_load_entries<T>(a, eval, e0, e1, sub, cur);
+        prb_load_entries<T>(a, eval, e0, e1, sub, cur, row0);
     }
     int ne0 = 0, ne1 = 0;  // slot bounds of step b+1
     if (a.nb > 1) prb_load_sp(a, g, 1, slot, c2 - c1, ne0, ne1, lm1);
@@ -375,12 +401,19 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         } else {
 #pragma unroll
             for (int u = 0; u < PRB_PF; ++u) {  // all gathers in flight before any use
-                const size_t i = (size_t)cur.row[u];
-                const typename Vec2<T>::type yv = yy2[i];
-                yh[u] = (double)yv.x;
-                yt[u] = (double)yv.y;
+                if constexpr (LR) {
+                    const int il = cur.row[u] - row0;
+                    yh[u] = (double)lds_r[il];
+                    yt[u] = 0.0;
+                    av[u][0] = (double)lds_a[il];
+                } else {
+                    const size_t i = (size_t)cur.row[u];
+                    const typename Vec2<T>::type yv = yy2[i];
+                    yh[u] = (double)yv.x;
+                    yt[u] = (double)yv.y;
 #pragma unroll
-                for (int t = 0; t < AS; ++t) av[u][t] = (double)A[i * AS + t];
+                    for (int t = 0; t < AS; ++t) av[u][t] = (double)A[i * AS + t];
+                }
             }
             double ag = 0.0, ah = 0.0;
 #pragma unroll
@@ -395,12 +428,20 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {  // rare: long slot
                 const int i = a.erow[e];
                 const double x = (double)eval[e];
-                const typename Vec2<T>::type yv = yy2[i];
-                double a1[AS];
+                double a1[AS], y0, y1;
+                if constexpr (LR) {
+                    y0 = (double)lds_r[i - row0];
+                    y1 = 0.0;
+                    a1[0] = (double)lds_a[i - row0];
+                } else {
+                    const typename Vec2<T>::type yv = yy2[i];
+                    y0 = (double)yv.x;
+                    y1 = (double)yv.y;
 #pragma unroll
-                for (int t = 0; t < AS; ++t) a1[t] = (double)A[(size_t)i * AS + t];
+                    for (int t = 0; t < AS; ++t) a1[t] = (double)A[(size_t)i * AS + t];
+                }
                 const double dprev = grad_factor<M>(a1, x, p_slot);
-                ag += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * dprev;
+                ag += dloss_dev(LOSS, y0, y1) * dprev;
                 ah += dprev * dprev;
             }
             ag += __shfl_xor(ag, 1, kWave);
@@ -436,13 +477,21 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                     for (int e = le0 + wt; e < le1; e += 256) {
                         const int i = a.erow[e];
                         const double x = (double)eval[e];
-                        const typename Vec2<T>::type yv = yy2[i];
-                        double a1[Kind<M>::AS];
+                        double a1[Kind<M>::AS], y0, y1;
+                        if constexpr (LR) {
+                            y0 = (double)lds_r[i - row0];
+                            y1 = 0.0;
+                            a1[0] = (double)lds_a[i - row0];
+                        } else {
+                            const typename Vec2<T>::type yv = yy2[i];
+                            y0 = (double)yv.x;
+                            y1 = (double)yv.y;
 #pragma unroll
-                        for (int t = 0; t < Kind<M>::AS; ++t)
-                            a1[t] = (double)A[(size_t)i * Kind<M>::AS + t];
+                            for (int t = 0; t < Kind<M>::AS; ++t)
+                                a1[t] = (double)A[(size_t)i * Kind<M>::AS + t];
+                        }
                         const double dprev = grad_factor<M>(a1, x, pq);
-                        lg += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * dprev;
+                        lg += dloss_dev(LOSS, y0, y1) * dprev;
                         lh += dprev * dprev;
                     }
                     lg = wave_sum(lg);
@@ -485,7 +534,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 // prefetch (after the exchange: vmcnt retires in order, so streaming loads
                 // issued earlier would delay every granule check): entries of step b+1
                 // (bounds already in registers), bounds of b+2
-                prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt);
+                prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt, row0);
                 if (slot < c2 - c1) p_next = pold_sched[c1 + slot];
             }
         }
@@ -541,8 +590,16 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                             double an = av[u][0] / (1.0 + x * p_old);
                             an *= 1.0 + x * (p_old - upd);
                             yn += lam * an;
-                            A[i] = (T)an;
-                            yy[2 * i] = (T)yn;
+                            if constexpr (LR) {
+                                lds_a[i - row0] = (T)an;
+                                lds_r[i - row0] = (T)yn;
+                            } else {
+                                A[i] = (T)an;
+                                yy[2 * i] = (T)yn;
+                            }
+                        } else if constexpr (LR) {  // M == 2
+                            lds_a[i - row0] = (T)(av[u][0] - upd * x);
+                            lds_r[i - row0] = (T)(yh[u] - lam * upd * dlast[u]);
                         } else {
                             double dprev = x;
 #pragma unroll
@@ -556,9 +613,14 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                         }
                     }
                 }
-                for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4)
-                    pcd_sync_entry<T, M>((size_t)a.erow[e], (double)eval[e], p_old, upd, lam, A,
-                                         yy);
+                for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {
+                    if constexpr (LR)
+                        pcd_sync_entry_lds<T, M>(a.erow[e] - row0, (double)eval[e], p_old, upd,
+                                                 lam, lds_a, lds_r);
+                    else
+                        pcd_sync_entry<T, M>((size_t)a.erow[e], (double)eval[e], p_old, upd, lam,
+                                             A, yy);
+                }
             }
         }
         if (lmu != 0ull && !control) {  // long slots: every worker thread scatters
@@ -569,9 +631,14 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 if (upd != 0.0) {
                     const double p_old = sh_pold[q];
                     const int le0 = spb[q], le1 = spb[q + 1];
-                    for (int e = le0 + wt; e < le1; e += 256)
-                        pcd_sync_entry<T, M>((size_t)a.erow[e], (double)eval[e], p_old, upd, lam,
-                                             A, yy);
+                    for (int e = le0 + wt; e < le1; e += 256) {
+                        if constexpr (LR)
+                            pcd_sync_entry_lds<T, M>(a.erow[e] - row0, (double)eval[e], p_old,
+                                                     upd, lam, lds_a, lds_r);
+                        else
+                            pcd_sync_entry<T, M>((size_t)a.erow[e], (double)eval[e], p_old, upd,
+                                                 lam, A, yy);
+                    }
                 }
             }
         }
@@ -586,12 +653,26 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         c2 = c3;
         c3 = c4;
         PRB_WSTAMP(6)  // scatter issue
-        __syncthreads();  // B5: rows move between slots from step to step
+        // B5: rows move between slots from step to step.  With the rows in LDS only LDS
+        // traffic has to land (the prefetch loads of the next step stay in flight).
+        if constexpr (LR)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+            __syncthreads();
         PRB_STAMP(6)
         PRB_WSTAMP(7)  // B5 (stores acknowledged)
     }
 #undef PRB_STAMP
 #undef PRB_WSTAMP
+    if constexpr (LR) {  // write the row block back: yhat = r + y
+        __syncthreads();
+        const int nr = min(a.rows_per, a.n_rows - row0);
+        for (int il = tid; il < nr; il += kPrbThreads) {
+            const size_t i = (size_t)(row0 + il);
+            A[i] = lds_a[il];
+            yy[2 * i] = (T)((double)lds_r[il] + (double)yy[2 * i + 1]);
+        }
+    }
     if (stamp && (tid == 0 || tid == 64)) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) a.stamps[(size_t)g * 16 + (tid == 64 ? 8 : 0) + q] = acc[q];

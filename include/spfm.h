@@ -212,11 +212,15 @@ int spfm_set_use_graph(spfm_handle h, int on);
  * block above which the whole workgroup, not 4 lanes, processes it), "prb_exchange"
  * (per-step exchange of the persistent pass: 0 = every workgroup sweeps all partial
  * sums, the default; 1 = one owner workgroup per column adds them and publishes the
- * total), "prb_stamps" (diagnostic phase timers).  They change how a sweep is cut into
+ * total), "prb_lds" (0/1, default 1: keep each workgroup's row block -- A and the
+ * residual / prediction -- in LDS for the whole pass when it fits: f32 storage, one cache
+ * value per row, squared loss or +-1 targets), "prb_stamps" (diagnostic phase timers).  They change how a sweep is cut into
  * launches and in which order partial sums are added, never the coordinate order. */
 int spfm_set_option(spfm_handle h, const char* key, int value);
 /* read back a tunable, or the derived "persistent_active" (1 if the next pcd epoch
- * will use the persistent pass: option on, single GPU, steps of <= 64 columns) */
+ * will use the persistent pass: option on, single GPU, steps of <= 64 columns) and
+ * "prb_lds_active" (what the last pcd pass used: 0 global rows, 1 LDS residual form,
+ * 2 LDS prediction + label sign) */
 int spfm_get_option(spfm_handle h, const char* key, int* value);
 
 /* diagnostic ("prb_stamps" option): accumulated shader cycles per phase of the last

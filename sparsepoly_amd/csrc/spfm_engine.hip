@@ -183,7 +183,8 @@ struct spfm_engine {
     int prb_G = 64;
     int prb_xmode = 0;  // granule exchange: 0 flat all-to-all sweep, 1 owner reduce
     bool prb_lds = true;  // keep the row block (A, residual) in LDS when it fits (f32, squared)
-    int prb_lds_active = 0;  // what the last pcd pass actually used
+    int prb_lds_active = 0;  // what the last pcd pass actually used (0 / 1 residual / 2 sign)
+    bool y_pm1 = false;      // every target is +1 or -1
     bool prb_ready = false;
     int prb_has_long = 0;
     int prb_long = kPrbLong;  // entries per (workgroup, step, slot) above which a slot is "long"
@@ -426,6 +427,12 @@ struct spfm_engine {
         n = n_;
         d = d_;
         nnz = nz;
+        y_pm1 = true;
+        for (int64_t i = 0; i < n; ++i)
+            if (std::fabs(y[i]) != 1.0) {
+                y_pm1 = false;
+                break;
+            }
         h_cptr.assign(indptr, indptr + d + 1);
         h_cidx.assign(indices, indices + nnz);
         have_data = true;
@@ -1043,22 +1050,25 @@ struct spfm_engine {
         Ctl* c = ctl.as<Ctl>();
         double* cb = cache.as<double>();
         // row block resident in LDS (8 bytes per row) when the variant exists and fits
-        constexpr bool can_lr = std::is_same<T, float>::value && LOSS == LOSS_SQUARED &&
-                                Kind<M>::AS == 1;
+        // (squared loss: A + residual, 8 bytes per row; +-1 targets: A + yhat + sign, 9 bytes)
+        constexpr bool can_lr = std::is_same<T, float>::value && Kind<M>::AS == 1;
+        constexpr int LRV = (LOSS == LOSS_SQUARED) ? 1 : 2;
         const PrbArgs pa = prb_args();
         int lds_max = 0;
         HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
-        const size_t lds_lr = sizeof(double) * kPrbLdsFixed + (size_t)pa.rows_per * 8;
-        const bool use_lr = can_lr && prb_lds && lds_lr <= (size_t)lds_max;
+        const size_t lds_lr = sizeof(double) * kPrbLdsFixed +
+                              (size_t)pa.rows_per * (LRV == 1 ? 8 : 9) + 16;
+        const bool use_lr = can_lr && prb_lds && lds_lr <= (size_t)lds_max &&
+                            (LRV == 1 || y_pm1);
         const size_t lds_bytes = use_lr ? std::max(lds_lr, kPrbLds) : kPrbLds;
-        prb_lds_active = use_lr;
+        prb_lds_active = use_lr ? LRV : 0;
         if constexpr (can_lr) {
             if (use_lr)
-                HIPC(hipFuncSetAttribute((const void*)pcd_prb_kernel<T, M, LOSS, true>,
+                HIPC(hipFuncSetAttribute((const void*)pcd_prb_kernel<T, M, LOSS, LRV>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes));
         }
-        HIPC(hipFuncSetAttribute((const void*)pcd_prb_kernel<T, M, LOSS, false>,
+        HIPC(hipFuncSetAttribute((const void*)pcd_prb_kernel<T, M, LOSS, 0>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrbLds));
         hipLaunchKernelGGL(begin_pass_kernel, dim3(1), dim3(64), 0, stream, c,
                            comp_order.as<int32_t>(), lams.as<double>());
@@ -1072,7 +1082,7 @@ struct spfm_engine {
         bool launched = false;
         if constexpr (can_lr) {
             if (use_lr) {
-                hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, true>), dim3(prb_G),
+                hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, LRV>), dim3(prb_G),
                                    dim3(kPrbThreads), lds_bytes, stream, c, pa, prb_eval.as<T>(),
                                    A.as<T>(), (size_t)n * Kind<M>::AS, yy.as<T>(),
                                    prow_old.as<double>(), Po, d, reg, cb, mu, beta, gamma, eta,
@@ -1081,7 +1091,7 @@ struct spfm_engine {
             }
         }
         if (!launched)
-            hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, false>), dim3(prb_G), dim3(kPrbThreads),
+            hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, 0>), dim3(prb_G), dim3(kPrbThreads),
                                kPrbLds, stream, c, pa, prb_eval.as<T>(), A.as<T>(),
                                (size_t)n * Kind<M>::AS, yy.as<T>(), prow_old.as<double>(), Po, d,
                                reg, cb, mu, beta, gamma, eta, prb_viol.as<double>());

@@ -304,15 +304,17 @@ __device__ __forceinline__ void prb_load_entries(const PrbArgs& a, const T* __re
 constexpr int kPrbThreads = 320;
 constexpr int kPrbLdsFixed = 1536;  // doubles of fixed LDS (control data, part sums, long slots)
 
-// LR = row state resident in LDS (float storage, squared loss, one cache value per row:
-// M == 2 or the all-subsets model): the workgroup keeps A[i] and the residual
-// r_i = yhat_i - y_i of its rows in LDS for the whole pass (8 bytes per row; 125 KB at
-// 15 625 rows), so the per-step gather and scatter are LDS accesses instead of L2 round
-// trips and the end-of-step barrier no longer waits for store acknowledgements.  dloss of
-// the squared loss is the residual itself, so the kernel runs unchanged with
-// (yhat, y) := (r, 0); the block is loaded at the start and written back (yhat = r + y)
-// at the end of the launch.
-template <typename T, int M, int LOSS, bool LR>
+// LR != 0: row state resident in LDS (float storage, one cache value per row: M == 2 or
+// the all-subsets model).  The workgroup keeps A[i] and a 4-byte prediction word of its
+// rows in LDS for the whole pass (8-9 bytes per row; 125 KB at 15 625 rows), so the
+// per-step gather and scatter are LDS accesses instead of L2 round trips and the
+// end-of-step barrier no longer waits for store acknowledgements.
+//   LR == 1 (squared loss): the word is the residual r_i = yhat_i - y_i; dloss is the
+//            residual itself, so the kernel runs unchanged with (yhat, y) := (r, 0);
+//            written back as yhat = r + y.
+//   LR == 2 (targets are +-1, any loss): the word is yhat_i, the label's sign is one byte.
+// The block is loaded at the start and written back at the end of the launch.
+template <typename T, int M, int LOSS, int LR>
 __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     const Ctl* __restrict__ ctl, PrbArgs a, const T* __restrict__ eval, T* __restrict__ A_all,
     size_t a_stride, T* __restrict__ yy, const double* __restrict__ pold_sched,
@@ -338,17 +340,24 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     for (int t = 0; t <= M; ++t) cache[t] = cache_in[t];
 
     double* sh_long = dyn_lds + 1024;  // [64][4][2] wave partials of long slots
-    static_assert(!LR || (Kind<M>::AS == 1 && LOSS == LOSS_SQUARED && sizeof(T) == 4),
-                  "LDS-resident rows: float storage, squared loss, one cache value per row");
+    static_assert(LR == 0 || (Kind<M>::AS == 1 && sizeof(T) == 4 &&
+                              (LR == 2 || LOSS == LOSS_SQUARED)),
+                  "LDS-resident rows: float storage, one cache value per row");
     const int row0 = LR ? g * a.rows_per : 0;
     T* lds_a = reinterpret_cast<T*>(dyn_lds + kPrbLdsFixed);  // [rows_per] A[i]
-    T* lds_r = lds_a + a.rows_per;                             // [rows_per] yhat_i - y_i
-    if constexpr (LR) {
+    T* lds_r = lds_a + a.rows_per;                             // [rows_per] residual or yhat
+    unsigned char* lds_s = reinterpret_cast<unsigned char*>(lds_r + a.rows_per);  // y > 0
+    if constexpr (LR != 0) {
         const int nr = min(a.rows_per, a.n_rows - row0);
         for (int il = tid; il < nr; il += kPrbThreads) {
             const typename Vec2<T>::type yv = yy2[(size_t)(row0 + il)];
             lds_a[il] = A[(size_t)(row0 + il)];
-            lds_r[il] = (T)((double)yv.x - (double)yv.y);
+            if constexpr (LR == 1) {
+                lds_r[il] = (T)((double)yv.x - (double)yv.y);
+            } else {
+                lds_r[il] = yv.x;
+                lds_s[il] = yv.y > (T)0 ? 1 : 0;
+            }
         }
         __syncthreads();
     }
@@ -401,10 +410,10 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         } else {
 #pragma unroll
             for (int u = 0; u < PRB_PF; ++u) {  // all gathers in flight before any use
-                if constexpr (LR) {
+                if constexpr (LR != 0) {
                     const int il = cur.row[u] - row0;
                     yh[u] = (double)lds_r[il];
-                    yt[u] = 0.0;
+                    yt[u] = (LR == 1) ? 0.0 : (lds_s[il] ? 1.0 : -1.0);
                     av[u][0] = (double)lds_a[il];
                 } else {
                     const size_t i = (size_t)cur.row[u];
@@ -429,9 +438,9 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 const int i = a.erow[e];
                 const double x = (double)eval[e];
                 double a1[AS], y0, y1;
-                if constexpr (LR) {
+                if constexpr (LR != 0) {
                     y0 = (double)lds_r[i - row0];
-                    y1 = 0.0;
+                    y1 = (LR == 1) ? 0.0 : (lds_s[i - row0] ? 1.0 : -1.0);
                     a1[0] = (double)lds_a[i - row0];
                 } else {
                     const typename Vec2<T>::type yv = yy2[i];
@@ -478,9 +487,9 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                         const int i = a.erow[e];
                         const double x = (double)eval[e];
                         double a1[Kind<M>::AS], y0, y1;
-                        if constexpr (LR) {
+                        if constexpr (LR != 0) {
                             y0 = (double)lds_r[i - row0];
-                            y1 = 0.0;
+                            y1 = (LR == 1) ? 0.0 : (lds_s[i - row0] ? 1.0 : -1.0);
                             a1[0] = (double)lds_a[i - row0];
                         } else {
                             const typename Vec2<T>::type yv = yy2[i];
@@ -525,12 +534,19 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
         if (!control) {
             PRB_WSTAMP(1)  // publish issue
+            if (LR != 0 && b + 1 < a.nb) {
+                // rows in LDS: the end-of-step barrier no longer drains vmcnt, so the
+                // streaming prefetch of step b+1 is issued BEFORE the exchange -- it has the
+                // whole sweep (which waits for the slowest workgroup anyway) to land
+                prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt, row0);
+                if (slot < c2 - c1) p_next = pold_sched[c1 + slot];
+            }
             if (a.xmode == 0) {
                 const bool ok = prb_collect_quarter<2>(a, b, wave - 1, lane, ncols, sh_quart);
                 if (!ok) *sh_ok = 0;
             }
             PRB_WSTAMP(2)  // granule sweep until every workgroup's partials are in
-            if (b + 1 < a.nb) {
+            if (LR == 0 && b + 1 < a.nb) {
                 // prefetch (after the exchange: vmcnt retires in order, so streaming loads
                 // issued earlier would delay every granule check): entries of step b+1
                 // (bounds already in registers), bounds of b+2
@@ -590,14 +606,14 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                             double an = av[u][0] / (1.0 + x * p_old);
                             an *= 1.0 + x * (p_old - upd);
                             yn += lam * an;
-                            if constexpr (LR) {
+                            if constexpr (LR != 0) {
                                 lds_a[i - row0] = (T)an;
                                 lds_r[i - row0] = (T)yn;
                             } else {
                                 A[i] = (T)an;
                                 yy[2 * i] = (T)yn;
                             }
-                        } else if constexpr (LR) {  // M == 2
+                        } else if constexpr (LR != 0) {  // M == 2
                             lds_a[i - row0] = (T)(av[u][0] - upd * x);
                             lds_r[i - row0] = (T)(yh[u] - lam * upd * dlast[u]);
                         } else {
@@ -614,7 +630,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                     }
                 }
                 for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {
-                    if constexpr (LR)
+                    if constexpr (LR != 0)
                         pcd_sync_entry_lds<T, M>(a.erow[e] - row0, (double)eval[e], p_old, upd,
                                                  lam, lds_a, lds_r);
                     else
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                     const double p_old = sh_pold[q];
                     const int le0 = spb[q], le1 = spb[q + 1];
                     for (int e = le0 + wt; e < le1; e += 256) {
-                        if constexpr (LR)
+                        if constexpr (LR != 0)
                             pcd_sync_entry_lds<T, M>(a.erow[e] - row0, (double)eval[e], p_old,
                                                      upd, lam, lds_a, lds_r);
                         else
@@ -655,7 +671,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         PRB_WSTAMP(6)  // scatter issue
         // B5: rows move between slots from step to step.  With the rows in LDS only LDS
         // traffic has to land (the prefetch loads of the next step stay in flight).
-        if constexpr (LR)
+        if constexpr (LR != 0)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else
             __syncthreads();
@@ -664,13 +680,16 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     }
 #undef PRB_STAMP
 #undef PRB_WSTAMP
-    if constexpr (LR) {  // write the row block back: yhat = r + y
+    if constexpr (LR != 0) {  // write the row block back (LR == 1: yhat = r + y)
         __syncthreads();
         const int nr = min(a.rows_per, a.n_rows - row0);
         for (int il = tid; il < nr; il += kPrbThreads) {
             const size_t i = (size_t)(row0 + il);
             A[i] = lds_a[il];
-            yy[2 * i] = (T)((double)lds_r[il] + (double)yy[2 * i + 1]);
+            if constexpr (LR == 1)
+                yy[2 * i] = (T)((double)lds_r[il] + (double)yy[2 * i + 1]);
+            else
+                yy[2 * i] = lds_r[il];
         }
     }
     if (stamp && (tid == 0 || tid == 64)) {

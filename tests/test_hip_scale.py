@@ -207,3 +207,51 @@ def test_skewed_columns_long_slots(oracle, groups):
         np.testing.assert_allclose(P, fm.P_, rtol=0, atol=1e-9)
         np.testing.assert_allclose(w, fm.w_, rtol=0, atol=1e-9)
         np.testing.assert_allclose(yp, fm.y_pred_, rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("loss,model,want_mode", [("squared", "fm", 1), ("logistic", "fm", 2),
+                                                  ("squared_hinge", "fm", 2),
+                                                  ("squared", "all_subsets", 1)])
+def test_lds_resident_row_block_matches_global_path(oracle, loss, model, want_mode):
+    """f32 persistent pass with the row block in LDS (residual form for the squared loss,
+    yhat + label sign for +-1 targets) vs the same pass on global memory and vs the f64
+    oracle; the engine reports which variant ran."""
+    from sparsepoly_amd.engine import HipEngine
+    from sparsepoly_amd.synth import make_problem
+
+    n, d, k = 30_000, 3_000, 12
+    X, y = make_problem(n, d, 50, seed=4)
+    if loss != "squared":
+        y = np.where(y > np.median(y), 1.0, -1.0)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    degree = 2 if model == "fm" else -1
+    reg = "squaredl12" if model == "fm" else "l1"
+    P0 = 0.01 * np.random.RandomState(0).randn(1, k, d)
+    lams = np.ones(k) if model == "fm" else np.where(np.arange(k) % 2 == 0, 1.0, -1.0)
+    ic = np.arange(k, dtype=np.int32)
+    out = {}
+    for lds in (1, 0):
+        eng = HipEngine(0, "f32")
+        eng.set_option("prb_lds", lds)
+        eng.set_data(Xc, y)
+        eng.set_params(P0, np.zeros(d), lams)
+        eng.configure("pcd", loss, reg, degree)
+        eng.init_pred(degree, False, False)
+        order = eng.set_schedule("colored", np.arange(d, dtype=np.int32))
+        viol = [eng.pcd_epoch(0, degree, 10.0, 1e-3, 1.0, ic) for _ in range(2)]
+        assert eng.get_option("prb_lds_active") == (want_mode if lds else 0)
+        out[lds] = (np.array(viol), eng.loss_sum(), eng.get_params()[0], eng.get_y_pred(), order)
+        eng.close()
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=2e-6)
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=2e-6)
+    np.testing.assert_allclose(out[1][2], out[0][2], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out[1][3], out[0][3], rtol=0, atol=2e-5)
+    # and against the oracle in the reported order
+    if model == "fm":
+        fm = oracle.OracleFM(degree=2, loss=loss, n_components=k, solver="pcd", regularizer=reg,
+                             beta=10.0, gamma=1e-3, tol=0, max_iter=2, fit_linear=False,
+                             feature_order=out[1][4])
+        fm.fit(X, y, P_init=P0, lams_init=lams)
+        np.testing.assert_allclose(out[1][0], [h[0] for h in fm.history], rtol=1e-5)
+        np.testing.assert_allclose(out[1][2], fm.P_, rtol=0, atol=1e-4)

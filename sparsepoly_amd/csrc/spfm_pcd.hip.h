@@ -108,10 +108,18 @@ __global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __
     const double* ps = P + (size_t)ctl->s * d;
     const int tid = threadIdx.x;
     if (reg == REG_SQL12) {
+        // 8 independent loads in flight per thread (same summation order as a plain loop:
+        // the padding adds exact zeros)
         double a = 0, b = 0;
-        for (int j = tid; j < d; j += kBlock) {
-            const double v = fabs(ps[j]);
-            a += v;
+        for (int j0 = tid; j0 < d; j0 += kBlock * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * kBlock;
+                v[u] = (j < d) ? fabs(ps[j]) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
         }
         block_sum2(a, b, sh);
         if (tid == 0) cache[0] = a;
@@ -120,7 +128,16 @@ __global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __
     if (reg != REG_OMEGATI) return;
     if constexpr (M == 0) {  // omegati.py:75-80: _cache_all_subsets = prod_j (1 + |p_sj|)
         double pr = 1.0;
-        for (int j = tid; j < d; j += kBlock) pr *= 1.0 + fabs(ps[j]);
+        for (int j0 = tid; j0 < d; j0 += kBlock * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * kBlock;
+                v[u] = (j < d) ? fabs(ps[j]) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pr *= 1.0 + v[u];
+        }
         sh[tid] = pr;
         __syncthreads();
         for (int half = kBlock / 2; half >= 1; half >>= 1) {
@@ -134,10 +151,18 @@ __global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __
     c[0] = 1.0;
 #pragma unroll
     for (int t = 1; t <= M; ++t) c[t] = 0.0;
-    for (int j = tid; j < d; j += kBlock) {
-        const double v = fabs(ps[j]);
+    for (int j0 = tid; j0 < d; j0 += kBlock * 8) {
+        double v[8];
 #pragma unroll
-        for (int t = M; t >= 1; --t) c[t] += c[t - 1] * v;
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * kBlock;
+            v[u] = (j < d) ? fabs(ps[j]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int t = M; t >= 1; --t) c[t] += c[t - 1] * v[u];
+        }
     }
 #pragma unroll
     for (int t = 0; t <= M; ++t) sh[tid * (M + 1) + t] = c[t];

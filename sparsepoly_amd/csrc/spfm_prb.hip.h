@@ -263,12 +263,19 @@ __device__ __forceinline__ void prb_load_sp(const PrbArgs& a, int g, int b, int 
     e0 = 0;
     e1 = 0;
     lmask = 0ull;
+    const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
+    // Two separate paths on purpose: the mask is consumed only inside the has_long branch, so
+    // the common (no long slot anywhere) path carries no wait for it.  Merged, the compiler
+    // put an s_waitcnt vmcnt(0) at the join, which -- vmcnt retiring in order -- also
+    // drained the granule stores published just before (0.5 us per step).
     if (a.has_long) {
         const uint32_t* lm = a.lmask + ((size_t)g * a.nb + b) * 2;
         lmask = ((unsigned long long)lm[1] << 32) | (unsigned long long)lm[0];
-    }
-    if (slot < ncols && !((lmask >> slot) & 1ull)) {  // long slots: no per-lane entries
-        const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
+        if (slot < ncols && !((lmask >> slot) & 1ull)) {  // long slots: no per-lane entries
+            e0 = spb[slot];
+            e1 = spb[slot + 1];
+        }
+    } else if (slot < ncols) {
         e0 = spb[slot];
         e1 = spb[slot + 1];
     }
@@ -395,6 +402,13 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     for (int b = 0; b < a.nb; ++b) {
         const int ncols = c1 - c0;
         const int c4 = (b + 4 <= a.nb) ? a.bptr[b + 4] : c3;  // used two steps from now
+        // Drain vmcnt here, where it is free (this step's entries are needed at once and
+        // everything else was issued a step ago).  It is a real S_WAITCNT (not inline asm), so
+        // the compiler's wait-count bookkeeping knows that nothing is pending from the previous
+        // iteration; without it, loop-carried destinations (slot bounds, prefetched entries)
+        // made it insert vmcnt(0) right behind the granule stores further down, i.e. wait
+        // for their acknowledgement (0.5 us per step).  vmcnt(0), expcnt/lgkmcnt untouched.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         // ---- phase 1 (workers): gather the rows of the prefetched entries, partial sums
         // (pcd.py:52-59); A / yhat values stay in registers for phase 3
         constexpr int AS = Kind<M>::AS;

@@ -926,9 +926,12 @@ struct spfm_engine {
         hipLaunchKernelGGL(begin_pass_kernel, dim3(1), dim3(64), 0, stream, c,
                            comp_order.as<int32_t>(), lams.as<double>());
         const size_t a_stride = (size_t)n * Kind<M>::AS;
-        if (reg != SPFM_REG_L1)
-            hipLaunchKernelGGL((pcd_compute_cache_kernel<M>), dim3(1), dim3(kBlock), 0, stream, c,
-                               Po, d, reg, cbuf[0]);
+        if (reg != SPFM_REG_L1) {
+            hipLaunchKernelGGL((pcd_compute_cache_kernel<M>), dim3(kCacheBlocks), dim3(kBlock), 0,
+                               stream, c, Po, d, reg, partial.as<double>());
+            hipLaunchKernelGGL((pcd_cache_combine_kernel<M>), dim3(1), dim3(64), 0, stream, reg,
+                               kCacheBlocks, partial.as<double>(), cbuf[0]);
+        }
         const int nb = n_batches();
         int par = 0;  // batch b reads cbuf[par], writes cbuf[par ^ 1]
         for (int b = 0; b < nb; ++b) {
@@ -1072,9 +1075,12 @@ struct spfm_engine {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrbLds));
         hipLaunchKernelGGL(begin_pass_kernel, dim3(1), dim3(64), 0, stream, c,
                            comp_order.as<int32_t>(), lams.as<double>());
-        if (reg != SPFM_REG_L1)
-            hipLaunchKernelGGL((pcd_compute_cache_kernel<M>), dim3(1), dim3(kBlock), 0, stream, c,
-                               Po, d, reg, cb);
+        if (reg != SPFM_REG_L1) {
+            hipLaunchKernelGGL((pcd_compute_cache_kernel<M>), dim3(kCacheBlocks), dim3(kBlock), 0,
+                               stream, c, Po, d, reg, partial.as<double>());
+            hipLaunchKernelGGL((pcd_cache_combine_kernel<M>), dim3(1), dim3(64), 0, stream, reg,
+                               kCacheBlocks, partial.as<double>(), cb);
+        }
         hipLaunchKernelGGL(snapshot_row_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, c, Po, d,
                            d_desc.as<ColDesc>(), prow_old.as<double>());
         HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));  // tag 0 = "not yet"

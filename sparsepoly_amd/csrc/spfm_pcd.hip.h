@@ -96,16 +96,23 @@ __global__ __launch_bounds__(kBlock) void pcd_precompute_all_kernel(
 
 // regularizer.compute_cache_pcd(P, degree, s): squaredl12.py:42-45 (|P[s]| and
 // its sum), omegati.py:62-74 (|P[s]| and the elementary symmetric polynomials
-// e_0..e_M of |P[s,:]|).  One workgroup; e_t by per-thread DP over a strided
-// subset, then a tree of truncated polynomial products (e_t is symmetric, so any
-// partition of the features gives the same value up to rounding).
+// e_0..e_M of |P[s,:]|).  Workgroup b reduces its slice of the features (one workgroup
+// alone is latency-starved: 150 us for 100k features) into part[b][0..M]: e_t by
+// per-thread DP over a strided subset, then a tree of truncated polynomial products (e_t
+// is symmetric, so any partition of the features gives the same value up to rounding);
+// pcd_cache_combine_kernel folds the partials in fixed order.
+constexpr int kCacheBlocks = 64;
 template <int M>
 __global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __restrict__ ctl,
                                                                     const double* __restrict__ P,
-                                                                    int d, int reg,
-                                                                    double* __restrict__ cache) {
+                                                                    int d_all, int reg,
+                                                                    double* __restrict__ part) {
     __shared__ double sh[kBlock * (M + 1)];
-    const double* ps = P + (size_t)ctl->s * d;
+    const int per = (d_all + gridDim.x - 1) / gridDim.x;
+    const int lo = min(per * (int)blockIdx.x, d_all);
+    const int d = min(per, d_all - lo);
+    const double* ps = P + (size_t)ctl->s * d_all + lo;
+    double* cache = part + (size_t)blockIdx.x * (M + 1);
     const int tid = threadIdx.x;
     if (reg == REG_SQL12) {
         // 8 independent loads in flight per thread (same summation order as a plain loop:
@@ -186,6 +193,43 @@ __global__ __launch_bounds__(kBlock) void pcd_compute_cache_kernel(const Ctl* __
     if (tid == 0) {
 #pragma unroll
         for (int t = 0; t <= M; ++t) cache[t] = sh[t];
+    }
+}
+
+// cache <- combination of the per-workgroup partials, in workgroup order (one thread)
+template <int M>
+__global__ void pcd_cache_combine_kernel(int reg, int nblk, const double* __restrict__ part,
+                                         double* __restrict__ cache) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (reg == REG_SQL12) {
+        double a = 0.0;
+        for (int b = 0; b < nblk; ++b) a += part[(size_t)b * (M + 1)];
+        cache[0] = a;
+        return;
+    }
+    if (reg != REG_OMEGATI) return;
+    if constexpr (M == 0) {
+        double pr = 1.0;
+        for (int b = 0; b < nblk; ++b) pr *= part[b];
+        cache[0] = pr;
+    } else {
+        double c[M + 1];
+#pragma unroll
+        for (int t = 0; t <= M; ++t) c[t] = part[t];
+        for (int b = 1; b < nblk; ++b) {
+            double o[M + 1];
+#pragma unroll
+            for (int t = 0; t <= M; ++t) {
+                double acc = 0.0;
+#pragma unroll
+                for (int u = 0; u <= t; ++u) acc += c[u] * part[(size_t)b * (M + 1) + (t - u)];
+                o[t] = acc;
+            }
+#pragma unroll
+            for (int t = 0; t <= M; ++t) c[t] = o[t];
+        }
+#pragma unroll
+        for (int t = 0; t <= M; ++t) cache[t] = c[t];
     }
 }
 

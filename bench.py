@@ -190,6 +190,9 @@ def main():
                 "alg_bytes_per_launch": round(bytes_per_launch, 1),
                 "launches_timed": int(g_launch)}
         if persistent:
+            # 0 = row state in global memory, 1 / 2 = row block resident in LDS:
+            # then `traffic` is below the algorithmic bytes, which charge every gather / scatter
+            roof["row_block_in_lds"] = int(eng.get_option("prb_lds_active"))
             roof["dependent_steps_per_launch"] = n_batches
             roof["us_per_dependent_step_in_kernel"] = round(avg_us / n_batches, 3)
         else:

@@ -25,6 +25,10 @@ Additional keywords (after the reference's, so positional use is unchanged):
                (reductions, prox and parameters stay float64); 'f64' stores them
                in float64.
 ``device``     HIP device ordinal (default: ``LOCAL_RANK`` or 0).
+``warm_start=True`` additionally keeps the device session of the last fit (data, schedule,
+row-block stream: SURVEY.md 8f N4): the next ``fit`` on the same ``X, y`` re-uploads only
+the parameters, which is what a regularization path needs.  ``release_device()`` frees it.
+
 ``distributed`` shard the rows over the ranks of the initialised
                ``torch.distributed`` process group (one process per GPU); the
                per-step column partial sums are all-reduced with RCCL.
@@ -48,6 +52,30 @@ from .regularizer import REGULARIZATION
 
 def _default_device():
     return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def _fingerprint(Xc, y):
+    """Cheap content hash of the training set (structure, values, targets): decides
+    whether a warm-started fit may reuse the device-resident data of the previous one."""
+    try:
+        import xxhash
+
+        h = xxhash.xxh3_64()
+        upd, fin = h.update, h.hexdigest
+    except Exception:  # pragma: no cover - xxhash is optional
+        import zlib
+
+        state = [1]
+
+        def upd(b):
+            state[0] = zlib.adler32(b, state[0])
+
+        def fin():
+            return "%08x" % state[0]
+
+    for a in (Xc.indptr, Xc.indices, Xc.data, np.ascontiguousarray(y)):
+        upd(memoryview(np.ascontiguousarray(a)).cast("B"))
+    return (Xc.shape, int(Xc.nnz), fin())
 
 
 class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
@@ -142,6 +170,17 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
     def _set_schedule(self, engine, indices_feature, conflict_csc):
         """Fix the visiting order of the next epochs (the reference passes
         ``indices_feature`` to every epoch call: :198-205, :289-295)."""
+        # a reused device session that already holds this very schedule (natural order, same
+        # mode, or the same Schedule object) keeps it -- and its row-block stream
+        tag = None
+        if not self.shuffle:
+            tag = ("obj", id(self.schedule)) if isinstance(self.schedule, Schedule) else \
+                ("mode", self.schedule)
+            if getattr(engine, "_sched_tag", None) == tag and engine.order is not None:
+                self.schedule_ = self.schedule if isinstance(self.schedule, Schedule) else None
+                self.feature_order_ = engine.order
+                return engine.order
+        engine._sched_tag = tag
         if isinstance(self.schedule, Schedule):
             order = engine.install_schedule(self.schedule, conflict_csc)
             self.schedule_ = self.schedule
@@ -331,9 +370,28 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
 
         Xc = canonical_csc(X)
         conflict_csc = None
-        engine = self._new_engine()
+        # warm_start keeps the device session: same data => no re-upload,
+        # no re-colouring, no new row-block stream
+        key = None
+        engine = None
+        if self.warm_start and not self.distributed:
+            key = (_fingerprint(Xc, y), self.precision,
+                   _default_device() if self.device is None else self.device)
+            cached = getattr(self, "_device_session", None)
+            self._device_session = None
+            if cached is not None:
+                if cached[0] == key:
+                    engine = cached[1]
+                else:
+                    cached[1].close()
+        fresh = engine is None
+        if fresh:
+            engine = self._new_engine()
+        keep = False
         try:
-            if self.distributed:
+            if not fresh:
+                pass
+            elif self.distributed:
                 from . import distributed as _dist
 
                 lo, hi = _dist.row_block(n_samples)
@@ -353,6 +411,7 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 nnz = X.nnz if sp.issparse(X) else n_samples * n_features
                 converged, self.n_iter_ = self._fit_psgd(engine, n_samples, n_features,
                                                          nnz, rng)
+                keep = key is not None
                 return self._finish_fit(converged)
             # y_pred = self._get_output(X) (:408)
             engine.init_pred(self.degree, self.fit_linear, self._add_lower_deg2())
@@ -365,9 +424,25 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
             self.n_steps_per_sweep_ = engine.n_batches
             if self.schedule_ is None:
                 self.schedule_ = engine.get_schedule(self.schedule)
+            keep = key is not None
         finally:
-            engine.close()
+            if keep:
+                self._device_session = (key, engine)
+            else:
+                engine.close()
         return self._finish_fit(converged)
+
+    def release_device(self):
+        """Free the device session kept by ``warm_start=True`` (data, schedule, stream)."""
+        cached = getattr(self, "_device_session", None)
+        self._device_session = None
+        if cached is not None:
+            cached[1].close()
+
+    def __getstate__(self):
+        state = dict(super().__getstate__())
+        state.pop("_device_session", None)  # a device handle is not picklable
+        return state
 
     def _finish_fit(self, converged):
         if not converged:

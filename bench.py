@@ -63,6 +63,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: SPFM_DEVICE=0 SPFM_COMM=shm runs all ranks on device 0 with
+    # the engine's host shared-memory exchange instead of RCCL (see spfm_comm_init_shm)
+    local_rank = int(os.environ.get("SPFM_DEVICE", local_rank))
     import torch
 
     dist = None
@@ -98,9 +101,7 @@ def main():
     if world > 1:
         lo, hi = spdist.row_block(n, rank, world)
         Xl = canonical_csc(X[lo:hi])
-        uid = eng.comm_unique_id() if rank == 0 else None
-        uid = spdist.broadcast_bytes(uid, 0)
-        eng.comm_init(uid, world, rank)
+        spdist.init_engine_comm(eng)  # RCCL unique id shipped over the gloo group
         eng.set_data(Xl, y[lo:hi])
         conflict = Xc
     else:
@@ -253,7 +254,9 @@ def main():
                                    "%dx%d CSR nnz=%d (~50/row)" % (n, d, nnz),
                        "schedule": args.schedule, "dependent_steps_per_sweep": n_batches,
                        "alpha": ALPHA, "beta": BETA, "gamma": GAMMA,
-                       "parallelism": "rows sharded x%d, per-step RCCL all-reduce" % world
+                       "parallelism": ("rows sharded x%d, per-step %s all-reduce"
+                                       % (world, "host-shm (rehearsal)"
+                                          if os.environ.get("SPFM_COMM") == "shm" else "RCCL"))
                        if world > 1 else "single GPU"},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -190,6 +190,13 @@ int spfm_psgd_epoch(spfm_handle h, int degree, double alpha, double beta, double
  * 128-byte RCCL unique id created on rank 0 and shipped by the caller. */
 int spfm_comm_unique_id(char* id128);
 int spfm_comm_init(spfm_handle h, const char* id128, int n_ranks, int rank);
+/* The same sharded protocol with the all-reduce carried through a POSIX shared-memory
+ * segment on the host (name as for shm_open, e.g. "/spfm_test_123"; created zero-filled by
+ * whichever rank arrives first, the caller unlinks it).  For ranks that share ONE GPU, where
+ * RCCL refuses to form a communicator: lets the multi-GPU code path (row shards, per-step
+ * all-reduce, replicated chain) be run and checked on a single-GPU machine.  A test and
+ * bring-up facility, orders of magnitude slower than RCCL over xGMI. */
+int spfm_comm_init_shm(spfm_handle h, const char* shm_name, int n_ranks, int rank);
 
 /* -- instrumentation ----------------------------------------------------------
  * Device time (ms, HIP events on the handle's stream) and launch count of the

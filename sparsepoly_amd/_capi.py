@@ -27,7 +27,7 @@ SYMBOLS = [
     "spfm_loss_sum", "spfm_predict_csr", "spfm_set_schedule", "spfm_set_schedule_raw",
     "spfm_get_schedule", "spfm_schedule_build",
     "spfm_cd_linear_epoch",
-    "spfm_pcd_epoch", "spfm_pbcd_epoch", "spfm_psgd_epoch", "spfm_comm_unique_id", "spfm_comm_init",
+    "spfm_pcd_epoch", "spfm_pbcd_epoch", "spfm_psgd_epoch", "spfm_comm_unique_id", "spfm_comm_init", "spfm_comm_init_shm",
     "spfm_profile_enable", "spfm_profile_get", "spfm_profile_reset", "spfm_set_use_graph",
     "spfm_set_option", "spfm_get_option", "spfm_debug_prb_stamps",
 ]
@@ -80,6 +80,7 @@ def load():
                                   _dp]
     L.spfm_comm_unique_id.argtypes = [C.c_char_p]
     L.spfm_comm_init.argtypes = [_h, C.c_char_p, C.c_int, C.c_int]
+    L.spfm_comm_init_shm.argtypes = [_h, C.c_char_p, C.c_int, C.c_int]
     L.spfm_profile_enable.argtypes = [_h, C.c_int]
     L.spfm_profile_get.argtypes = [_h, C.c_int, _dp, _lp, _lp]
     L.spfm_profile_reset.argtypes = [_h]

@@ -1,8 +1,13 @@
 // spfm_engine.hip -- host engine + C ABI (include/spfm.h) of the gfx950 sparse-FM
 // proximal coordinate-descent core.  See DESIGN.md for the execution model.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <chrono>
 #include <hip/hip_runtime.h>
 
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -196,6 +201,23 @@ struct spfm_engine {
 
     // comm
     ncclComm_t comm = nullptr;
+    // Host shared-memory communicator (spfm_comm_init_shm): the same sharded protocol with
+    // the all-reduce done through a POSIX shm segment, for ranks that share ONE GPU (RCCL
+    // refuses two ranks per device) -- exercises the multi-GPU path on a single-GPU box.
+    struct ShmComm {
+        static constexpr size_t kMaxDoubles = 1 << 16;
+        struct Hdr {
+            volatile int arrive;
+            volatile int sense;
+            int pad[14];
+        };
+        Hdr* hdr = nullptr;
+        double* slots = nullptr;  // [n_ranks][kMaxDoubles]
+        size_t bytes = 0;
+        int local_sense = 0;
+    } shm;
+    std::vector<double> shm_host;
+    bool dist() const { return comm != nullptr || shm.hdr != nullptr; }
     int n_ranks = 1, rank = 0;
 
     // profile
@@ -207,6 +229,7 @@ struct spfm_engine {
         for (auto& ps : prof)
             for (auto e : ps.ev) (void)hipEventDestroy(e);
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+        if (shm.hdr) munmap((void*)shm.hdr, shm.bytes);
         if (h_scalar) (void)hipHostFree(h_scalar);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -283,7 +306,49 @@ struct spfm_engine {
     }
 
     // ------------------------------------------------------------------- comm
+    // sense-reversing barrier over the shm header; bounded (30 s) so that a dead peer
+    // becomes an error instead of a hang
+    int shm_barrier() {
+        shm.local_sense ^= 1;
+        if (__atomic_add_fetch(&shm.hdr->arrive, 1, __ATOMIC_ACQ_REL) == n_ranks) {
+            __atomic_store_n(&shm.hdr->arrive, 0, __ATOMIC_RELAXED);
+            __atomic_store_n(&shm.hdr->sense, shm.local_sense, __ATOMIC_RELEASE);
+            return SPFM_OK;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        while (__atomic_load_n(&shm.hdr->sense, __ATOMIC_ACQUIRE) != shm.local_sense) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+                FAIL(SPFM_ERR_RUNTIME, "shm communicator: peer did not arrive within 30 s");
+        }
+        return SPFM_OK;
+    }
+
+    int allreduce_shm(double* buf, size_t count) {
+        if (count > ShmComm::kMaxDoubles)
+            FAIL(SPFM_ERR_UNSUPPORTED, "shm communicator: message too large");
+        shm_host.resize(count);
+        HIPC(hipMemcpyAsync(shm_host.data(), buf, sizeof(double) * count, hipMemcpyDeviceToHost,
+                            stream));
+        HIPC(hipStreamSynchronize(stream));
+        std::memcpy(shm.slots + (size_t)rank * ShmComm::kMaxDoubles, shm_host.data(),
+                    sizeof(double) * count);
+        int rc = shm_barrier();
+        if (rc) return rc;
+        for (size_t i = 0; i < count; ++i) {  // fixed rank order: identical on every rank
+            double a = 0.0;
+            for (int r = 0; r < n_ranks; ++r) a += shm.slots[(size_t)r * ShmComm::kMaxDoubles + i];
+            shm_host[i] = a;
+        }
+        rc = shm_barrier();  // nobody overwrites a slot before everyone has read it
+        if (rc) return rc;
+        HIPC(hipMemcpyAsync(buf, shm_host.data(), sizeof(double) * count, hipMemcpyHostToDevice,
+                            stream));
+        HIPC(hipStreamSynchronize(stream));
+        return SPFM_OK;
+    }
+
     int allreduce(double* buf, size_t count) {
+        if (shm.hdr) return allreduce_shm(buf, count);
         if (!comm) return SPFM_OK;
         int rc = g_rccl.AllReduce(buf, buf, count, ncclFloat64_, ncclSum_, comm, stream);
         if (rc != 0) {
@@ -295,7 +360,7 @@ struct spfm_engine {
     }
 
     int ensure_col_norm() {
-        if (col_norm_reduced || !comm) return SPFM_OK;
+        if (col_norm_reduced || !dist()) return SPFM_OK;
         int rc = allreduce(col_norm.as<double>(), (size_t)d);
         if (rc) return rc;
         col_norm_reduced = true;
@@ -332,7 +397,7 @@ struct spfm_engine {
     // graphs are enabled, captured once under `key` and replayed.
     template <typename F>
     int run_cached(const std::string& key, F&& body) {
-        const bool graph_ok = use_graph && !prof_on && !comm;
+        const bool graph_ok = use_graph && !prof_on && !dist();
         if (!graph_ok) return body();
         auto it = graphs.find(key);
         if (it == graphs.end()) {
@@ -588,7 +653,7 @@ struct spfm_engine {
         const int64_t rows = cf_indptr ? cf_rows : n;
         if (cf_indptr && (!cf_indices || cf_rows <= 0))
             FAIL(SPFM_ERR_INVALID, "set_schedule: bad conflict structure");
-        const int max_batch = (persistent && !comm) ? std::min(max_batch_opt, 64) : max_batch_opt;
+        const int max_batch = (persistent && !dist()) ? std::min(max_batch_opt, 64) : max_batch_opt;
         if (mode == SPFM_SCHED_EXACT) {
             order.assign(indices_feature, indices_feature + d);
             schedule_exact(rows, d, cp, ci, indices_feature, max_batch, batch_ptr);
@@ -847,7 +912,7 @@ struct spfm_engine {
             if (nc == 0) continue;
             const int32_t* cols = d_order.as<int32_t>() + c0;
             prof_begin(4, prof_on ? batch_nnz(b) : 0);
-            if (!comm) {
+            if (!dist()) {
                 hipLaunchKernelGGL((lin_fused_kernel<T>), dim3(nc), dim3(kBlock), 0, stream,
                                    d_desc.as<ColDesc>() + c0, cidx.as<int32_t>(), cval.as<T>(),
                                    yy.as<T>(), loss, w.as<double>(), col_norm.as<double>(), alpha,
@@ -974,7 +1039,7 @@ struct spfm_engine {
 
     // ---------------------------------------------------- persistent row-block pass
     bool prb_usable() const {
-        return persistent && !comm && max_batch_cols <= 64 && nnz < ((int64_t)1 << 31) && n > 0;
+        return persistent && !dist() && max_batch_cols <= 64 && nnz < ((int64_t)1 << 31) && n > 0;
     }
 
     template <typename T>
@@ -1468,7 +1533,7 @@ struct spfm_engine {
         if (!have_data || !have_params || !configured)
             FAIL(SPFM_ERR_INVALID, "epoch: data, parameters and configuration are required");
         if (solver != SPFM_SOLVER_PSGD) FAIL(SPFM_ERR_INVALID, "engine is not configured for psgd");
-        if (comm) FAIL(SPFM_ERR_UNSUPPORTED, "psgd: multi-GPU is not supported");
+        if (dist()) FAIL(SPFM_ERR_UNSUPPORTED, "psgd: multi-GPU is not supported");
         if (degree != top_degree) FAIL(SPFM_ERR_INVALID, "psgd: degree differs from configure()");
         if (!indices_samples || !it || n_samples != n)
             FAIL(SPFM_ERR_INVALID, "psgd: indices_samples must list every sample once");
@@ -1753,6 +1818,43 @@ int spfm_comm_init(spfm_handle h, const char* id128, int n_ranks, int rank) {
         h->comm = nullptr;
         return SPFM_ERR_RUNTIME;
     }
+    h->n_ranks = n_ranks;
+    h->rank = rank;
+    h->col_norm_reduced = false;
+    h->clear_graphs();
+    return SPFM_OK;
+}
+
+int spfm_comm_init_shm(spfm_handle h, const char* shm_name, int n_ranks, int rank) {
+    GUARD(h);
+    if (!shm_name || n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks)
+        return SPFM_ERR_INVALID;
+    if (h->comm || h->shm.hdr) {
+        h->err = "a communicator is already attached";
+        return SPFM_ERR_INVALID;
+    }
+    using Shm = spfm_engine::ShmComm;
+    const size_t bytes = sizeof(Shm::Hdr) + sizeof(double) * Shm::kMaxDoubles * (size_t)n_ranks;
+    int fd = shm_open(shm_name, O_RDWR | O_CREAT, 0600);
+    if (fd < 0) {
+        h->err = std::string("shm_open failed: ") + std::strerror(errno);
+        return SPFM_ERR_RUNTIME;
+    }
+    if (ftruncate(fd, (off_t)bytes) != 0) {  // new segments are zero-filled
+        h->err = std::string("ftruncate failed: ") + std::strerror(errno);
+        close(fd);
+        return SPFM_ERR_RUNTIME;
+    }
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+        h->err = std::string("mmap failed: ") + std::strerror(errno);
+        return SPFM_ERR_RUNTIME;
+    }
+    h->shm.hdr = reinterpret_cast<Shm::Hdr*>(p);
+    h->shm.slots = reinterpret_cast<double*>(reinterpret_cast<char*>(p) + sizeof(Shm::Hdr));
+    h->shm.bytes = bytes;
+    h->shm.local_sense = 0;
     h->n_ranks = n_ranks;
     h->rank = rank;
     h->col_norm_reduced = false;

@@ -48,8 +48,23 @@ def broadcast_bytes(payload, src=0):
 
 
 def init_engine_comm(engine):
-    """Create the engine's RCCL communicator spanning the torch process group."""
+    """Create the engine's communicator spanning the torch process group: RCCL (one GPU per
+    rank), or -- ``SPFM_COMM=shm``, ranks sharing one GPU on a test box, where RCCL cannot
+    form a communicator -- the engine's host shared-memory exchange."""
+    import os
+
     rank, world = rank_world()
+    if os.environ.get("SPFM_COMM", "rccl") == "shm":
+        name = broadcast_bytes(("/spfm_%d_%s" % (os.getpid(), os.environ.get("MASTER_PORT", "0")))
+                               .encode() if rank == 0 else None, src=0).decode()
+        engine.comm_init_shm(name, world, rank)
+        _dist().barrier()  # every rank has mapped the segment
+        if rank == 0:
+            try:
+                os.unlink("/dev/shm" + name)
+            except OSError:
+                pass
+        return rank, world
     uid = engine.comm_unique_id() if rank == 0 else None
     uid = broadcast_bytes(uid, src=0)
     engine.comm_init(uid, world, rank)

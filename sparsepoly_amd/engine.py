@@ -257,6 +257,10 @@ class HipEngine(object):
         assert len(uid) == 128
         self._check(self._lib.spfm_comm_init(self._h, uid, int(n_ranks), int(rank)))
 
+    def comm_init_shm(self, name, n_ranks, rank):
+        """Host shared-memory communicator for ranks sharing one GPU (test / bring-up)."""
+        self._check(self._lib.spfm_comm_init_shm(self._h, name.encode(), int(n_ranks), int(rank)))
+
     # -------------------------------------------------------- instrumentation
     def profile_enable(self, on=True):
         self._check(self._lib.spfm_profile_enable(self._h, int(bool(on))))

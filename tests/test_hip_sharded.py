@@ -1,0 +1,198 @@
+"""The multi-GPU protocol (contiguous row shards, per-step all-reduce of
+the column partial sums, replicated chain) executed by the real engine: two processes share
+the one GPU of the test box and exchange through the host shared-memory communicator
+(`spfm_comm_init_shm`; RCCL refuses two ranks on one device).  The sharded result must equal
+the single-process multi-kernel engine and the oracle, and be bit-identical on both ranks.
+Needs a real MI355X: ``pytest -m gpu``."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {
+    # tag: solver, regularizer, degree, k, loss, beta, gamma
+    "pcd_sql12": ("pcd", "squaredl12", 2, 6, "squared", 10.0, 1e-3),
+    "pcd_ti3": ("pcd", "omegati", 3, 4, "logistic", 10.0, 1e-4),
+    "pbcd_cs": ("pbcd", "omegacs", 2, 6, "squared", 1.0, 1e-2),
+}
+
+
+def _problem(loss):
+    sys.path.insert(0, ROOT)
+    from sparsepoly_amd.synth import make_problem
+
+    X, y = make_problem(6000, 500, 20, seed=3)
+    if loss != "squared":
+        y = np.where(y > np.median(y), 1.0, -1.0)
+    return sp.csr_matrix(X), y
+
+
+def _run(case, world, rank, shm_name, precision):
+    """One rank of the sharded run (world == 1: the whole problem, no communicator)."""
+    sys.path.insert(0, ROOT)
+    from sparsepoly_amd.engine import HipEngine, canonical_csc
+
+    solver, reg, degree, k, loss, beta, gamma = CASES[case]
+    X, y = _problem(loss)
+    n, d = X.shape
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    Xg = canonical_csc(X)
+    eng = HipEngine(0, precision)
+    eng.set_option("persistent", 0)       # the multi-kernel engine in both runs
+    if world > 1:
+        eng.comm_init_shm(shm_name, world, rank)
+    eng.set_data(canonical_csc(X[lo:hi]), y[lo:hi])
+    P0 = 0.01 * np.random.RandomState(0).randn(degree - 1, k, d)
+    eng.set_params(P0, np.zeros(d), np.ones(k))
+    eng.configure(solver, loss, reg, degree)
+    eng.init_pred(degree, True, degree == 3)
+    order = eng.set_schedule("colored", np.arange(d, dtype=np.int32), Xg)  # GLOBAL conflicts
+    ic = np.arange(k, dtype=np.int32)
+    viol, losses = [], []
+    for _ in range(2):
+        v = eng.cd_linear_epoch(0.1)
+        for deg in list(range(2, degree)) + [degree]:
+            o = degree - deg if deg != degree else 0
+            v += (eng.pcd_epoch(o, deg, beta, gamma, 1.0, ic) if solver == "pcd"
+                  else eng.pbcd_epoch(o, deg, beta, gamma, 1.0))
+        viol.append(v)
+        losses.append(eng.loss_sum())       # all-reduced over the shards
+    P, w = eng.get_params()
+    yp = eng.get_y_pred()
+    eng.close()
+    return dict(P=P, w=w, viol=np.array(viol), loss=np.array(losses), y_pred=yp, order=order,
+                rows=(lo, hi))
+
+
+def _worker(case, world, rank, shm_name, precision, q):
+    try:
+        q.put((rank, _run(case, world, rank, shm_name, precision)))
+    except Exception as e:  # surface the failure in the parent
+        q.put((rank, repr(e)))
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_two_row_shards_on_one_gpu(oracle, case):
+    solver, reg, degree, k, loss, beta, gamma = CASES[case]
+    shm_name = "/spfm_test_%d_%s" % (os.getpid(), case)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(case, 2, r, shm_name, "f64", q)) for r in (0, 1)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in procs:
+            rank, res = q.get(timeout=240)
+            got[rank] = res
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+        try:
+            os.unlink("/dev/shm" + shm_name)
+        except OSError:
+            pass
+    for r in (0, 1):
+        assert isinstance(got[r], dict), got[r]
+    a, b = got[0], got[1]
+    # replicated state is bit-identical on both ranks
+    assert np.array_equal(a["P"], b["P"]) and np.array_equal(a["w"], b["w"])
+    assert np.array_equal(a["viol"], b["viol"]) and np.array_equal(a["loss"], b["loss"])
+    assert np.array_equal(a["order"], b["order"])
+    # equals the unsharded engine (summation order of the partial sums differs: 1e-10)
+    one = _run(case, 1, 0, None, "f64")
+    assert np.array_equal(one["order"], a["order"])
+    np.testing.assert_allclose(a["P"], one["P"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(a["w"], one["w"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(a["viol"], one["viol"], rtol=1e-10)
+    np.testing.assert_allclose(a["loss"], one["loss"], rtol=1e-10)
+    yp = np.concatenate([a["y_pred"], b["y_pred"]])
+    np.testing.assert_allclose(yp, one["y_pred"], rtol=0, atol=1e-9)
+    assert a["rows"] == (0, 3000) and b["rows"] == (3000, 6000)
+    # ... and the oracle replaying the coloured order
+    X, y = _problem(loss)
+    fm = oracle.OracleFM(degree=degree, loss=loss, n_components=k, solver=solver, regularizer=reg,
+                         alpha=0.1, beta=beta, gamma=gamma, tol=0, max_iter=2,
+                         feature_order=a["order"])
+    fm.fit(X, y, P_init=0.01 * np.random.RandomState(0).randn(degree - 1, k, X.shape[1]),
+           lams_init=np.ones(k))
+    np.testing.assert_allclose(a["P"], fm.P_, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(a["viol"], [h[0] for h in fm.history], rtol=1e-9)
+
+
+def _est_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import warnings
+
+        import torch.distributed as dist
+
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPFM_COMM="shm")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from sparsepoly_amd import SparseFactorizationMachineClassifier
+
+        X, y = _problem("logistic")
+        est = SparseFactorizationMachineClassifier(
+            degree=2, loss="logistic", n_components=5, solver="pcd", regularizer="squaredl12",
+            beta=10.0, gamma=1e-3, max_iter=2, tol=0, random_state=0, schedule="colored",
+            precision="f64", device=0, distributed=True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            est.fit(X, y)
+        q.put((rank, dict(P=est.P_, w=est.w_, n_iter=est.n_iter_)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, repr(e)))
+
+
+def test_estimator_distributed_flag_two_ranks_one_gpu():
+    """The estimator's distributed=True path (torch.distributed for rank/world and the
+    bootstrap message, engine communicator for the data path) with two gloo ranks."""
+    import socket
+    import warnings
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_est_worker, args=(r, 2, port, q)) for r in (0, 1)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in procs:
+            rank, res = q.get(timeout=240)
+            got[rank] = res
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for r in (0, 1):
+        assert isinstance(got[r], dict), got[r]
+    assert np.array_equal(got[0]["P"], got[1]["P"]) and np.array_equal(got[0]["w"], got[1]["w"])
+    sys.path.insert(0, ROOT)
+    from sparsepoly_amd import SparseFactorizationMachineClassifier
+
+    X, y = _problem("logistic")
+    one = SparseFactorizationMachineClassifier(
+        degree=2, loss="logistic", n_components=5, solver="pcd", regularizer="squaredl12",
+        beta=10.0, gamma=1e-3, max_iter=2, tol=0, random_state=0, schedule="colored",
+        precision="f64", device=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        one.fit(X, y)
+    np.testing.assert_allclose(got[0]["P"], one.P_, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(got[0]["w"], one.w_, rtol=0, atol=1e-10)
+    assert got[0]["n_iter"] == one.n_iter_

@@ -234,6 +234,13 @@ int spfm_get_option(spfm_handle h, const char* key, int* value);
  * persistent pass, 16 values per workgroup (8 control-wave, 8 worker-wave phases);
  * returns the number of values written. */
 int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap);
+/* diagnostic: latency of one hand-off "agent-scope store by one workgroup becomes visible to
+ * an agent-scope load of another" (the primitive of the persistent pass's exchange), measured
+ * by ping-pong between workgroup 0 and workgroup `partner` of one launch (workgroups are
+ * dealt round-robin to the 8 XCDs: partner 1 = other XCD, partner 8 = same XCD).
+ * xcc_ids[2] receives the XCC_ID register of the two players. */
+int spfm_debug_hop_latency(spfm_handle h, int partner, int rounds, double* ns_per_hop,
+                           int* xcc_ids);
 
 #ifdef __cplusplus
 }

@@ -1965,6 +1965,52 @@ int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap) {
     return nval;
 }
 
+int spfm_debug_hop_latency(spfm_handle h, int partner, int rounds, double* ns_per_hop,
+                           int* xcc_ids /* [2] */) {
+    GUARD(h);
+    if (partner < 1 || partner > 255 || rounds < 1 || rounds > (1 << 20) || !ns_per_hop)
+        return SPFM_ERR_INVALID;
+    DevBuf words, info;
+    if (words.alloc(sizeof(unsigned long long) * 32) != hipSuccess ||
+        info.alloc(sizeof(int) * 4) != hipSuccess)
+        return SPFM_ERR_RUNTIME;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return SPFM_ERR_RUNTIME;
+    float best = 1e30f;
+    int hinfo[4] = {0, 0, 0, 0};
+    for (int rep = 0; rep < 3; ++rep) {  // first repetition warms the code path
+        (void)hipMemsetAsync(words.p, 0, sizeof(unsigned long long) * 32, h->stream);
+        (void)hipMemsetAsync(info.p, 0, sizeof(int) * 4, h->stream);
+        (void)hipEventRecord(e0, h->stream);
+        hipLaunchKernelGGL(hop_pingpong_kernel, dim3(partner + 1), dim3(kWave), 0, h->stream,
+                           words.as<unsigned long long>(), rounds, partner, info.as<int>());
+        (void)hipEventRecord(e1, h->stream);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) {
+            h->err = "hop_pingpong_kernel failed";
+            return SPFM_ERR_RUNTIME;
+        }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipMemcpy(hinfo, info.p, sizeof(int) * 4, hipMemcpyDeviceToHost);
+        if (hinfo[2] != 0) {
+            h->err = "hop latency probe: partner workgroup did not respond";
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            return SPFM_ERR_RUNTIME;
+        }
+        if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ns_per_hop = (double)best * 1e6 / (2.0 * rounds);
+    if (xcc_ids) {
+        xcc_ids[0] = hinfo[0];
+        xcc_ids[1] = hinfo[1];
+    }
+    return SPFM_OK;
+}
+
 int spfm_set_use_graph(spfm_handle h, int on) {
     if (!h) return SPFM_ERR_INVALID;
     h->use_graph = on != 0;

@@ -889,6 +889,39 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
     }
 }
 
+// ---- diagnostic: latency of one cross-workgroup hand-off -----------------------------
+// Workgroups 0 and `partner` (all others leave at once) play ping-pong on two 8-byte words
+// with the same agent-scope (sc1) stores and loads as the granule exchange: a round trip is
+// two hops "store becomes visible to the other CU's load".  Workgroups are dealt to the 8
+// XCDs round-robin, so partner = 1 crosses XCDs and partner = 8 stays inside XCD 0; the
+// XCC_ID register of both players is returned for confirmation.  Bounded spins.
+__global__ __launch_bounds__(kWave) void hop_pingpong_kernel(unsigned long long* words,
+                                                             int rounds, int partner,
+                                                             int* info /* [4] */) {
+    const int b = blockIdx.x;
+    if ((b != 0 && b != partner) || threadIdx.x != 0) return;
+    const int me = (b == 0) ? 0 : 1;
+    info[me] = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_REG_XCC_ID, 4 bits
+    unsigned long long* mine = words + (me ? 16 : 0);   // separate cache lines
+    unsigned long long* theirs = words + (me ? 0 : 16);
+    for (int r = 1; r <= rounds; ++r) {
+        if (me == 0)
+            __hip_atomic_store(mine, (unsigned long long)r, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+               (unsigned long long)r) {
+            if (++spins > (1u << 22)) {
+                info[2] = r;  // gave up (partner never ran): reported as a failure
+                return;
+            }
+        }
+        if (me == 1)
+            __hip_atomic_store(mine, (unsigned long long)r, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // out[pos] = v[desc[pos].j]
 __global__ void gather_sched_kernel(int d, const ColDesc* __restrict__ desc,
                                     const double* __restrict__ v, double* __restrict__ out) {

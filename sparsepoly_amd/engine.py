@@ -277,6 +277,14 @@ class HipEngine(object):
     def set_use_graph(self, on):
         self._check(self._lib.spfm_set_use_graph(self._h, int(bool(on))))
 
+    def debug_hop_latency(self, partner=1, rounds=20000):
+        """(ns per hand-off, (xcc of workgroup 0, xcc of the partner)); see spfm.h."""
+        ns = C.c_double()
+        xcc = (C.c_int32 * 2)()
+        self._check(self._lib.spfm_debug_hop_latency(self._h, int(partner), int(rounds),
+                                                     C.byref(ns), xcc))
+        return ns.value, (xcc[0], xcc[1])
+
     def debug_prb_stamps(self):
         buf = np.zeros(16 * 256, dtype=np.int64)
         nv = self._lib.spfm_debug_prb_stamps(self._h, buf.ctypes.data_as(_capi._lp), buf.size)

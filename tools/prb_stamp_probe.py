@@ -16,8 +16,8 @@ for G in [int(g) for g in os.environ.get("GS", "16,32").split(",")]:
     names = ["c:pre", "c:-", "c:-", "c:waitB3", "c:sum+chain", "c:B4", "c:ph3+B5", "c:-",
              "w:gather+sum", "w:publish", "w:sweep", "w:prefetch", "w:B3", "w:waitB4", "w:scatter",
              "w:B5"]
-    print("G=%d pass %.2f ms, %.2f us/step; cycles/step (WG0 | mean over WGs | max):" % (G, dt*1e3, dt*1e6/nb))
+    print("G=%d pass %.2f ms, %.2f us/step; cycles/step (WG0 | min | mean over WGs | max):" % (G, dt*1e3, dt*1e6/nb))
     for k in range(16):
-        print("   %-10s %8.0f %8.0f %8.0f" % (names[k], st[0,k]/nb, st[:,k].mean()/nb, st[:,k].max()/nb))
+        print("   %-10s %8.0f %8.0f %8.0f %8.0f" % (names[k], st[0,k]/nb, st[:,k].min()/nb, st[:,k].mean()/nb, st[:,k].max()/nb))
     print("   total cycles/step WG0: control %.0f worker %.0f" % (st[0,:8].sum()/nb, st[0,8:].sum()/nb))
     eng.close()

@@ -241,6 +241,12 @@ int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap);
  * xcc_ids[2] receives the XCC_ID register of the two players. */
 int spfm_debug_hop_latency(spfm_handle h, int partner, int rounds, double* ns_per_hop,
                            int* xcc_ids);
+/* diagnostic: cost of the bare per-step exchange of the persistent pass -- `groups`
+ * workgroups publish 64 granule pairs each and sweep all the others', `rounds` times, with
+ * no other work (readers_mod > 1: only every readers_mod-th workgroup sweeps and passes its
+ * totals on to the rest).  ncols = slots actually read. */
+int spfm_debug_exchange_cost(spfm_handle h, int groups, int ncols, int readers_mod, int rounds,
+                             double* ns_per_round);
 
 #ifdef __cplusplus
 }

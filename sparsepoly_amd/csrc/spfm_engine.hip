@@ -2011,6 +2011,53 @@ int spfm_debug_hop_latency(spfm_handle h, int partner, int rounds, double* ns_pe
     return SPFM_OK;
 }
 
+int spfm_debug_exchange_cost(spfm_handle h, int groups, int ncols, int readers_mod, int rounds,
+                             double* ns_per_round) {
+    GUARD(h);
+    if (groups < 1 || groups > 256 || ncols < 1 || ncols > 64 || readers_mod == 0 ||
+        rounds < 1 || rounds > (1 << 20) || !ns_per_round)
+        return SPFM_ERR_INVALID;
+    DevBuf slab, abortw;
+    const size_t bytes = sizeof(double) * 2 * (2 * (size_t)groups + 2) * 64 * 2;
+    if (slab.alloc(bytes) != hipSuccess || abortw.alloc(16) != hipSuccess) return SPFM_ERR_RUNTIME;
+    PrbArgs a{};
+    a.G = groups;
+    a.slab = slab.as<double>();
+    a.abort_flag = abortw.as<unsigned>();
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return SPFM_ERR_RUNTIME;
+    (void)hipFuncSetAttribute((const void*)exchange_probe_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->kPrbLds);
+    float best = 1e30f;
+    unsigned aborted = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipMemsetAsync(slab.p, 0, bytes, h->stream);
+        (void)hipMemsetAsync(abortw.p, 0, 16, h->stream);
+        (void)hipEventRecord(e0, h->stream);
+        hipLaunchKernelGGL(exchange_probe_kernel, dim3(groups), dim3(readers_mod < 0 ? 512 : kPrbThreads),
+                           h->kPrbLds, h->stream, a, rounds, ncols, readers_mod);
+        (void)hipEventRecord(e1, h->stream);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) {
+            h->err = "exchange_probe_kernel failed";
+            return SPFM_ERR_RUNTIME;
+        }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipMemcpy(&aborted, abortw.p, sizeof(unsigned), hipMemcpyDeviceToHost);
+        if (aborted) break;
+        if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (aborted) {
+        h->err = "exchange probe timed out (workgroups not co-resident?)";
+        return SPFM_ERR_RUNTIME;
+    }
+    *ns_per_round = (double)best * 1e6 / rounds;
+    return SPFM_OK;
+}
+
 int spfm_set_use_graph(spfm_handle h, int on) {
     if (!h) return SPFM_ERR_INVALID;
     h->use_graph = on != 0;

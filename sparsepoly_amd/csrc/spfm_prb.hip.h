@@ -180,10 +180,11 @@ __device__ __forceinline__ void prb_load_pairs8(const double* const* p, prb_u4* 
 
 template <int NV>
 __device__ __forceinline__ bool prb_collect_quarter(const PrbArgs& a, int b, int w, int lane,
-                                                    int ncols, double* out /* [4][64][2] LDS */) {
+                                                    int ncols, double* out /* [nparts][64][2] LDS */,
+                                                    int nparts = 4) {
     const double* slab = a.slab + (size_t)(b & 1) * a.G * 64 * 2;
     const unsigned long long tag = prb_tag(b);
-    const int g0 = (a.G * w) / 4, g1 = (a.G * (w + 1)) / 4;
+    const int g0 = (a.G * w) / nparts, g1 = (a.G * (w + 1)) / nparts;
     double tot[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) tot[v] = 0.0;
@@ -302,14 +303,20 @@ __device__ __forceinline__ void prb_load_entries(const PrbArgs& a, const T* __re
     }
 }
 
-// Workgroup = 5 wavefronts: wave 0 is the CONTROL wave (publish, poll, chain), waves
-// 1..4 are WORKERS (256 threads = 64 slots x 4 lanes) that own the entries.  Software
+// Workgroup = 8 wavefronts: wave 0 is the CONTROL wave (chain), waves 1..4 are WORKERS
+// (256 threads = 64 slots x 4 lanes) that own the entries, waves 5..7 are HELPERS.  All
+// eight take part in the granule sweep, an eighth of the workgroups each, so that at
+// G = 64 every lane needs ONE round of 8 pair loads instead of two back-to-back rounds (the
+// bare exchange, spfm_debug_exchange_cost: 2.10 us instead of 2.60 us per step).  The
+// control wave and the helpers start polling only when the own workers have published (an
+// LDS word): polling from the start of the step floods the fabric.  Software
 // pipeline of step b: its entries are already in worker registers (loaded during step
 // b-1 from slot bounds loaded during step b-2), so phase 1 starts with the row gathers;
 // the workers issue the next step's streaming loads while the control wave waits for
 // the other workgroups.
-constexpr int kPrbThreads = 320;
-constexpr int kPrbLdsFixed = 1536;  // doubles of fixed LDS (control data, part sums, long slots)
+constexpr int kPrbThreads = 512;
+constexpr int kPrbParts = 8;  // waves that sweep = parts of the workgroup range
+constexpr int kPrbLdsFixed = 2560;  // doubles of fixed LDS (control data, part sums, long slots)
 
 // LR != 0: row state resident in LDS (float storage, one cache value per row: M == 2 or
 // the all-subsets model).  The workgroup keeps A[i] and a 4-byte prediction word of its
@@ -331,14 +338,17 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // sized to pin 1 WG / CU
     double* sh_delta = dyn_lds + 128;  // [64]
     double* sh_pold = dyn_lds + 192;   // [64]
-    double* sh_quart = dyn_lds + 256;  // [4][64][2] quarter sums over workgroups
+    double* sh_quart = dyn_lds + 1536;  // [8][64][2] part sums over workgroups
     int* sh_ok = reinterpret_cast<int*>(dyn_lds + 768);
+    int* sh_go = reinterpret_cast<int*>(dyn_lds + 770);  // last step this workgroup published
     const typename Vec2<T>::type* yy2 = reinterpret_cast<const typename Vec2<T>::type*>(yy);
     const int g = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool control = wave == 0;
-    const int wt = tid - 64;  // worker thread id (negative on the control wave)
-    const int slot = control ? 64 : (wt >> 2), sub = wt & 3;
+    const bool worker = wave >= 1 && wave <= 4;
+    const int part = worker ? wave - 1 : (control ? 4 : wave);  // swept part, 0..7
+    const int wt = tid - 64;  // worker thread id (0..255 on the worker waves)
+    const int slot = worker ? (wt >> 2) : 64, sub = wt & 3;
     const int s = ctl->s;
     const double lam = ctl->lam;
     double* ps = P + (size_t)s * d;
@@ -381,7 +391,10 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     int ne0 = 0, ne1 = 0;  // slot bounds of step b+1
     if (a.nb > 1) prb_load_sp(a, g, 1, slot, c2 - c1, ne0, ne1, lm1);
     double p_slot = (slot < c1 - c0) ? pold_sched[c0 + slot] : 0.0;
-    if (tid == 0) *sh_ok = 1;
+    if (tid == 0) {
+        *sh_ok = 1;
+        *sh_go = 0;
+    }
     // diagnostic stamps (only when a.stamps != nullptr): cycles per phase, thread 0
     const bool stamp = a.stamps != nullptr;
     long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 pl = pold_sched[c0 + lane];
                 if (g == 0) jl = a.desc[c0 + lane].j;
             }
-        } else {
+        } else if (worker) {
 #pragma unroll
             for (int u = 0; u < PRB_PF; ++u) {  // all gathers in flight before any use
                 if constexpr (LR != 0) {
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             int qi = 0;
             for (unsigned long long mm = lmu; mm != 0ull; mm &= mm - 1, ++qi) {
                 const int q = __builtin_ctzll(mm);
-                if (!control) {
+                if (worker) {
                     const int le0 = spb[q], le1 = spb[q + 1];
                     const double pq = pold_sched[c0 + q];
                     double lg = 0.0, lh = 0.0;
@@ -526,7 +539,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 }
             }
             __syncthreads();
-            if (!control && wt < qi) {
+            if (worker && wt < qi) {
                 const int q = nth_set_bit(lmu, wt);
                 double tg = 0.0, th = 0.0;
                 for (int w4 = 0; w4 < 4; ++w4) {
@@ -546,8 +559,10 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         // slot bounds + long-slot mask of step b+2: issued before the sweep so that the
         // (scalar) mask load has landed long before the barrier's lgkmcnt(0)
         if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
-        if (!control) {
+        if (worker) {
             PRB_WSTAMP(1)  // publish issue
+            if (tid == 64 + 255)  // last worker wave: this workgroup's partials are on their way
+                __hip_atomic_store(sh_go, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (LR != 0 && b + 1 < a.nb) {
                 // rows in LDS: the end-of-step barrier no longer drains vmcnt, so the
                 // streaming prefetch of step b+1 is issued BEFORE the exchange -- it has the
@@ -556,7 +571,8 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 if (slot < c2 - c1) p_next = pold_sched[c1 + slot];
             }
             if (a.xmode == 0) {
-                const bool ok = prb_collect_quarter<2>(a, b, wave - 1, lane, ncols, sh_quart);
+                const bool ok =
+                    prb_collect_quarter<2>(a, b, part, lane, ncols, sh_quart, kPrbParts);
                 if (!ok) *sh_ok = 0;
             }
             PRB_WSTAMP(2)  // granule sweep until every workgroup's partials are in
@@ -567,8 +583,18 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt, row0);
                 if (slot < c2 - c1) p_next = pold_sched[c1 + slot];
             }
+        } else if (a.xmode == 0) {
+            // control wave and helpers: their parts of the sweep, once the own workers have
+            // published (the other workgroups are at the same point of the step)
+            unsigned spins = 0;
+            while (__hip_atomic_load(sh_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                       b + 1 &&
+                   ++spins < (1u << 24))
+                __builtin_amdgcn_s_sleep(1);
+            const bool ok = prb_collect_quarter<2>(a, b, part, lane, ncols, sh_quart, kPrbParts);
+            if (!ok) *sh_ok = 0;
         }
-        // B3: quarter sums in LDS.  Raw barrier: only LDS traffic must have landed; the
+        // B3: part sums in LDS.  Raw barrier: only LDS traffic must have landed; the
         // prefetch loads just issued stay in flight across it (a __syncthreads() would
         // add s_waitcnt vmcnt(0) and expose their HBM latency on every step).
         PRB_WSTAMP(3)  // prefetch issue
@@ -582,10 +608,11 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             double tot[2];
             if (a.xmode == 0) {
 #pragma unroll
-                for (int v = 0; v < 2; ++v)
-                    tot[v] = ((sh_quart[(0 * 64 + lane) * 2 + v] + sh_quart[(1 * 64 + lane) * 2 + v]) +
-                              sh_quart[(2 * 64 + lane) * 2 + v]) +
-                             sh_quart[(3 * 64 + lane) * 2 + v];
+                for (int v = 0; v < 2; ++v) {
+                    tot[v] = sh_quart[lane * 2 + v];
+#pragma unroll
+                    for (int w = 1; w < kPrbParts; ++w) tot[v] += sh_quart[(w * 64 + lane) * 2 + v];
+                }
             } else if (!prb_owner_exchange<2>(a, b, g, lane, ncols, tot)) {
                 *sh_ok = 0;
             }
@@ -653,7 +680,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 }
             }
         }
-        if (lmu != 0ull && !control) {  // long slots: every worker thread scatters
+        if (lmu != 0ull && worker) {  // long slots: every worker thread scatters
             const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
             for (unsigned long long mm = lmu; mm != 0ull; mm &= mm - 1) {
                 const int q = __builtin_ctzll(mm);
@@ -724,14 +751,17 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
     double* __restrict__ w, double alpha, double mu, double* __restrict__ viol_pos) {
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
     double* sh_delta = dyn_lds + 128;  // [64]
-    double* sh_quart = dyn_lds + 256;  // [4][64][2]
+    double* sh_quart = dyn_lds + 1536;  // [8][64][2]
     int* sh_ok = reinterpret_cast<int*>(dyn_lds + 768);
+    int* sh_go = reinterpret_cast<int*>(dyn_lds + 770);
     const typename Vec2<T>::type* yy2 = reinterpret_cast<const typename Vec2<T>::type*>(yy);
     const int g = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool control = wave == 0;
+    const bool worker = wave >= 1 && wave <= 4;
+    const int part = worker ? wave - 1 : (control ? 4 : wave);
     const int wt = tid - 64;
-    const int slot = control ? 64 : (wt >> 2), sub = wt & 3;
+    const int slot = worker ? (wt >> 2) : 64, sub = wt & 3;
     double* sh_long = dyn_lds + 1024;  // [64][4][2]
     PrbEntries<T> cur, nxt;
     int c0 = a.bptr[0], c1 = a.bptr[1];
@@ -745,7 +775,10 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
     }
     int ne0 = 0, ne1 = 0;
     if (a.nb > 1) prb_load_sp(a, g, 1, slot, c2 - c1, ne0, ne1, lm1);
-    if (tid == 0) *sh_ok = 1;
+    if (tid == 0) {
+        *sh_ok = 1;
+        *sh_go = 0;
+    }
     for (int b = 0; b < a.nb; ++b) {
         const int ncols = c1 - c0;
         const int c4 = (b + 4 <= a.nb) ? a.bptr[b + 4] : c3;
@@ -762,7 +795,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
             int qi = 0;
             for (unsigned long long mm = lmu; mm != 0ull; mm &= mm - 1, ++qi) {
                 const int q = __builtin_ctzll(mm);
-                if (!control) {
+                if (worker) {
                     const int le0 = spb[q], le1 = spb[q + 1];
                     double lg = 0.0;
                     for (int e = le0 + wt; e < le1; e += 256) {
@@ -774,7 +807,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 }
             }
             __syncthreads();
-            if (!control && wt < qi) {
+            if (worker && wt < qi) {
                 const int q = nth_set_bit(lmu, wt);
                 double tg = 0.0;
                 for (int w4 = 0; w4 < 4; ++w4) tg += sh_long[(wt * 4 + w4) * 2];
@@ -788,7 +821,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 cnl = cn_sched[c0 + lane];
                 if (g == 0) jl = a.desc[c0 + lane].j;
             }
-        } else {
+        } else if (worker) {
             double yt[PRB_PF];
 #pragma unroll
             for (int u = 0; u < PRB_PF; ++u) {
@@ -812,16 +845,40 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + slot) * 2;
                 prb_store_granule(sl, ag, prb_tag(b));
             }
+            if (tid == 64 + 255)
+                __hip_atomic_store(sh_go, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
             if (a.xmode == 0) {
-                const bool ok = prb_collect_quarter<1>(a, b, wave - 1, lane, ncols, sh_quart);
+                const bool ok =
+                    prb_collect_quarter<1>(a, b, part, lane, ncols, sh_quart, kPrbParts);
                 if (!ok) *sh_ok = 0;
             }
             if (b + 1 < a.nb) {
                 prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt);
             }
+        } else if (a.xmode == 0) {  // helpers: their parts, once the workers have published
+            if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
+            unsigned spins = 0;
+            while (__hip_atomic_load(sh_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                       b + 1 &&
+                   ++spins < (1u << 24))
+                __builtin_amdgcn_s_sleep(1);
+            const bool ok = prb_collect_quarter<1>(a, b, part, lane, ncols, sh_quart, kPrbParts);
+            if (!ok) *sh_ok = 0;
         }
-        if (control && b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
+        if (control) {
+            if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
+            if (a.xmode == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(sh_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                           b + 1 &&
+                       ++spins < (1u << 24))
+                    __builtin_amdgcn_s_sleep(1);
+                const bool ok =
+                    prb_collect_quarter<1>(a, b, part, lane, ncols, sh_quart, kPrbParts);
+                if (!ok) *sh_ok = 0;
+            }
+        }
         if (a.xmode == 0) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // quarter sums in LDS
             if (!*sh_ok) break;
@@ -829,9 +886,9 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
         if (control) {
             double tot;
             if (a.xmode == 0) {
-                tot = ((sh_quart[(0 * 64 + lane) * 2] + sh_quart[(1 * 64 + lane) * 2]) +
-                       sh_quart[(2 * 64 + lane) * 2]) +
-                      sh_quart[(3 * 64 + lane) * 2];
+                tot = sh_quart[lane * 2];
+#pragma unroll
+                for (int w = 1; w < kPrbParts; ++w) tot += sh_quart[(w * 64 + lane) * 2];
             } else if (!prb_owner_exchange<1>(a, b, g, lane, ncols, &tot)) {
                 *sh_ok = 0;
             }
@@ -862,7 +919,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 }
             }
         }
-        if (lmu != 0ull && !control) {
+        if (lmu != 0ull && worker) {
             const int32_t* spb = a.sp + ((size_t)g * a.nb + b) * 65;
             for (unsigned long long mm = lmu; mm != 0ull; mm &= mm - 1) {
                 const int q = __builtin_ctzll(mm);
@@ -919,6 +976,84 @@ __global__ __launch_bounds__(kWave) void hop_pingpong_kernel(unsigned long long*
         if (me == 1)
             __hip_atomic_store(mine, (unsigned long long)r, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- diagnostic: cost of the bare all-to-all exchange ---------------------------------
+// G workgroups of 5 waves repeat `rounds` times exactly what one step of the persistent pass
+// does for its exchange and nothing else: the 4 worker waves publish 64 tagged granule pairs
+// into the workgroup's slab (parity double-buffered), then each sweeps a quarter of all G
+// slabs until every tag is current, then a workgroup barrier.  readers_mod > 1: only
+// workgroups with g % readers_mod == 0 sweep the partials, the others read one pair per slot
+// from that leader (which republishes its totals) -- the two-level variant.
+__global__ __launch_bounds__(512) void exchange_probe_kernel(PrbArgs a, int rounds,
+                                                                     int ncols, int readers_mod) {
+    __shared__ double quart[8 * 64 * 2];
+    __shared__ int ok_flag;
+    __shared__ int go_flag;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool control = wave == 0;
+    const int wt = tid - 64, slot = (wave >= 1 && wave <= 4) ? (wt >> 2) : 64, sub = wt & 3;
+    const bool eight = readers_mod < 0;  // 8 sweeping waves, one round each
+    if (eight) readers_mod = 1;
+    const bool sweeps = (g % readers_mod) == 0;
+    if (tid == 0) {
+        ok_flag = 1;
+        go_flag = 0;
+    }
+    __syncthreads();
+    for (int b = 0; b < rounds; ++b) {
+        const unsigned long long tag = prb_tag(b);
+        if (eight) {
+            const bool worker = wave >= 1 && wave <= 4;
+            if (worker) {
+                if (sub == 0) {
+                    double* sl =
+                        a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + slot) * 2;
+                    prb_store_granule(sl, 1.0 + b, tag);
+                    prb_store_granule(sl + 1, 2.0 + g, tag);
+                }
+                if (tid == 64 + 255)
+                    __hip_atomic_store(&go_flag, b + 1, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                unsigned spins = 0;
+                while (__hip_atomic_load(&go_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                           b + 1 &&
+                       ++spins < (1u << 24))
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            const int part = worker ? wave - 1 : (control ? 4 : wave);  // 0..7
+            if (!prb_collect_quarter<2>(a, b, part, lane, ncols, quart, 8)) ok_flag = 0;
+            __syncthreads();
+            if (!ok_flag) break;
+            continue;
+        }
+        if (!control && wave <= 4) {
+            if (sub == 0) {
+                double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + slot) * 2;
+                prb_store_granule(sl, 1.0 + b, tag);
+                prb_store_granule(sl + 1, 2.0 + g, tag);
+            }
+            if (sweeps && !prb_collect_quarter<2>(a, b, wave - 1, lane, ncols, quart)) ok_flag = 0;
+        }
+        __syncthreads();
+        if (!ok_flag) break;
+        if (readers_mod > 1 && control) {
+            double* tb = a.slab + (size_t)2 * a.G * 64 * 2 +
+                         ((size_t)(b & 1) * a.G + (g / readers_mod)) * 64 * 2 + (size_t)lane * 2;
+            if (sweeps) {
+                prb_store_granule(tb, quart[lane * 2], tag);
+                prb_store_granule(tb + 1, quart[lane * 2 + 1], tag);
+            } else {
+                double t2[2];
+                bool okp = true;
+                if (lane < ncols) okp = prb_poll<2>(a, tb, tag, t2);
+                if (!__all(okp)) ok_flag = 0;
+            }
+        }
+        __syncthreads();
+        if (!ok_flag) break;
     }
 }
 

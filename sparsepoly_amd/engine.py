@@ -285,6 +285,14 @@ class HipEngine(object):
                                                      C.byref(ns), xcc))
         return ns.value, (xcc[0], xcc[1])
 
+    def debug_exchange_cost(self, groups=64, ncols=37, readers_mod=1, rounds=5000):
+        """ns per bare exchange round of the persistent pass; see spfm.h."""
+        ns = C.c_double()
+        self._check(self._lib.spfm_debug_exchange_cost(self._h, int(groups), int(ncols),
+                                                       int(readers_mod), int(rounds),
+                                                       C.byref(ns)))
+        return ns.value
+
     def debug_prb_stamps(self):
         buf = np.zeros(16 * 256, dtype=np.int64)
         nv = self._lib.spfm_debug_prb_stamps(self._h, buf.ctypes.data_as(_capi._lp), buf.size)

@@ -2035,7 +2035,7 @@ int spfm_debug_exchange_cost(spfm_handle h, int groups, int ncols, int readers_m
         (void)hipMemsetAsync(slab.p, 0, bytes, h->stream);
         (void)hipMemsetAsync(abortw.p, 0, 16, h->stream);
         (void)hipEventRecord(e0, h->stream);
-        hipLaunchKernelGGL(exchange_probe_kernel, dim3(groups), dim3(readers_mod < 0 ? 512 : kPrbThreads),
+        hipLaunchKernelGGL(exchange_probe_kernel, dim3(groups), dim3(readers_mod == -12 ? 768 : 512),
                            h->kPrbLds, h->stream, a, rounds, ncols, readers_mod);
         (void)hipEventRecord(e1, h->stream);
         if (hipStreamSynchronize(h->stream) != hipSuccess) {

@@ -986,7 +986,7 @@ __global__ __launch_bounds__(kWave) void hop_pingpong_kernel(unsigned long long*
 // slabs until every tag is current, then a workgroup barrier.  readers_mod > 1: only
 // workgroups with g % readers_mod == 0 sweep the partials, the others read one pair per slot
 // from that leader (which republishes its totals) -- the two-level variant.
-__global__ __launch_bounds__(512) void exchange_probe_kernel(PrbArgs a, int rounds,
+__global__ __launch_bounds__(768) void exchange_probe_kernel(PrbArgs a, int rounds,
                                                                      int ncols, int readers_mod) {
     __shared__ double quart[8 * 64 * 2];
     __shared__ int ok_flag;
@@ -1023,8 +1023,15 @@ __global__ __launch_bounds__(512) void exchange_probe_kernel(PrbArgs a, int roun
                        ++spins < (1u << 24))
                     __builtin_amdgcn_s_sleep(1);
             }
-            const int part = worker ? wave - 1 : (control ? 4 : wave);  // 0..7
-            if (!prb_collect_quarter<2>(a, b, part, lane, ncols, quart, 8)) ok_flag = 0;
+            if (blockDim.x == 768) {  // 12 waves: the 8 sweepers are all store-free
+                if (!worker) {
+                    const int part12 = control ? 0 : wave - 4;  // waves 5..11 -> 1..7
+                    if (!prb_collect_quarter<2>(a, b, part12, lane, ncols, quart, 8)) ok_flag = 0;
+                }
+            } else {
+                const int part = worker ? wave - 1 : (control ? 4 : wave);  // 0..7
+                if (!prb_collect_quarter<2>(a, b, part, lane, ncols, quart, 8)) ok_flag = 0;
+            }
             __syncthreads();
             if (!ok_flag) break;
             continue;

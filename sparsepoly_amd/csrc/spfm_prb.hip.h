@@ -18,17 +18,15 @@ namespace spfm {
 //
 // Per dependent step the only exchange is the all-gather of the per-slot partial
 // sums: workgroup g stores its (sum dloss*dA, sum dA^2) pairs write-through
-// (agent-scope relaxed atomic stores = global_store sc1) into slab[parity][g][slot],
-// drains them (s_waitcnt vmcnt(0)), and one lane adds 1 to the step's arrival
-// counter; one lane polls that counter with sc1 loads until G arrivals, after
-// which the same wave reads all G slabs with sc1 loads and sums them in fixed
-// order g = 0..G-1 (bitwise identical in every workgroup).  This is the hand-off
-// form "one signalling lane per storing workgroup, counter add / sc1 poll, all
-// stores and loads sc1, one workgroup per CU" of MI355X_MICROARCH.md (Valid forms,
-// first table row).  Every workgroup then runs the scalar chain redundantly and
-// scatter-updates its own rows.  Slabs are double-buffered by step parity: a
-// workgroup can only be two publishes ahead of a reader if it passed the
-// intermediate all-gather, which needs that reader's arrival.
+// (agent-scope relaxed atomic stores = global_store sc1) into slab[parity][g][slot]
+// as TAGGED GRANULES (below: the data is the flag, no counter, no drain), and every
+// workgroup reads all G slabs with sc1 loads, re-reading until every word carries the
+// step's tag, and sums them in fixed order g = 0..G-1 (bitwise identical in every
+// workgroup).  All stores and loads of the hand-off are sc1, one workgroup per CU
+// (MI355X_MICROARCH.md, valid hand-off forms).  Every workgroup then runs the scalar
+// chain redundantly and scatter-updates its own rows.  Slabs are double-buffered by
+// step parity: a workgroup can only be two publishes ahead of a reader if it passed
+// the intermediate all-gather, which needs that reader's publish.
 // Every spin is bounded; on time-out the abort word is set and all workgroups
 // leave the loop (the host reports the failure).
 
@@ -151,10 +149,11 @@ __device__ __forceinline__ bool prb_owner_exchange(const PrbArgs& a, int b, int 
     return __all(ok) != 0;
 }
 
-// Worker wave `w` (0..3) sums the granules of workgroups [w*G/4, (w+1)*G/4) for slot
-// `lane` (all loads in flight together, re-swept until every tag matches); the control
-// wave later adds the four quarter sums in order w = 0..3, so the total is the same bit
-// pattern in every workgroup.  Returns false after a bounded number of sweeps.
+// Sweeping wave `w` (0..nparts-1) sums the granules of workgroups [w*G/nparts,
+// (w+1)*G/nparts) for slot `lane` (all loads in flight together, re-swept until every
+// tag matches); the control wave later adds the part sums in order w = 0..nparts-1, so
+// the total is the same bit pattern in every workgroup.  Returns false after a bounded
+// number of sweeps.  (prb_collect_quarter: the name dates from four sweeping waves.)
 typedef unsigned __attribute__((ext_vector_type(4))) prb_u4;
 
 // Eight 16-byte agent-scope loads (one granule PAIR each) issued back to back, then one
@@ -880,7 +879,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
             }
         }
         if (a.xmode == 0) {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // quarter sums in LDS
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // part sums in LDS
             if (!*sh_ok) break;
         }
         if (control) {
@@ -980,12 +979,16 @@ __global__ __launch_bounds__(kWave) void hop_pingpong_kernel(unsigned long long*
 }
 
 // ---- diagnostic: cost of the bare all-to-all exchange ---------------------------------
-// G workgroups of 5 waves repeat `rounds` times exactly what one step of the persistent pass
-// does for its exchange and nothing else: the 4 worker waves publish 64 tagged granule pairs
-// into the workgroup's slab (parity double-buffered), then each sweeps a quarter of all G
-// slabs until every tag is current, then a workgroup barrier.  readers_mod > 1: only
-// workgroups with g % readers_mod == 0 sweep the partials, the others read one pair per slot
-// from that leader (which republishes its totals) -- the two-level variant.
+// G workgroups repeat `rounds` times exactly what one step of the persistent pass does for
+// its exchange and nothing else: the 4 worker waves publish 64 tagged granule pairs into the
+// workgroup's slab (parity double-buffered), the slabs of all G workgroups are swept until
+// every tag is current, then a workgroup barrier.  readers_mod = 1: the 4 worker waves sweep
+// a quarter each (two rounds of loads per lane at G = 64; the engine before v6);
+// readers_mod > 1: only workgroups with g % readers_mod == 0 sweep, the others read one pair
+// per slot from that leader, which republishes its totals (two-level variant);
+// readers_mod = -8: eight waves sweep an eighth each, control wave and helpers gated on the
+// publish flag (the engine since v6); readers_mod = -12: twelve waves, the eight sweepers
+// all store-free.
 __global__ __launch_bounds__(768) void exchange_probe_kernel(PrbArgs a, int rounds,
                                                                      int ncols, int readers_mod) {
     __shared__ double quart[8 * 64 * 2];

@@ -1,0 +1,97 @@
+"""Randomised differential test: small random problems x random engine options, f64 engine
+vs the oracle replaying the reported coordinate order.  Shapes are drawn to hit the corners
+(fewer rows than workgroups, empty rows and columns, a dense column, k not a power of two,
+one column, every solver/regularizer/loss).  Needs a real MI355X: ``pytest -m gpu``."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+PAIRS = [("pcd", "l1"), ("pcd", "squaredl12"), ("pcd", "omegati"), ("pbcd", "l1"),
+         ("pbcd", "l21"), ("pbcd", "squaredl21"), ("pbcd", "omegacs")]
+
+
+def _case(seed):
+    rng = np.random.RandomState(1000 + seed)
+    n = int(rng.choice([1, 3, 17, 63, 64, 65, 200, 777]))
+    d = int(rng.choice([1, 2, 7, 33, 64, 65, 130]))
+    dens = float(rng.choice([0.02, 0.1, 0.4, 1.0]))
+    X = sp.random(n, d, density=dens, random_state=rng, data_rvs=rng.randn, format="lil")
+    if n > 2 and d > 2:
+        X[:, rng.randint(d)] = rng.randn(n, 1)      # a dense column
+        X[rng.randint(n), :] = 0                    # an empty row
+        X[:, rng.randint(d)] = 0                    # an empty column
+    X = sp.csr_matrix(X)
+    X.eliminate_zeros()
+    solver, reg = PAIRS[seed % len(PAIRS)]
+    degree = 2 if reg in ("squaredl12", "squaredl21") else int(rng.choice([2, 3, 4]))
+    k = int(rng.choice([1, 3, 8, 17, 33]))
+    loss = ["squared", "logistic", "squared_hinge"][int(rng.randint(3))]
+    y = rng.randn(n)
+    if loss != "squared":
+        y = np.where(y > 0, 1.0, -1.0)
+    opts = {}
+    if rng.rand() < 0.5:
+        opts["prb_groups"] = int(rng.choice([1, 2, 5, 64, 200]))
+    if rng.rand() < 0.3:
+        opts["persistent"] = 0
+    if rng.rand() < 0.3:
+        opts["max_batch"] = int(rng.choice([1, 2, 7, 64]))
+    if rng.rand() < 0.2:
+        opts["prb_exchange"] = 1
+    if rng.rand() < 0.2:
+        opts["prb_long"] = 16
+    sched = "colored" if rng.rand() < 0.6 else "exact"
+    fit_lower = "explicit" if rng.rand() < 0.7 else None
+    return dict(X=X, y=y, solver=solver, reg=reg, degree=degree, k=k, loss=loss, opts=opts,
+                sched=sched, fit_lower=fit_lower, beta=10.0 if solver == "pcd" else 1.0,
+                gamma=float(rng.choice([1e-3, 1e-2, 0.1])), alpha=float(rng.choice([1e-2, 1.0])))
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("seed", range(42))
+def test_random_problem_matches_oracle(oracle, seed, precision):
+    from sparsepoly_amd.engine import HipEngine
+
+    c = _case(seed)
+    if precision == "f32":  # float storage (LDS-resident row blocks where they apply)
+        c["X"].data[:] = c["X"].data.astype(np.float32)
+        c["y"] = c["y"].astype(np.float32).astype(np.float64)
+    X, y, degree, k = c["X"], c["y"], c["degree"], c["k"]
+    n, d = X.shape
+    n_orders = degree - 1 if c["fit_lower"] == "explicit" else 1
+    rng = np.random.RandomState(seed)
+    P0 = 0.05 * rng.randn(n_orders, k, d)
+    lams = np.sign(rng.randn(k))
+    eng = HipEngine(0, precision)
+    for key, val in c["opts"].items():
+        eng.set_option(key, val)
+    eng.set_data(X, y)
+    eng.set_params(P0, np.zeros(d), lams)
+    eng.configure(c["solver"], c["loss"], c["reg"], degree)
+    eng.init_pred(degree, True, degree == 3 and c["fit_lower"] == "explicit")
+    order = eng.set_schedule(c["sched"], np.arange(d, dtype=np.int32))
+    ic = np.arange(k, dtype=np.int32)
+    viol = []
+    for _ in range(2):
+        v = eng.cd_linear_epoch(c["alpha"])
+        degs = (list(range(2, degree)) if c["fit_lower"] == "explicit" else []) + [degree]
+        for deg in degs:
+            o = degree - deg if deg != degree else 0
+            v += (eng.pcd_epoch(o, deg, c["beta"], c["gamma"], 1.0, ic) if c["solver"] == "pcd"
+                  else eng.pbcd_epoch(o, deg, c["beta"], c["gamma"], 1.0))
+        viol.append(v)
+    P, w = eng.get_params()
+    yp = eng.get_y_pred()
+    eng.close()
+    fm = oracle.OracleFM(degree=degree, loss=c["loss"], n_components=k, solver=c["solver"],
+                         regularizer=c["reg"], alpha=c["alpha"], beta=c["beta"], gamma=c["gamma"],
+                         tol=0, max_iter=2, fit_lower=c["fit_lower"], feature_order=order)
+    fm.fit(X, y, P_init=P0, lams_init=lams)
+    msg = str({kk: vv for kk, vv in c.items() if kk not in ("X", "y")}) + " shape=%s" % (X.shape,)
+    pa, vr, ya = (1e-8, 1e-8, 1e-7) if precision == "f64" else (2e-4, 2e-4, 2e-3)
+    np.testing.assert_allclose(P, fm.P_, rtol=0, atol=pa, err_msg=msg)
+    np.testing.assert_allclose(w, fm.w_, rtol=0, atol=pa, err_msg=msg)
+    np.testing.assert_allclose(viol, [h[0] for h in fm.history], rtol=vr, atol=pa, err_msg=msg)
+    np.testing.assert_allclose(yp, fm.y_pred_, rtol=0, atol=ya, err_msg=msg)

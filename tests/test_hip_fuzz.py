@@ -95,3 +95,53 @@ def test_random_problem_matches_oracle(oracle, seed, precision):
     np.testing.assert_allclose(w, fm.w_, rtol=0, atol=pa, err_msg=msg)
     np.testing.assert_allclose(viol, [h[0] for h in fm.history], rtol=vr, atol=pa, err_msg=msg)
     np.testing.assert_allclose(yp, fm.y_pred_, rtol=0, atol=ya, err_msg=msg)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_psgd_matches_oracle(oracle, seed):
+    from sparsepoly_amd.engine import HipEngine
+
+    rng = np.random.RandomState(5000 + seed)
+    n = int(rng.choice([1, 3, 65, 200, 513]))
+    d = int(rng.choice([1, 7, 65, 129]))
+    X = sp.random(n, d, density=float(rng.choice([0.05, 0.3, 1.0])), random_state=rng,
+                  data_rvs=rng.randn, format="csr")
+    degree = int(rng.choice([2, 3, 4]))
+    n_orders = int(rng.choice([1, degree - 1]))
+    k = int(rng.choice([1, 5, 17, 33, 70]))
+    reg = ["l1", "l21", "squaredl12", "squaredl21"][seed % 4]
+    loss = ["squared", "logistic", "squared_hinge"][int(rng.randint(3))]
+    y = rng.randn(n)
+    if loss != "squared":
+        y = np.where(y > 0, 1.0, -1.0)
+    batch = int(rng.choice([1, 2, 7, max(n, 1), 2 * n + 1]))
+    lr = ["constant", "optimal", "pegasos", "invscaling"][int(rng.randint(4))]
+    alpha, beta = (20.0, 20.0) if lr == "pegasos" else (1e-2, 0.1)
+    gamma = float(rng.choice([0.0, 1e-3, 1e-2]))
+    P0 = 0.1 * rng.randn(n_orders, k, d)
+    lams = np.sign(rng.randn(k))
+    w0 = 0.01 * rng.randn(d)
+    eng = HipEngine(0, "f64")
+    eng.set_data(X, y)
+    eng.set_params(P0, w0, lams)
+    eng.configure("psgd", loss, reg, degree)
+    Po = np.ascontiguousarray(P0.swapaxes(1, 2))
+    wo = w0.copy()
+    Xr = oracle.CSR(X)
+    it_d = it_o = 1
+    fit_linear = bool(rng.randint(2))
+    for _ in range(2):
+        idx = rng.permutation(n).astype(np.int32)
+        sl_d, it_d = eng.psgd_epoch(degree, alpha, beta, gamma, 0.05, lr, 0.7, batch, idx,
+                                    fit_linear, it_d)
+        sl_o, it_o = oracle.psgd_epoch(Po, wo, Xr, y, lams, degree, alpha, beta, gamma, reg, loss,
+                                       idx, fit_linear, 0.05, lr, 0.7, batch, it_o)
+        assert it_d == it_o
+        np.testing.assert_allclose(sl_d, sl_o, rtol=1e-10, atol=1e-12)
+    P, w = eng.get_params()
+    eng.close()
+    msg = "n=%d d=%d k=%d deg=%d orders=%d %s %s batch=%d lr=%s" % (n, d, k, degree, n_orders, reg,
+                                                                  loss, batch, lr)
+    # (some draws diverge -- degree 4 with step 0.05 -- hence the relative part)
+    np.testing.assert_allclose(P, Po.swapaxes(1, 2), rtol=1e-8, atol=1e-10, err_msg=msg)
+    np.testing.assert_allclose(w, wo, rtol=1e-8, atol=1e-10, err_msg=msg)

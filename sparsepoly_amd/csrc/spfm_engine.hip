@@ -176,7 +176,8 @@ struct spfm_engine {
 
     // psgd (minibatch solver): gradient accumulators, sample order, Michelot state
     DevBuf sg_gradP, sg_gradw, sg_samples, sg_part, sg_cond, sg_thr, sg_theta, sg_done,
-        sg_norms, sg_conv;
+        sg_norms, sg_conv, sg_sched, sg_idx;
+    std::vector<PsgdBatch> h_sched;
 
     // graphs
     bool use_graph = true;
@@ -1473,6 +1474,66 @@ struct spfm_engine {
         ms.NB = nb_dense;
         const int nb_fin = cdiv(ms.V, kBlock / kWave);
         int* h_done = reinterpret_cast<int*>(h_scalar + 4);
+        // l1 / l21 (no host round trip inside a minibatch): tabulate the epoch and replay runs
+        // of kPsgdRun minibatches from one hipGraph -- the kernels take the batch from a device
+        // table, so every (gradient, update) pair has identical arguments
+        if (!mich && use_graph && !prof_on) {
+            constexpr int kPsgdRun = 32;
+            const int64_t nbat = cdiv(n, batch_size);
+            h_sched.resize((size_t)nbat);
+            for (int64_t bi = 0; bi < nbat; ++bi) {
+                const int64_t pos = bi * batch_size;
+                const int B = (int)std::min<int64_t>(batch_size, n - pos);
+                double eta_P, eta_w;
+                psgd_eta(lr, eta0, alpha, beta, power_t, *it + bi, &eta_P, &eta_w);
+                PsgdBatch& e = h_sched[(size_t)bi];
+                e.pos = pos;
+                e.B = B;
+                e.pad = 0;
+                e.cp = eta_P / (double)B;
+                e.denp = 1.0 + eta_P * beta;
+                e.strength = gamma * eta_P / (1 + eta_P * beta);
+                e.cw = eta_w / (double)B;
+                e.denw = 1 + eta_w * alpha;
+            }
+            const void* old = sg_sched.p;
+            HIPC(sg_sched.alloc(sizeof(PsgdBatch) * (size_t)nbat));
+            HIPC(sg_idx.alloc(sizeof(int) * 4));
+            if (sg_sched.p != old) clear_graphs();
+            HIPC(hipMemcpyAsync(sg_sched.p, h_sched.data(), sizeof(PsgdBatch) * (size_t)nbat,
+                                hipMemcpyHostToDevice, stream));
+            HIPC(hipMemsetAsync(sg_idx.p, 0, sizeof(int) * 4, stream));
+            const int gridg = cdiv(std::min<int64_t>(batch_size, n), gpb);
+            auto pair = [&]() {
+                hipLaunchKernelGGL((psgd_grad_kernel<T, L>), dim3(gridg), dim3(kBlock), 0, stream,
+                                   sg_samples.as<int32_t>(), 0, rptr.as<int64_t>(),
+                                   ridx.as<int32_t>(), rval.as<T>(), yy.as<T>(), Pt.as<double>(),
+                                   w.as<double>(), lams.as<double>(), n_orders, k, d, degree, loss,
+                                   fit_linear, sg_gradP.as<double>(), sg_gradw.as<double>(),
+                                   pred_tmp.as<double>(), sg_sched.as<PsgdBatch>(),
+                                   sg_idx.as<int>());
+                hipLaunchKernelGGL((psgd_update_kernel<L>), dim3(nb_dense), dim3(kBlock), 0, stream,
+                                   Pt.as<double>(), sg_gradP.as<double>(), w.as<double>(),
+                                   sg_gradw.as<double>(), n_orders, k, d, reg, 0.0, 1.0, 0.0,
+                                   fit_linear, 0.0, 1.0, sg_norms.as<double>(), ms,
+                                   sg_sched.as<PsgdBatch>(), sg_idx.as<int>());
+            };
+            const std::string key = fkey("psgd", {}, {degree, loss, reg, fit_linear, gridg, L,
+                                                      (int64_t)sizeof(T)});
+            int64_t done_b = 0;
+            for (; done_b + kPsgdRun <= nbat; done_b += kPsgdRun) {
+                int rc = run_cached(key, [&]() {
+                    for (int q = 0; q < kPsgdRun; ++q) pair();
+                    return (int)SPFM_OK;
+                });
+                if (rc) return rc;
+            }
+            for (; done_b < nbat; ++done_b) pair();
+            *it += nbat;
+            HIPC(hipGetLastError());
+            HIPC(hipStreamSynchronize(stream));  // h_sched may be rewritten by the next epoch
+            return SPFM_OK;
+        }
         for (int64_t pos = 0; pos < n; pos += batch_size) {
             const int B = (int)std::min<int64_t>(batch_size, n - pos);
             prof_begin(0, 0);
@@ -1481,7 +1542,8 @@ struct spfm_engine {
                                ridx.as<int32_t>(), rval.as<T>(), yy.as<T>(), Pt.as<double>(),
                                w.as<double>(), lams.as<double>(), n_orders, k, d, degree, loss,
                                fit_linear, sg_gradP.as<double>(), sg_gradw.as<double>(),
-                               pred_tmp.as<double>() + pos);
+                               pred_tmp.as<double>() + pos, (const PsgdBatch*)nullptr,
+                               (int*)nullptr);
             prof_end(0);
             double eta_P, eta_w;
             psgd_eta(lr, eta0, alpha, beta, power_t, *it, &eta_P, &eta_w);
@@ -1491,7 +1553,8 @@ struct spfm_engine {
                                Pt.as<double>(), sg_gradP.as<double>(), w.as<double>(),
                                sg_gradw.as<double>(), n_orders, k, d, reg, eta_P / (double)B,
                                1.0 + eta_P * beta, strength, fit_linear, eta_w / (double)B,
-                               1 + eta_w * alpha, sg_norms.as<double>(), ms);
+                               1 + eta_w * alpha, sg_norms.as<double>(), ms,
+                               (const PsgdBatch*)nullptr, (int*)nullptr);
             prof_end(1);
             if (mich) {
                 prof_begin(2, 0);

@@ -18,6 +18,19 @@
 
 namespace spfm {
 
+// One minibatch as the kernels see it when a whole run of minibatches is replayed from a
+// hipGraph (identical kernel arguments for every batch): the host tabulates the epoch
+// (psgd.py:9-22 step sizes included) and two device counters walk through the table --
+// the gradient kernel reads idx[0] and leaves idx[1] = that batch for the update kernel,
+// which leaves idx[0] = batch + 1 when it is done.  Kernels on one stream run one after
+// the other, so a counter is never written while a kernel that reads it is running.
+struct PsgdBatch {
+    long long pos;  // first position of the batch in the sample order
+    int B;          // rows in the batch
+    int pad;
+    double cp, denp, strength, cw, denw;  // eta_P/B, 1+eta_P*beta, prox strength, eta_w/B, 1+eta_w*alpha
+};
+
 constexpr int kPsgdNB = 1024;  // workgroups of the dense passes (partials per vector)
 constexpr int kPsgdMaxC = 4;   // component chunks per lane (k <= 4 * 64)
 constexpr int kPsgdRC = 64;    // row entries per chunk: all their P loads are in flight together
@@ -97,10 +110,17 @@ __global__ __launch_bounds__(kBlock) void psgd_grad_kernel(
     const double* __restrict__ Pt, const double* __restrict__ w,
     const double* __restrict__ lams, int n_orders, int k, int d, int degree, int loss,
     int fit_linear, double* __restrict__ grad_P, double* __restrict__ grad_w,
-    double* __restrict__ loss_row) {
+    double* __restrict__ loss_row, const PsgdBatch* __restrict__ sched, int* __restrict__ idx) {
     constexpr int gpb = kBlock / L;
     const int grp = threadIdx.x / L, ln = threadIdx.x % L;
     const int r = blockIdx.x * gpb + grp;
+    if (sched) {  // table-driven (graph replay): this launch handles batch idx[0]
+        const int bi = idx[0];
+        if (blockIdx.x == 0 && threadIdx.x == 0) idx[1] = bi;
+        B = sched[bi].B;
+        samples += sched[bi].pos;
+        loss_row += sched[bi].pos;
+    }
     if (r >= B) return;  // whole groups leave; no block-level synchronisation below
     const int i = samples[r];
     const int64_t lo = rptr[i], hi = rptr[i + 1];
@@ -211,9 +231,18 @@ __global__ __launch_bounds__(kBlock) void psgd_update_kernel(
     double* __restrict__ Pt, double* __restrict__ grad_P, double* __restrict__ w,
     double* __restrict__ grad_w, int n_orders, int k, int d, int reg, double cp, double denp,
     double strength, int fit_linear, double cw, double denw, double* __restrict__ norms,
-    MichState ms) {
+    MichState ms, const PsgdBatch* __restrict__ sched, int* __restrict__ idx) {
     constexpr int gpb = kBlock / L;
     __shared__ double red[2][kBlock];
+    if (sched) {  // table-driven (graph replay): batch idx[1], then hand idx[0] on
+        const int bi = idx[1];
+        cp = sched[bi].cp;
+        denp = sched[bi].denp;
+        strength = sched[bi].strength;
+        cw = sched[bi].cw;
+        denw = sched[bi].denw;
+        if (blockIdx.x == 0 && threadIdx.x == 0) idx[0] = bi + 1;
+    }
     const int grp = threadIdx.x / L, ln = threadIdx.x % L;
     const int C = (k + L - 1) / L;
     if (fit_linear) {

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void pbcd_compute_cache_kernel(int d, int r
 //                      "synchronize predictions and caches" (pbcd.py:135-144)
 // Rounding note: update_cache_pbcd's l2 = ||P[j]|| after the prox is taken as f * ||p_j'||
 // (equal up to ~2 ulp) so that the chain needs no vector work.
-constexpr int kPbW = 8;  // workgroups per column in the gather / scatter kernels
+constexpr int kPbW = 32;  // workgroups per column in the gather / scatter kernels
 
 template <typename T, int M, int L, int C>
 __global__ __launch_bounds__(kBlock) void pbcd_grad_kernel(

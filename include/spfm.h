@@ -221,8 +221,12 @@ int spfm_set_use_graph(spfm_handle h, int on);
  * sums, the default; 1 = one owner workgroup per column adds them and publishes the
  * total), "prb_lds" (0/1, default 1: keep each workgroup's row block -- A and the
  * residual / prediction -- in LDS for the whole pass when it fits: f32 storage, one cache
- * value per row, squared loss or +-1 targets), "prb_stamps" (diagnostic phase timers).  They change how a sweep is cut into
- * launches and in which order partial sums are added, never the coordinate order. */
+ * value per row, squared loss or +-1 targets), "prb_stamps" (diagnostic phase timers),
+ * "psgd_eager" (1: launch every psgd minibatch eagerly instead of replaying runs of 32 from
+ * a hipGraph), "psgd_graph_sweeps" (support-search sweeps recorded per minibatch for the
+ * squared-norm prox, default 4; an epoch in which that was not enough is redone eagerly from
+ * a snapshot -- spfm_get_option("psgd_redone") counts those).  They change how a sweep is
+ * cut into launches and in which order partial sums are added, never the coordinate order. */
 int spfm_set_option(spfm_handle h, const char* key, int value);
 /* read back a tunable, or the derived "persistent_active" (1 if the next pcd epoch
  * will use the persistent pass: option on, single GPU, steps of <= 64 columns) and

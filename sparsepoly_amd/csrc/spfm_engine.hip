@@ -176,7 +176,11 @@ struct spfm_engine {
 
     // psgd (minibatch solver): gradient accumulators, sample order, Michelot state
     DevBuf sg_gradP, sg_gradw, sg_samples, sg_part, sg_cond, sg_thr, sg_theta, sg_done,
-        sg_norms, sg_conv, sg_sched, sg_idx;
+        sg_norms, sg_conv, sg_sched, sg_idx, sg_snapP, sg_snapw, sg_snapc;
+    bool psgd_force_eager = false;
+    int psgd_graph_sweeps = 4;
+    bool psgd_warm = false;  // sg_cond holds thresholds of a previous minibatch
+    int psgd_redone = 0;  // epochs that fell back from graph replay to eager launches
     std::vector<PsgdBatch> h_sched;
 
     // graphs
@@ -1427,6 +1431,7 @@ struct spfm_engine {
         HIPC(sg_conv.alloc(sizeof(int) * V));
         HIPC(sg_norms.alloc(sizeof(double) * (size_t)n_orders * d));
         HIPC(hipMemsetAsync(sg_cond.p, 0, sizeof(double) * V, stream));  // first prox: G = all
+        psgd_warm = false;
         HIPC(hipMemsetAsync(sg_gradP.p, 0, sizeof(double) * np, stream));
         HIPC(hipMemsetAsync(sg_gradw.p, 0, sizeof(double) * (size_t)d, stream));
         HIPC(hipMemsetAsync(sg_done.p, 0, sizeof(int) * 4, stream));
@@ -1477,8 +1482,13 @@ struct spfm_engine {
         // l1 / l21 (no host round trip inside a minibatch): tabulate the epoch and replay runs
         // of kPsgdRun minibatches from one hipGraph -- the kernels take the batch from a device
         // table, so every (gradient, update) pair has identical arguments
-        if (!mich && use_graph && !prof_on) {
+        // (squared-norm prox: the first epoch after configure() starts the support search cold --
+        // 6-13 sweeps -- and runs eagerly; afterwards minibatches warm-start each other)
+        if (use_graph && !prof_on && !psgd_force_eager && (!mich || psgd_warm)) {
             constexpr int kPsgdRun = 32;
+            const int kMichSweeps = psgd_graph_sweeps;  // recorded sweeps per minibatch (2 suffice
+                                                        // with the warm start; a failed check
+                                                        // redoes the epoch eagerly)
             const int64_t nbat = cdiv(n, batch_size);
             h_sched.resize((size_t)nbat);
             for (int64_t bi = 0; bi < nbat; ++bi) {
@@ -1502,7 +1512,19 @@ struct spfm_engine {
             if (sg_sched.p != old) clear_graphs();
             HIPC(hipMemcpyAsync(sg_sched.p, h_sched.data(), sizeof(PsgdBatch) * (size_t)nbat,
                                 hipMemcpyHostToDevice, stream));
-            HIPC(hipMemsetAsync(sg_idx.p, 0, sizeof(int) * 4, stream));
+            HIPC(hipMemsetAsync(sg_idx.p, 0, sizeof(int) * 4, stream));  // idx[0..1], idx[2] = failed
+            const size_t np = (size_t)n_orders * k * d;
+            if (mich) {  // snapshot for the (rare) eager redo
+                HIPC(sg_snapP.alloc(sizeof(double) * np));
+                HIPC(sg_snapw.alloc(sizeof(double) * (size_t)d));
+                HIPC(sg_snapc.alloc(sizeof(double) * (size_t)ms.V));
+                HIPC(hipMemcpyAsync(sg_snapP.p, Pt.p, sizeof(double) * np, hipMemcpyDeviceToDevice,
+                                    stream));
+                HIPC(hipMemcpyAsync(sg_snapw.p, w.p, sizeof(double) * (size_t)d,
+                                    hipMemcpyDeviceToDevice, stream));
+                HIPC(hipMemcpyAsync(sg_snapc.p, sg_cond.p, sizeof(double) * (size_t)ms.V,
+                                    hipMemcpyDeviceToDevice, stream));
+            }
             const int gridg = cdiv(std::min<int64_t>(batch_size, n), gpb);
             auto pair = [&]() {
                 hipLaunchKernelGGL((psgd_grad_kernel<T, L>), dim3(gridg), dim3(kBlock), 0, stream,
@@ -1517,9 +1539,25 @@ struct spfm_engine {
                                    sg_gradw.as<double>(), n_orders, k, d, reg, 0.0, 1.0, 0.0,
                                    fit_linear, 0.0, 1.0, sg_norms.as<double>(), ms,
                                    sg_sched.as<PsgdBatch>(), sg_idx.as<int>());
+                if (!mich) return;
+                hipLaunchKernelGGL(psgd_mich_finish_kernel, dim3(nb_fin), dim3(kBlock), 0, stream,
+                                   ms, 0.0, sg_sched.as<PsgdBatch>(), sg_idx.as<int>());
+                for (int sweep = 0; sweep < kMichSweeps; ++sweep) {
+                    hipLaunchKernelGGL((psgd_mich_reduce_kernel<L>), dim3(nb_dense), dim3(kBlock),
+                                       0, stream, Pt.as<double>(), sg_norms.as<double>(), n_orders,
+                                       k, d, reg, ms);
+                    hipLaunchKernelGGL(psgd_mich_finish_kernel, dim3(nb_fin), dim3(kBlock), 0,
+                                       stream, ms, 0.0, sg_sched.as<PsgdBatch>(), sg_idx.as<int>());
+                }
+                hipLaunchKernelGGL(psgd_mich_verify_kernel, dim3(1), dim3(kBlock), 0, stream, ms,
+                                   sg_idx.as<int>() + 2);
+                hipLaunchKernelGGL((psgd_mich_apply_kernel<L>), dim3(nb_dense), dim3(kBlock), 0,
+                                   stream, Pt.as<double>(), sg_norms.as<double>(), n_orders, k, d,
+                                   reg, sg_thr.as<double>());
             };
             const std::string key = fkey("psgd", {}, {degree, loss, reg, fit_linear, gridg, L,
-                                                      (int64_t)sizeof(T)});
+                                                      (int64_t)sizeof(T), (int64_t)mich,
+                                                      (int64_t)psgd_graph_sweeps});
             int64_t done_b = 0;
             for (; done_b + kPsgdRun <= nbat; done_b += kPsgdRun) {
                 int rc = run_cached(key, [&]() {
@@ -1529,10 +1567,26 @@ struct spfm_engine {
                 if (rc) return rc;
             }
             for (; done_b < nbat; ++done_b) pair();
-            *it += nbat;
             HIPC(hipGetLastError());
+            int failed = 0;
+            if (mich)
+                HIPC(hipMemcpyAsync(&failed, sg_idx.as<int>() + 2, sizeof(int),
+                                    hipMemcpyDeviceToHost, stream));
             HIPC(hipStreamSynchronize(stream));  // h_sched may be rewritten by the next epoch
-            return SPFM_OK;
+            if (!failed) {
+                *it += nbat;
+                return SPFM_OK;
+            }
+            // some minibatch needed more sweeps than were recorded: restore and redo eagerly
+            HIPC(hipMemcpyAsync(Pt.p, sg_snapP.p, sizeof(double) * np, hipMemcpyDeviceToDevice,
+                                stream));
+            HIPC(hipMemcpyAsync(w.p, sg_snapw.p, sizeof(double) * (size_t)d,
+                                hipMemcpyDeviceToDevice, stream));
+            HIPC(hipMemcpyAsync(sg_cond.p, sg_snapc.p, sizeof(double) * (size_t)ms.V,
+                                hipMemcpyDeviceToDevice, stream));
+            HIPC(hipMemsetAsync(sg_gradP.p, 0, sizeof(double) * np, stream));
+            HIPC(hipMemsetAsync(sg_gradw.p, 0, sizeof(double) * (size_t)d, stream));
+            psgd_redone += 1;
         }
         for (int64_t pos = 0; pos < n; pos += batch_size) {
             const int B = (int)std::min<int64_t>(batch_size, n - pos);
@@ -1559,7 +1613,7 @@ struct spfm_engine {
             if (mich) {
                 prof_begin(2, 0);
                 hipLaunchKernelGGL(psgd_mich_finish_kernel, dim3(nb_fin), dim3(kBlock), 0, stream,
-                                   ms, strength);
+                                   ms, strength, (const PsgdBatch*)nullptr, (const int*)nullptr);
                 // the iteration is monotone after the first sweep, so it terminates (<= d
                 // sweeps; 2-4 with the warm start); the host looks at the flag per chunk
                 for (int guard = 0;; ++guard) {
@@ -1568,7 +1622,8 @@ struct spfm_engine {
                                            dim3(kBlock), 0, stream, Pt.as<double>(),
                                            sg_norms.as<double>(), n_orders, k, d, reg, ms);
                         hipLaunchKernelGGL(psgd_mich_finish_kernel, dim3(nb_fin), dim3(kBlock),
-                                           0, stream, ms, strength);
+                                           0, stream, ms, strength, (const PsgdBatch*)nullptr,
+                                           (const int*)nullptr);
                     }
                     hipLaunchKernelGGL(psgd_mich_check_kernel, dim3(1), dim3(kBlock), 0, stream,
                                        ms);
@@ -1645,6 +1700,7 @@ struct spfm_engine {
         HIPC(hipStreamSynchronize(stream));
         prof_collect();
         if (sum_loss) *sum_loss = h_scalar[0];
+        psgd_warm = true;
         return SPFM_OK;
     }
 };
@@ -1969,6 +2025,14 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->prb_ready = false;
     } else if (k == "prb_stamps") {
         h->prb_stamp_on = value != 0;
+    } else if (k == "psgd_graph_sweeps") {
+        if (value < 0 || value > 64) {
+            h->err = "psgd_graph_sweeps must be in 0..64";
+            return SPFM_ERR_INVALID;
+        }
+        h->psgd_graph_sweeps = value;
+    } else if (k == "psgd_eager") {
+        h->psgd_force_eager = value != 0;
     } else if (k == "prb_lds") {
         h->prb_lds = value != 0;
     } else if (k == "prb_exchange") {
@@ -2008,6 +2072,7 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "prb_groups") *value = h->prb_G;
     else if (k == "prb_exchange") *value = h->prb_xmode;
     else if (k == "prb_lds") *value = h->prb_lds;
+    else if (k == "psgd_redone") *value = h->psgd_redone;
     else if (k == "prb_lds_active") *value = h->prb_lds_active;
     else if (k == "persistent_active") *value = h->have_schedule && h->prb_usable();
     else {

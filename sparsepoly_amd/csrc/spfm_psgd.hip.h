@@ -356,7 +356,9 @@ __global__ __launch_bounds__(kBlock) void psgd_update_kernel(
 
 // One wave per vector: fold its NB partials in fixed order, derive the next thresholds,
 // mark the vector converged when its support size did not change.
-__global__ __launch_bounds__(kBlock) void psgd_mich_finish_kernel(MichState ms, double strength) {
+__global__ __launch_bounds__(kBlock) void psgd_mich_finish_kernel(
+    MichState ms, double strength, const PsgdBatch* __restrict__ sched, const int* __restrict__ idx) {
+    if (sched) strength = sched[idx[1]].strength;  // table-driven (graph replay)
     const int v = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (v >= ms.V || ms.conv[v]) return;
@@ -442,6 +444,13 @@ __global__ __launch_bounds__(kBlock) void psgd_mich_reduce_kernel(
 __global__ __launch_bounds__(kBlock) void psgd_mich_check_kernel(MichState ms) {
     const bool all = mich_all_converged(ms);
     if (threadIdx.x == 0) *ms.done = all ? 1 : 0;
+}
+
+// graph replay: a fixed number of sweeps was recorded; if that was not enough for some
+// minibatch, say so (sticky) -- the host then redoes the epoch from its snapshot, eagerly
+__global__ __launch_bounds__(kBlock) void psgd_mich_verify_kernel(MichState ms, int* failed) {
+    const bool all = mich_all_converged(ms);
+    if (threadIdx.x == 0 && !all) *failed = 1;
 }
 
 // Final soft threshold (squaredl12.py:73-75 / squaredl21.py:67-74).

@@ -246,3 +246,58 @@ def test_psgd_errors_and_api():
     with pytest.raises(ValueError):
         eng.pcd_epoch(0, 2, 1, 1, 1, np.arange(2, dtype=np.int32))             # wrong solver
     eng.close()
+
+
+@pytest.mark.parametrize("regname", ["squaredl12", "squaredl21", "l1"])
+def test_graph_replay_and_eager_redo_give_the_same_result(oracle, regname):
+    """l1 / l21 and (after the first, cold epoch) the squared-norm regularizers replay runs of
+    32 minibatches from a hipGraph.  For the squared norms the graph records a fixed number of
+    support-search sweeps; with too few (0) every replayed epoch fails its check and is redone
+    eagerly from the snapshot.  All three ways must agree with the oracle."""
+    from sparsepoly_amd.engine import HipEngine
+    from sparsepoly_amd.synth import make_problem
+
+    n, d, k = 6400, 500, 12
+    X, y = make_problem(n, d, 12, seed=11)
+    rng = np.random.RandomState(3)
+    P0 = 0.05 * rng.randn(1, k, d)
+    lams = np.ones(k)
+    gamma = 1e-3 if regname != "l1" else 3e-3
+    args = (2, 1e-2, 0.5, gamma, 0.05, "optimal", 0.8, 50)   # 128 minibatches per epoch
+    res = {}
+    for mode, opts in (("graph", {}), ("eager", {"psgd_eager": 1}),
+                       ("redo", {"psgd_graph_sweeps": 0})):
+        eng = HipEngine(0, "f64")
+        for key, val in opts.items():
+            eng.set_option(key, val)
+        eng.set_data(X, y)
+        eng.set_params(P0, np.zeros(d), lams)
+        eng.configure("psgd", "squared", regname, 2)
+        it, sls = 1, []
+        r2 = np.random.RandomState(4)
+        for _ in range(3):
+            idx = r2.permutation(n).astype(np.int32)
+            sl, it = eng.psgd_epoch(*args, idx, True, it)
+            sls.append(sl)
+        res[mode] = (eng.get_params(), np.array(sls), it, eng.get_option("psgd_redone"))
+        eng.close()
+    Po = np.ascontiguousarray(P0.swapaxes(1, 2))
+    wo = np.zeros(d)
+    it_o, r2, slo = 1, np.random.RandomState(4), []
+    for _ in range(3):
+        idx = r2.permutation(n).astype(np.int32)
+        sl, it_o = oracle.psgd_epoch(Po, wo, oracle.CSR(X), y, lams, 2, 1e-2, 0.5, gamma, regname,
+                                     "squared", idx, True, 0.05, "optimal", 0.8, 50, it_o)
+        slo.append(sl)
+    for mode in res:
+        (P, w), sls, it, redone = res[mode]
+        assert it == it_o == 1 + 3 * 128
+        np.testing.assert_allclose(sls, slo, rtol=1e-10, err_msg=mode)
+        np.testing.assert_allclose(P, Po.swapaxes(1, 2), rtol=0, atol=1e-10, err_msg=mode)
+        np.testing.assert_allclose(w, wo, rtol=0, atol=1e-10, err_msg=mode)
+    assert res["eager"][3] == 0
+    if regname == "l1":
+        assert res["graph"][3] == 0 and res["redo"][3] == 0
+    else:
+        assert res["redo"][3] == 2      # epochs 2 and 3 (epoch 1 runs eagerly: cold start)
+        assert res["graph"][3] == 0     # 4 recorded sweeps were enough

@@ -171,7 +171,9 @@ struct spfm_engine {
     int64_t sched_version = 0;
 
     // work
-    DevBuf part, delta, pold, viol_col, scalar, ctl, comp_order, pred_tmp, partial, pb_scal;
+    DevBuf part, delta, pold, viol_col, scalar, ctl, comp_order, pred_tmp, partial, pb_scal,
+        pb_ticket;
+    bool pbcd_fuse = true;  // prep + chain in one launch (ticket hand-off)
     double* h_scalar = nullptr;  // pinned
 
     // psgd (minibatch solver): gradient accumulators, sample order, Michelot state
@@ -623,6 +625,7 @@ struct spfm_engine {
         HIPC(hipMemsetAsync(ctl.p, 0, sizeof(Ctl), stream));
         HIPC(comp_order.alloc(sizeof(int32_t) * (size_t)k));
         HIPC(scalar.alloc(sizeof(double) * 8));
+        HIPC(pb_ticket.alloc(sizeof(int) * 4));
         if (!h_scalar) HIPC(hipHostMalloc((void**)&h_scalar, sizeof(double) * 8));
         HIPC(hipStreamSynchronize(stream));
         configured = true;
@@ -1328,6 +1331,7 @@ struct spfm_engine {
                                reg, rs);
         }
         const size_t shm = sizeof(double) * ((size_t)(kBlock / L) * k + 16);
+        HIPC(hipMemsetAsync(pb_ticket.p, 0, sizeof(int) * 4, stream));  // (resets itself per step)
         const int nb = n_batches();
         for (int b = 0; b < nb; ++b) {
             const int c0 = batch_ptr[b], nc = batch_ptr[b + 1] - c0;
@@ -1341,12 +1345,22 @@ struct spfm_engine {
             prof_end(2);
             int rc = allreduce(part.as<double>(), (size_t)nc * kPbW * (k + 1));
             if (rc) return rc;
-            hipLaunchKernelGGL((pbcd_prep_kernel<CW>), dim3(nc), dim3(kWave), 0, stream, desc, Po,
-                               k, part.as<double>(), lams.as<double>(), reg, mu, beta, gamma, eta,
-                               delta.as<double>(), pold.as<double>(), pb_scal.as<double>());
-            if (chained)
-                hipLaunchKernelGGL((pbcd_chain_kernel<M>), dim3(1), dim3(kWave), 0, stream, desc,
-                                   nc, d, reg, rs, top_degree > 0 ? top_degree + 1 : 1, pb_scal.as<double>());
+            const int ncache = top_degree > 0 ? top_degree + 1 : 1;
+            if (chained && pbcd_fuse) {
+                hipLaunchKernelGGL((pbcd_prep_chain_kernel<M, CW>), dim3(nc), dim3(kWave), 0,
+                                   stream, desc, nc, Po, k, part.as<double>(), lams.as<double>(),
+                                   reg, mu, beta, gamma, eta, delta.as<double>(),
+                                   pold.as<double>(), pb_scal.as<double>(), d, rs, ncache,
+                                   pb_ticket.as<int>());
+            } else {
+                hipLaunchKernelGGL((pbcd_prep_kernel<CW>), dim3(nc), dim3(kWave), 0, stream, desc,
+                                   Po, k, part.as<double>(), lams.as<double>(), reg, mu, beta,
+                                   gamma, eta, delta.as<double>(), pold.as<double>(),
+                                   pb_scal.as<double>());
+                if (chained)
+                    hipLaunchKernelGGL((pbcd_chain_kernel<M>), dim3(1), dim3(kWave), 0, stream,
+                                       desc, nc, d, reg, rs, ncache, pb_scal.as<double>());
+            }
             prof_begin(3, bn);
             hipLaunchKernelGGL((pbcd_sync_kernel<T, M, L, C>), dim3(nc * kPbW), dim3(kBlock), 0,
                                stream, desc, cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
@@ -2033,6 +2047,8 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->psgd_graph_sweeps = value;
     } else if (k == "psgd_eager") {
         h->psgd_force_eager = value != 0;
+    } else if (k == "pbcd_fuse") {
+        h->pbcd_fuse = value != 0;
     } else if (k == "prb_lds") {
         h->prb_lds = value != 0;
     } else if (k == "prb_exchange") {

@@ -134,6 +134,20 @@ __global__ __launch_bounds__(kBlock) void pbcd_compute_cache_kernel(int d, int r
 //                      "synchronize predictions and caches" (pbcd.py:135-144)
 // Rounding note: update_cache_pbcd's l2 = ||P[j]|| after the prox is taken as f * ||p_j'||
 // (equal up to ~2 ulp) so that the chain needs no vector work.
+// COH = true: the value crosses workgroups INSIDE one launch (prep + chain fused): written
+// through and read past the caches with agent-scope (sc1) accesses, as in the persistent
+// pass -- fences would flush the whole L2 of the XCD.
+template <bool COH>
+__device__ __forceinline__ double pb_ld(const double* p) {
+    if constexpr (COH) return ld_agent(p);
+    else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void pb_st(double* p, double v) {
+    if constexpr (COH) st_agent(p, v);
+    else *p = v;
+}
+
 constexpr int kPbW = 32;  // workgroups per column in the gather / scatter kernels
 
 template <typename T, int M, int L, int C>
@@ -217,13 +231,12 @@ __global__ __launch_bounds__(kBlock) void pbcd_grad_kernel(
 }
 
 // per column: scal[q] = {l2 of p_j', st0 = eta*gamma/inv, f (L1/L21: final), unused}
-template <int C>
-__global__ __launch_bounds__(kWave) void pbcd_prep_kernel(
-    const ColDesc* __restrict__ desc, const double* __restrict__ P /* (d,k) */, int k,
-    const double* __restrict__ part, const double* __restrict__ lams, int reg, double mu,
+template <int C, bool COH>
+__device__ __forceinline__ void pbcd_prep_col(
+    int q, int lane, const ColDesc* __restrict__ desc, const double* __restrict__ P /* (d,k) */,
+    int k, const double* __restrict__ part, const double* __restrict__ lams, int reg, double mu,
     double beta, double gamma, double eta, double* __restrict__ pin /* [ncols][k] p_j' */,
     double* __restrict__ pold /* [ncols][k] */, double* __restrict__ scal /* [ncols][4] */) {
-    const int q = blockIdx.x, lane = threadIdx.x;
     const int j = desc[q].j;
     const double* pq = part + (size_t)q * kPbW * (k + 1);
     double inv = 0.0;
@@ -264,8 +277,8 @@ __global__ __launch_bounds__(kWave) void pbcd_prep_kernel(
     if (lane == 0) {
         double f = 1.0;
         if (reg == REG_L21) f = (l2 > st0) ? (1.0 - st0 / l2) : 0.0;  // l21.py:33-38
-        scal[4 * q + 0] = l2;
-        scal[4 * q + 1] = st0;
+        pb_st<COH>(&scal[4 * q + 0], l2);
+        pb_st<COH>(&scal[4 * q + 1], st0);
         scal[4 * q + 2] = f;
         scal[4 * q + 3] = 0.0;
     }
@@ -275,11 +288,10 @@ __global__ __launch_bounds__(kWave) void pbcd_prep_kernel(
 // serial loop; writes the shrink factor f into scal[q][2] and the new block norm into
 // norms[j].  Fallback branches ("numerical error": squaredl21.py:48-49,
 // omegacs.py:75-76,90-96) recompute from all d norms with the whole wave.
-template <int M>
-__global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
-    const ColDesc* __restrict__ desc, int ncols, int d, int reg, RegState rs, int top_ncache,
-    double* __restrict__ scal) {
-    const int lane = threadIdx.x;
+template <int M, bool COH>
+__device__ __forceinline__ void pbcd_chain_body(
+    int lane, const ColDesc* __restrict__ desc, int ncols, int d, int reg, RegState rs,
+    int top_ncache, double* __restrict__ scal) {
     double cache[kMaxDegree + 2], dcache[kMaxDegree + 2];
     {   // one vector load each, then broadcast (the state is wave-uniform)
         const double cv = (lane < top_ncache) ? rs.cache[lane] : 0.0;
@@ -298,8 +310,8 @@ __global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
         double l2 = 0.0, st0 = 0.0, njl = 0.0;
         if (valid) {
             j = desc[q].j;
-            l2 = scal[4 * q + 0];
-            st0 = scal[4 * q + 1];
+            l2 = pb_ld<COH>(&scal[4 * q + 0]);
+            st0 = pb_ld<COH>(&scal[4 * q + 1]);
             njl = rs.norms[j];
         }
         if constexpr (M == 2) {
@@ -514,6 +526,48 @@ __global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
                 rs.dcache[t] = dcache[t];
             }
     }
+}
+
+// stand-alone forms
+template <int C>
+__global__ __launch_bounds__(kWave) void pbcd_prep_kernel(
+    const ColDesc* __restrict__ desc, const double* __restrict__ P, int k,
+    const double* __restrict__ part, const double* __restrict__ lams, int reg, double mu,
+    double beta, double gamma, double eta, double* __restrict__ pin, double* __restrict__ pold,
+    double* __restrict__ scal) {
+    pbcd_prep_col<C, false>(blockIdx.x, threadIdx.x, desc, P, k, part, lams, reg, mu, beta, gamma,
+                            eta, pin, pold, scal);
+}
+template <int M>
+__global__ __launch_bounds__(kWave) void pbcd_chain_kernel(
+    const ColDesc* __restrict__ desc, int ncols, int d, int reg, RegState rs, int top_ncache,
+    double* __restrict__ scal) {
+    pbcd_chain_body<M, false>(threadIdx.x, desc, ncols, d, reg, rs, top_ncache, scal);
+}
+
+// prep + chain in one launch: one wave per column prepares it, writes the two scalars the
+// chain needs (block norm, strength) through to memory and takes a ticket; the wave that
+// takes the last ticket runs the chain, reading those scalars past the caches.  One kernel
+// boundary less per dependent step; the ticket word resets itself.
+template <int M, int C>
+__global__ __launch_bounds__(kWave) void pbcd_prep_chain_kernel(
+    const ColDesc* __restrict__ desc, int ncols, const double* __restrict__ P, int k,
+    const double* __restrict__ part, const double* __restrict__ lams, int reg, double mu,
+    double beta, double gamma, double eta, double* __restrict__ pin, double* __restrict__ pold,
+    double* __restrict__ scal, int d, RegState rs, int top_ncache, int* __restrict__ ticket) {
+    pbcd_prep_col<C, true>(blockIdx.x, threadIdx.x, desc, P, k, part, lams, reg, mu, beta, gamma,
+                           eta, pin, pold, scal);
+    // the write-through scalars of this column are acknowledged before the ticket is taken
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    int last = 0;
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == ncols - 1) ? 1 : 0;
+        if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    pbcd_chain_body<M, true>(threadIdx.x, desc, ncols, d, reg, rs, top_ncache, scal);
 }
 
 // p_j = f * p_j' (prox_bcd's shrink), P[j] write-back, sum_viol (pbcd.py:146) and

@@ -947,15 +947,42 @@ struct spfm_engine {
         const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
         int rc = ensure_prb<T>();
         if (rc) return rc;
-        HIPC(hipFuncSetAttribute((const void*)lin_prb_kernel<T, LOSS>,
+        // row block resident in LDS (4-5 bytes per row: residual, or prediction + label sign)
+        constexpr bool can_lr = std::is_same<T, float>::value;
+        constexpr int LRV = (LOSS == LOSS_SQUARED) ? 1 : 2;
+        const PrbArgs pa = prb_args();
+        int lds_max = 0;
+        HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+        const size_t lds_lr = sizeof(double) * kPrbLdsFixed + (size_t)pa.rows_per * 5 + 16;
+        const bool use_lr = can_lr && prb_lds && lds_lr <= (size_t)lds_max && (LRV == 1 || y_pm1);
+        const size_t lds_bytes = use_lr ? std::max(lds_lr, kPrbLds) : kPrbLds;
+        if constexpr (can_lr) {
+            if (use_lr)
+                HIPC(hipFuncSetAttribute((const void*)lin_prb_kernel<T, LOSS, LRV>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_bytes));
+        }
+        HIPC(hipFuncSetAttribute((const void*)lin_prb_kernel<T, LOSS, 0>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrbLds));
         hipLaunchKernelGGL(gather_sched_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
                            d_desc.as<ColDesc>(), w.as<double>(), prow_old.as<double>());
         HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));
         prof_begin(4, nnz);
-        hipLaunchKernelGGL((lin_prb_kernel<T, LOSS>), dim3(prb_G), dim3(kPrbThreads), kPrbLds,
-                           stream, prb_args(), prb_eval.as<T>(), yy.as<T>(), prow_old.as<double>(),
-                           prb_cn.as<double>(), w.as<double>(), alpha, mu, prb_viol.as<double>());
+        bool launched = false;
+        if constexpr (can_lr) {
+            if (use_lr) {
+                hipLaunchKernelGGL((lin_prb_kernel<T, LOSS, LRV>), dim3(prb_G), dim3(kPrbThreads),
+                                   lds_bytes, stream, pa, prb_eval.as<T>(), yy.as<T>(),
+                                   prow_old.as<double>(), prb_cn.as<double>(), w.as<double>(),
+                                   alpha, mu, prb_viol.as<double>());
+                launched = true;
+            }
+        }
+        if (!launched)
+            hipLaunchKernelGGL((lin_prb_kernel<T, LOSS, 0>), dim3(prb_G), dim3(kPrbThreads),
+                               kPrbLds, stream, pa, prb_eval.as<T>(), yy.as<T>(),
+                               prow_old.as<double>(), prb_cn.as<double>(), w.as<double>(), alpha,
+                               mu, prb_viol.as<double>());
         prof_end(4);
         hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
                            d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());

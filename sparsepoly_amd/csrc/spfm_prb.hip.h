@@ -743,7 +743,9 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
 // one value per slot; the update has no regularizer, so the control wave's "chain" is
 // lane-parallel.  w_sched / cn_sched are w and col_norm_sq in visiting order (w as of the
 // epoch start: workgroup 0 writes the new w[j] while others may still read the old one).
-template <typename T, int LOSS>
+// LR as in pcd_prb_kernel: 1 = residual word per row in LDS (squared loss), 2 = prediction
+// word + label sign (+-1 targets); float storage.  4-5 bytes per row: it always fits.
+template <typename T, int LOSS, int LR>
 __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
     PrbArgs a, const T* __restrict__ eval, T* __restrict__ yy,
     const double* __restrict__ w_sched, const double* __restrict__ cn_sched,
@@ -762,6 +764,39 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
     const int wt = tid - 64;
     const int slot = worker ? (wt >> 2) : 64, sub = wt & 3;
     double* sh_long = dyn_lds + 1024;  // [64][4][2]
+    static_assert(LR == 0 || (sizeof(T) == 4 && (LR == 2 || LOSS == LOSS_SQUARED)),
+                  "LDS-resident rows: float storage");
+    const int row0 = LR ? g * a.rows_per : 0;
+    T* lds_r = reinterpret_cast<T*>(dyn_lds + kPrbLdsFixed);  // [rows_per] residual or yhat
+    unsigned char* lds_s = reinterpret_cast<unsigned char*>(lds_r + a.rows_per);  // y > 0
+    if constexpr (LR != 0) {
+        const int nr = min(a.rows_per, a.n_rows - row0);
+        for (int il = tid; il < nr; il += kPrbThreads) {
+            const typename Vec2<T>::type yv = yy2[(size_t)(row0 + il)];
+            if constexpr (LR == 1) {
+                lds_r[il] = (T)((double)yv.x - (double)yv.y);
+            } else {
+                lds_r[il] = yv.x;
+                lds_s[il] = yv.y > (T)0 ? 1 : 0;
+            }
+        }
+        __syncthreads();
+    }
+    // (yhat, y) of a row as the loss sees them
+    auto row_state = [&](int i, double& y0, double& y1) {
+        if constexpr (LR != 0) {
+            y0 = (double)lds_r[i - row0];
+            y1 = (LR == 1) ? 0.0 : (lds_s[i - row0] ? 1.0 : -1.0);
+        } else {
+            const typename Vec2<T>::type yv = yy2[(size_t)i];
+            y0 = (double)yv.x;
+            y1 = (double)yv.y;
+        }
+    };
+    auto row_update = [&](int i, double yold, double dec) {  // yhat_i (or r_i) -= dec
+        if constexpr (LR != 0) lds_r[i - row0] = (T)(yold - dec);
+        else yy[2 * (size_t)i] = (T)(yold - dec);
+    };
     PrbEntries<T> cur, nxt;
     int c0 = a.bptr[0], c1 = a.bptr[1];
     int c2 = (a.nb > 1) ? a.bptr[2] : c1;
@@ -770,7 +805,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
     {
         int e0, e1;
         prb_load_sp(a, g, 0, slot, c1 - c0, e0, e1, lm0);
-        prb_load_entries<T>(a, eval, e0, e1, sub, cur);
+        prb_load_entries<T>(a, eval, e0, e1, sub, cur, row0);
     }
     int ne0 = 0, ne1 = 0;
     if (a.nb > 1) prb_load_sp(a, g, 1, slot, c2 - c1, ne0, ne1, lm1);
@@ -798,8 +833,9 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                     const int le0 = spb[q], le1 = spb[q + 1];
                     double lg = 0.0;
                     for (int e = le0 + wt; e < le1; e += 256) {
-                        const typename Vec2<T>::type yv = yy2[(size_t)a.erow[e]];
-                        lg += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * (double)eval[e];
+                        double y0, y1;
+                        row_state(a.erow[e], y0, y1);
+                        lg += dloss_dev(LOSS, y0, y1) * (double)eval[e];
                     }
                     lg = wave_sum(lg);
                     if (lane == 0) sh_long[(qi * 4 + (wave - 1)) * 2] = lg;
@@ -823,11 +859,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
         } else if (worker) {
             double yt[PRB_PF];
 #pragma unroll
-            for (int u = 0; u < PRB_PF; ++u) {
-                const typename Vec2<T>::type yv = yy2[(size_t)cur.row[u]];
-                yh[u] = (double)yv.x;
-                yt[u] = (double)yv.y;
-            }
+            for (int u = 0; u < PRB_PF; ++u) row_state(cur.row[u], yh[u], yt[u]);
             double ag = 0.0;
 #pragma unroll
             for (int u = 0; u < PRB_PF; ++u) {
@@ -835,8 +867,9 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 ag += v ? dloss_dev(LOSS, yh[u], yt[u]) * (double)cur.x[u] : 0.0;
             }
             for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {
-                const typename Vec2<T>::type yv = yy2[(size_t)a.erow[e]];
-                ag += dloss_dev(LOSS, (double)yv.x, (double)yv.y) * (double)eval[e];
+                double y0, y1;
+                row_state(a.erow[e], y0, y1);
+                ag += dloss_dev(LOSS, y0, y1) * (double)eval[e];
             }
             ag += __shfl_xor(ag, 1, kWave);
             ag += __shfl_xor(ag, 2, kWave);
@@ -853,7 +886,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 if (!ok) *sh_ok = 0;
             }
             if (b + 1 < a.nb) {
-                prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt);
+                prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt, row0);
             }
         } else if (a.xmode == 0) {  // helpers: their parts, once the workers have published
             if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
@@ -911,10 +944,11 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
 #pragma unroll
                 for (int u = 0; u < PRB_PF; ++u)
                     if (cur.e0 + sub + 4 * u < cur.e1)
-                        yy[2 * (size_t)cur.row[u]] = (T)(yh[u] - upd * (double)cur.x[u]);
+                        row_update(cur.row[u], yh[u], upd * (double)cur.x[u]);
                 for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {
-                    const size_t i = (size_t)a.erow[e];
-                    yy[2 * i] = (T)((double)yy[2 * i] - upd * (double)eval[e]);
+                    double y0, y1;
+                    row_state(a.erow[e], y0, y1);
+                    row_update(a.erow[e], y0, upd * (double)eval[e]);
                 }
             }
         }
@@ -926,8 +960,9 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 if (upd != 0.0) {
                     const int le0 = spb[q], le1 = spb[q + 1];
                     for (int e = le0 + wt; e < le1; e += 256) {
-                        const size_t i = (size_t)a.erow[e];
-                        yy[2 * i] = (T)((double)yy[2 * i] - upd * (double)eval[e]);
+                        double y0, y1;
+                        row_state(a.erow[e], y0, y1);
+                        row_update(a.erow[e], y0, upd * (double)eval[e]);
                     }
                 }
             }
@@ -941,7 +976,21 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
         c1 = c2;
         c2 = c3;
         c3 = c4;
+        if constexpr (LR != 0)  // rows in LDS: only LDS traffic has to land
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+            __syncthreads();
+    }
+    if constexpr (LR != 0) {  // write the row block back (LR == 1: yhat = r + y)
         __syncthreads();
+        const int nr = min(a.rows_per, a.n_rows - row0);
+        for (int il = tid; il < nr; il += kPrbThreads) {
+            const size_t i = (size_t)(row0 + il);
+            if constexpr (LR == 1)
+                yy[2 * i] = (T)((double)lds_r[il] + (double)yy[2 * i + 1]);
+            else
+                yy[2 * i] = lds_r[il];
+        }
     }
 }
 

@@ -216,10 +216,7 @@ int spfm_set_use_graph(spfm_handle h, int on);
  * applies to the next spfm_set_schedule), "persistent" (0/1: one persistent launch
  * per pcd component pass, single GPU; caps steps at 64 columns), "prb_groups"
  * (workgroups of the persistent pass), "prb_long" (entries of one column in one row
- * block above which the whole workgroup, not 4 lanes, processes it), "prb_exchange"
- * (per-step exchange of the persistent pass: 0 = every workgroup sweeps all partial
- * sums, the default; 1 = one owner workgroup per column adds them and publishes the
- * total), "prb_lds" (0/1, default 1: keep each workgroup's row block -- A and the
+ * block above which the whole workgroup, not 4 lanes, processes it), "prb_lds" (0/1, default 1: keep each workgroup's row block -- A and the
  * residual / prediction -- in LDS for the whole pass when it fits: f32 storage, one cache
  * value per row, squared loss or +-1 targets), "prb_stamps" (diagnostic phase timers),
  * "psgd_eager" (1: launch every psgd minibatch eagerly instead of replaying runs of 32 from

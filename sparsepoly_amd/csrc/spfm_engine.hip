@@ -193,7 +193,6 @@ struct spfm_engine {
     // persistent row-block pass (single GPU, pcd): one launch per component pass
     bool persistent = true;
     int prb_G = 64;
-    int prb_xmode = 0;  // granule exchange: 0 flat all-to-all sweep, 1 owner reduce
     bool prb_lds = true;  // keep the row block (A, residual) in LDS when it fits (f32, squared)
     int prb_lds_active = 0;  // what the last pcd pass actually used (0 / 1 residual / 2 sign)
     bool y_pm1 = false;      // every target is +1 or -1
@@ -1136,7 +1135,6 @@ struct spfm_engine {
         a.has_long = prb_has_long;
         a.erow = prb_erow.as<int32_t>();
         a.slab = prb_slab.as<double>();
-        a.xmode = prb_xmode;
         a.rows_per = (int)std::max<int64_t>((n + prb_G - 1) / prb_G, 1);
         a.n_rows = (int)n;
         a.abort_flag = prb_abort.as<unsigned>();
@@ -1156,6 +1154,12 @@ struct spfm_engine {
         // (squared loss: A + residual, 8 bytes per row; +-1 targets: A + yhat + sign, 9 bytes)
         constexpr bool can_lr = std::is_same<T, float>::value && Kind<M>::AS == 1;
         constexpr int LRV = (LOSS == LOSS_SQUARED) ? 1 : 2;
+        // the in-kernel phase timers exist as a separate instantiation of ONE configuration
+        // (float, degree 2, squared loss, rows in LDS): tools/prb_stamp_probe.py
+        constexpr bool can_stamp = std::is_same<T, float>::value && M == 2 && LOSS == LOSS_SQUARED;
+        if (prb_stamp_on && !(can_stamp && prb_lds))
+            FAIL(SPFM_ERR_UNSUPPORTED,
+                 "prb_stamps: built for float storage, degree 2, squared loss, prb_lds=1 only");
         const PrbArgs pa = prb_args();
         int lds_max = 0;
         HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
@@ -1188,11 +1192,25 @@ struct spfm_engine {
         bool launched = false;
         if constexpr (can_lr) {
             if (use_lr) {
-                hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, LRV>), dim3(prb_G),
-                                   dim3(kPrbThreads), lds_bytes, stream, c, pa, prb_eval.as<T>(),
-                                   A.as<T>(), (size_t)n * Kind<M>::AS, yy.as<T>(),
-                                   prow_old.as<double>(), Po, d, reg, cb, mu, beta, gamma, eta,
-                                   prb_viol.as<double>());
+                if constexpr (can_stamp) {
+                    if (prb_stamp_on) {
+                        HIPC(hipFuncSetAttribute(
+                            (const void*)pcd_prb_kernel<T, M, LOSS, LRV, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                        hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, LRV, true>), dim3(prb_G),
+                                           dim3(kPrbThreads), lds_bytes, stream, c, pa,
+                                           prb_eval.as<T>(), A.as<T>(), (size_t)n * Kind<M>::AS,
+                                           yy.as<T>(), prow_old.as<double>(), Po, d, reg, cb, mu,
+                                           beta, gamma, eta, prb_viol.as<double>());
+                        launched = true;
+                    }
+                }
+                if (!launched)
+                    hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, LRV>), dim3(prb_G),
+                                       dim3(kPrbThreads), lds_bytes, stream, c, pa,
+                                       prb_eval.as<T>(), A.as<T>(), (size_t)n * Kind<M>::AS,
+                                       yy.as<T>(), prow_old.as<double>(), Po, d, reg, cb, mu, beta,
+                                       gamma, eta, prb_viol.as<double>());
                 launched = true;
             }
         }
@@ -2078,12 +2096,6 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->pbcd_fuse = value != 0;
     } else if (k == "prb_lds") {
         h->prb_lds = value != 0;
-    } else if (k == "prb_exchange") {
-        if (value != 0 && value != 1) {
-            h->err = "prb_exchange must be 0 (flat sweep) or 1 (owner reduce)";
-            return SPFM_ERR_INVALID;
-        }
-        h->prb_xmode = value;
     } else if (k == "prb_groups") {
         if (value < 1) {
             h->err = "prb_groups must be >= 1";
@@ -2113,7 +2125,6 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "max_batch") *value = h->max_batch_opt;
     else if (k == "persistent") *value = h->persistent;
     else if (k == "prb_groups") *value = h->prb_G;
-    else if (k == "prb_exchange") *value = h->prb_xmode;
     else if (k == "prb_lds") *value = h->prb_lds;
     else if (k == "psgd_redone") *value = h->psgd_redone;
     else if (k == "prb_lds_active") *value = h->prb_lds_active;

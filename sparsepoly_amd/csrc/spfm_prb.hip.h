@@ -39,8 +39,7 @@ struct PrbArgs {
     const uint32_t* lmask; // [G][nb][2] bit q: slot q is "long" in this row block
     int has_long;          // 0: no long slot anywhere in the schedule (masks not even read)
     const int32_t* erow;   // entry row ids, sorted by (workgroup, batch, slot, row)
-    double* slab;          // [2][G][64][2] partial sums, then [2][64][2] totals (xmode 1)
-    int xmode;             // exchange: 0 = every workgroup sweeps all slabs; 1 = owner reduce
+    double* slab;          // [2][G][64][2] partial sums (parity double-buffered)
     int rows_per;          // rows per workgroup (row block g = [g*rows_per, (g+1)*rows_per))
     int n_rows;            // n_samples
     unsigned* abort_flag;  // [1]
@@ -80,73 +79,6 @@ __device__ __forceinline__ void prb_store_granule(double* p, double v, unsigned 
 __device__ __forceinline__ unsigned long long prb_load_granule(const double* p) {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Poll NV adjacent granules until all carry `tag`; bounded, sets the abort word on time-out.
-template <int NV>
-__device__ __forceinline__ bool prb_poll(const PrbArgs& a, const double* p,
-                                         unsigned long long tag, double* out) {
-    unsigned long long t[NV];
-    unsigned spins = 0;
-    for (;;) {
-        bool all = true;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            t[v] = prb_load_granule(p + v);
-            all = all && ((t[v] & 3ull) == tag);
-        }
-        if (all) break;
-        if ((++spins & 63u) == 0) {
-            if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-                spins > (1u << 21)) {
-                __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-    }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) out[v] = __longlong_as_double((long long)(t[v] & ~3ull));
-    return true;
-}
-
-// Owner-reduce exchange (xmode 1), executed by the control wave.  Slot q belongs to
-// workgroup q % G: its control wave gathers the G partials of the slot (lane = source
-// workgroup), adds them in a fixed butterfly order and publishes ONE total granule per
-// value; then every control wave reads the <= 64 totals (lane = slot).  Two dependent
-// fabric hops, but 2 x 64 granule loads per workgroup and step instead of G x 64: the flat
-// sweep is bound by the number of uncached fabric transactions, not by their latency.
-// Every owner publishes every step (unused slots carry zeros), so a total word is always
-// rewritten before its tag value comes round again.
-template <int NV>
-__device__ __forceinline__ bool prb_owner_exchange(const PrbArgs& a, int b, int g, int lane,
-                                                   int ncols, double* tot) {
-    const double* slabA = a.slab + (size_t)(b & 1) * a.G * 64 * 2;
-    double* slabB = a.slab + (size_t)2 * a.G * 64 * 2 + (size_t)(b & 1) * 64 * 2;
-    const unsigned long long tag = prb_tag(b);
-    bool ok = true;
-    for (int q = g; q < 64; q += a.G) {
-        double acc[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-        for (int src = lane; src < a.G; src += 64) {
-            double val[NV];
-            if (!prb_poll<NV>(a, slabA + ((size_t)src * 64 + q) * 2, tag, val)) ok = false;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) acc[v] += ok ? val[v] : 0.0;
-        }
-#pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = wave_sum(acc[v]);
-        if (lane == 0) {
-#pragma unroll
-            for (int v = 0; v < NV; ++v) prb_store_granule(slabB + (size_t)q * 2 + v, acc[v], tag);
-        }
-    }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) tot[v] = 0.0;
-    if (lane < ncols) {
-        if (!prb_poll<NV>(a, slabB + (size_t)lane * 2, tag, tot)) ok = false;
-    }
-    return __all(ok) != 0;
 }
 
 // Sweeping wave `w` (0..nparts-1) sums the granules of workgroups [w*G/nparts,
@@ -327,7 +259,9 @@ constexpr int kPrbLdsFixed = 2560;  // doubles of fixed LDS (control data, part 
 //            written back as yhat = r + y.
 //   LR == 2 (targets are +-1, any loss): the word is yhat_i, the label's sign is one byte.
 // The block is loaded at the start and written back at the end of the launch.
-template <typename T, int M, int LOSS, int LR>
+// STAMP = true compiles the in-kernel phase timers in (diagnostic build of one
+// configuration); as a runtime switch they cost 5 % of every step.
+template <typename T, int M, int LOSS, int LR, bool STAMP = false>
 __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     const Ctl* __restrict__ ctl, PrbArgs a, const T* __restrict__ eval, T* __restrict__ A_all,
     size_t a_stride, T* __restrict__ yy, const double* __restrict__ pold_sched,
@@ -395,20 +329,23 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         *sh_go = 0;
     }
     // diagnostic stamps (only when a.stamps != nullptr): cycles per phase, thread 0
-    const bool stamp = a.stamps != nullptr;
     long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tprev = stamp ? clock64() : 0;
+    long long tprev = STAMP ? clock64() : 0;
 #define PRB_STAMP(k)                        \
-    if (stamp && tid == 0) {                \
-        const long long tn = clock64();     \
-        acc[k] += tn - tprev;               \
-        tprev = tn;                         \
+    if constexpr (STAMP) {                  \
+        if (tid == 0) {                     \
+            const long long tn = clock64(); \
+            acc[k] += tn - tprev;           \
+            tprev = tn;                     \
+        }                                   \
     }
 #define PRB_WSTAMP(k)                       \
-    if (stamp && tid == 64) {               \
-        const long long tn = clock64();     \
-        acc[k] += tn - tprev;               \
-        tprev = tn;                         \
+    if constexpr (STAMP) {                  \
+        if (tid == 64) {                    \
+            const long long tn = clock64(); \
+            acc[k] += tn - tprev;           \
+            tprev = tn;                     \
+        }                                   \
     }
 
     for (int b = 0; b < a.nb; ++b) {
@@ -569,7 +506,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt, row0);
                 if (slot < c2 - c1) p_next = pold_sched[c1 + slot];
             }
-            if (a.xmode == 0) {
+            {
                 const bool ok =
                     prb_collect_quarter<2>(a, b, part, lane, ncols, sh_quart, kPrbParts);
                 if (!ok) *sh_ok = 0;
@@ -582,7 +519,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt, row0);
                 if (slot < c2 - c1) p_next = pold_sched[c1 + slot];
             }
-        } else if (a.xmode == 0) {
+        } else {
             // control wave and helpers: their parts of the sweep, once the own workers have
             // published (the other workgroups are at the same point of the step)
             unsigned spins = 0;
@@ -597,23 +534,17 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         // prefetch loads just issued stay in flight across it (a __syncthreads() would
         // add s_waitcnt vmcnt(0) and expose their HBM latency on every step).
         PRB_WSTAMP(3)  // prefetch issue
-        if (a.xmode == 0) {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (!*sh_ok) break;
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!*sh_ok) break;
         PRB_STAMP(3)
         PRB_WSTAMP(4)  // B3
         if (control) {
             double tot[2];
-            if (a.xmode == 0) {
 #pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    tot[v] = sh_quart[lane * 2 + v];
+            for (int v = 0; v < 2; ++v) {
+                tot[v] = sh_quart[lane * 2 + v];
 #pragma unroll
-                    for (int w = 1; w < kPrbParts; ++w) tot[v] += sh_quart[(w * 64 + lane) * 2 + v];
-                }
-            } else if (!prb_owner_exchange<2>(a, b, g, lane, ncols, tot)) {
-                *sh_ok = 0;
+                for (int w = 1; w < kPrbParts; ++w) tot[v] += sh_quart[(w * 64 + lane) * 2 + v];
             }
             const bool valid = lane < ncols;
             const double res = pcd_chain_lanes<M>(reg, lane, ncols - 1, valid, pl, tot[0], tot[1],
@@ -628,7 +559,6 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             PRB_STAMP(4)
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B4: deltas in LDS
-        if (a.xmode != 0 && !*sh_ok) break;
         PRB_STAMP(5)
         PRB_WSTAMP(5)  // waiting for the control wave's chain
         // ---- phase 3 (workers): scatter-update of the own rows (pcd.py:124-133)
@@ -732,7 +662,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 yy[2 * i] = lds_r[il];
         }
     }
-    if (stamp && (tid == 0 || tid == 64)) {
+    if (STAMP && a.stamps != nullptr && (tid == 0 || tid == 64)) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) a.stamps[(size_t)g * 16 + (tid == 64 ? 8 : 0) + q] = acc[q];
     }
@@ -880,7 +810,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
             if (tid == 64 + 255)
                 __hip_atomic_store(sh_go, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
-            if (a.xmode == 0) {
+            {
                 const bool ok =
                     prb_collect_quarter<1>(a, b, part, lane, ncols, sh_quart, kPrbParts);
                 if (!ok) *sh_ok = 0;
@@ -888,7 +818,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
             if (b + 1 < a.nb) {
                 prb_load_entries<T>(a, eval, ne0, ne1, sub, nxt, row0);
             }
-        } else if (a.xmode == 0) {  // helpers: their parts, once the workers have published
+        } else if (!control) {  // helpers: their parts, once the workers have published
             if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
             unsigned spins = 0;
             while (__hip_atomic_load(sh_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
@@ -900,7 +830,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
         }
         if (control) {
             if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
-            if (a.xmode == 0) {
+            {
                 unsigned spins = 0;
                 while (__hip_atomic_load(sh_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
                            b + 1 &&
@@ -911,19 +841,12 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 if (!ok) *sh_ok = 0;
             }
         }
-        if (a.xmode == 0) {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // part sums in LDS
-            if (!*sh_ok) break;
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // part sums in LDS
+        if (!*sh_ok) break;
         if (control) {
-            double tot;
-            if (a.xmode == 0) {
-                tot = sh_quart[lane * 2];
+            double tot = sh_quart[lane * 2];
 #pragma unroll
-                for (int w = 1; w < kPrbParts; ++w) tot += sh_quart[(w * 64 + lane) * 2];
-            } else if (!prb_owner_exchange<1>(a, b, g, lane, ncols, &tot)) {
-                *sh_ok = 0;
-            }
+            for (int w = 1; w < kPrbParts; ++w) tot += sh_quart[(w * 64 + lane) * 2];
             const bool valid = lane < ncols;
             double upd = tot;           // cd_linear.py:19-24
             upd += alpha * wl;
@@ -937,7 +860,6 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // updates in LDS
-        if (a.xmode != 0 && !*sh_ok) break;
         if (slot < ncols) {
             const double upd = sh_delta[slot];
             if (upd != 0.0) {
@@ -1025,6 +947,33 @@ __global__ __launch_bounds__(kWave) void hop_pingpong_kernel(unsigned long long*
             __hip_atomic_store(mine, (unsigned long long)r, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// Poll NV adjacent granules until all carry `tag`; bounded, sets the abort word on time-out.
+template <int NV>
+__device__ __forceinline__ bool prb_poll(const PrbArgs& a, const double* p,
+                                         unsigned long long tag, double* out) {
+    unsigned long long t[NV];
+    unsigned spins = 0;
+    for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            t[v] = prb_load_granule(p + v);
+            all = all && ((t[v] & 3ull) == tag);
+        }
+        if (all) break;
+        if ((++spins & 63u) == 0) {
+            if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                spins > (1u << 21)) {
+                __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[v] = __longlong_as_double((long long)(t[v] & ~3ull));
+    return true;
 }
 
 // ---- diagnostic: cost of the bare all-to-all exchange ---------------------------------

@@ -39,7 +39,7 @@ def _case(seed):
     if rng.rand() < 0.3:
         opts["max_batch"] = int(rng.choice([1, 2, 7, 64]))
     if rng.rand() < 0.2:
-        opts["prb_exchange"] = 1
+        opts["prb_lds"] = 0
     if rng.rand() < 0.2:
         opts["prb_long"] = 16
     sched = "colored" if rng.rand() < 0.6 else "exact"

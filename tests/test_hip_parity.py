@@ -210,8 +210,8 @@ def test_graph_replay_equals_eager(case):
 
 @pytest.mark.parametrize("options", [{"persistent": 0}, {"persistent": 0, "fuse_chain": 0},
                                      {"prb_groups": 3}, {"prb_groups": 256}, {"max_batch": 3},
-                                     {"prb_exchange": 1}, {"prb_exchange": 1, "prb_groups": 5},
-                                     {"prb_exchange": 1, "prb_groups": 200},
+                                     {"prb_lds": 0}, {"prb_lds": 0, "prb_groups": 5},
+                                     {"prb_groups": 200},
                                      {"max_batch": 1, "fuse_chain": 0, "persistent": 0}])
 @pytest.mark.parametrize("case", ["c2|squared", "c3|logistic", "c4d3|squared"])
 def test_engine_options_do_not_change_results(oracle, case, options):

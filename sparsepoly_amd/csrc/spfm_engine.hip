@@ -1169,14 +1169,6 @@ struct spfm_engine {
                             (LRV == 1 || y_pm1);
         const size_t lds_bytes = use_lr ? std::max(lds_lr, kPrbLds) : kPrbLds;
         prb_lds_active = use_lr ? LRV : 0;
-        if constexpr (can_lr) {
-            if (use_lr)
-                HIPC(hipFuncSetAttribute((const void*)pcd_prb_kernel<T, M, LOSS, LRV>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds_bytes));
-        }
-        HIPC(hipFuncSetAttribute((const void*)pcd_prb_kernel<T, M, LOSS, 0>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrbLds));
         hipLaunchKernelGGL(begin_pass_kernel, dim3(1), dim3(64), 0, stream, c,
                            comp_order.as<int32_t>(), lams.as<double>());
         if (reg != SPFM_REG_L1) {
@@ -1189,36 +1181,51 @@ struct spfm_engine {
                            d_desc.as<ColDesc>(), prow_old.as<double>());
         HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));  // tag 0 = "not yet"
         prof_begin(0, nnz);
+        // one instantiation per (rows in LDS?, timers?, regularizer): the fast configuration
+        // (float, one cache value per row) gets the regularizer as a compile-time constant
+        auto go = [&](auto lr_tag, auto stamp_tag, auto reg_tag) -> int {
+            constexpr int LRc = decltype(lr_tag)::value;
+            constexpr bool STc = decltype(stamp_tag)::value;
+            constexpr int RGc = decltype(reg_tag)::value;
+            const size_t lds = LRc != 0 ? lds_bytes : kPrbLds;
+            HIPC(hipFuncSetAttribute((const void*)pcd_prb_kernel<T, M, LOSS, LRc, STc, RGc>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, LRc, STc, RGc>), dim3(prb_G),
+                               dim3(kPrbThreads), lds, stream, c, pa, prb_eval.as<T>(), A.as<T>(),
+                               (size_t)n * Kind<M>::AS, yy.as<T>(), prow_old.as<double>(), Po, d,
+                               reg, cb, mu, beta, gamma, eta, prb_viol.as<double>());
+            return SPFM_OK;
+        };
+        using std::integral_constant;
+        int lrc = SPFM_OK;
         bool launched = false;
         if constexpr (can_lr) {
             if (use_lr) {
-                if constexpr (can_stamp) {
-                    if (prb_stamp_on) {
-                        HIPC(hipFuncSetAttribute(
-                            (const void*)pcd_prb_kernel<T, M, LOSS, LRV, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-                        hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, LRV, true>), dim3(prb_G),
-                                           dim3(kPrbThreads), lds_bytes, stream, c, pa,
-                                           prb_eval.as<T>(), A.as<T>(), (size_t)n * Kind<M>::AS,
-                                           yy.as<T>(), prow_old.as<double>(), Po, d, reg, cb, mu,
-                                           beta, gamma, eta, prb_viol.as<double>());
-                        launched = true;
-                    }
-                }
-                if (!launched)
-                    hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, LRV>), dim3(prb_G),
-                                       dim3(kPrbThreads), lds_bytes, stream, c, pa,
-                                       prb_eval.as<T>(), A.as<T>(), (size_t)n * Kind<M>::AS,
-                                       yy.as<T>(), prow_old.as<double>(), Po, d, reg, cb, mu, beta,
-                                       gamma, eta, prb_viol.as<double>());
                 launched = true;
+                if constexpr (can_stamp) {
+                    if (prb_stamp_on)
+                        lrc = go(integral_constant<int, LRV>{}, std::true_type{},
+                                 integral_constant<int, -1>{});
+                }
+                if (!prb_stamp_on) {
+                    if (reg == SPFM_REG_L1)
+                        lrc = go(integral_constant<int, LRV>{}, std::false_type{},
+                                 integral_constant<int, REG_L1>{});
+                    else if (reg == SPFM_REG_OMEGATI)
+                        lrc = go(integral_constant<int, LRV>{}, std::false_type{},
+                                 integral_constant<int, REG_OMEGATI>{});
+                    else if constexpr (M == 2)
+                        lrc = go(integral_constant<int, LRV>{}, std::false_type{},
+                                 integral_constant<int, REG_SQL12>{});
+                    else
+                        lrc = go(integral_constant<int, LRV>{}, std::false_type{},
+                                 integral_constant<int, -1>{});
+                }
             }
         }
         if (!launched)
-            hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, 0>), dim3(prb_G), dim3(kPrbThreads),
-                               kPrbLds, stream, c, pa, prb_eval.as<T>(), A.as<T>(),
-                               (size_t)n * Kind<M>::AS, yy.as<T>(), prow_old.as<double>(), Po, d,
-                               reg, cb, mu, beta, gamma, eta, prb_viol.as<double>());
+            lrc = go(integral_constant<int, 0>{}, std::false_type{}, integral_constant<int, -1>{});
+        if (lrc) return lrc;
         prof_end(0);
         hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
                            d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());

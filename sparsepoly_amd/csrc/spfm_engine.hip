@@ -26,6 +26,9 @@ void schedule_colored(int64_t, int32_t, const int64_t*, const int32_t*, const in
                       std::vector<int32_t>&, std::vector<int32_t>&);
 void csc_to_csr(int64_t, int32_t, const int64_t*, const int32_t*, std::vector<int64_t>&,
                 std::vector<int32_t>&, std::vector<int64_t>&);
+void build_pb_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
+                     const std::vector<int32_t>&, int, int, std::vector<int32_t>&,
+                     std::vector<int32_t>&, std::vector<uint8_t>&);
 void build_rowblock_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
                            const std::vector<int32_t>&, int, int, std::vector<int32_t>&,
                            std::vector<int32_t>&, std::vector<uint32_t>&);
@@ -203,6 +206,17 @@ struct spfm_engine {
         prb_viol, prb_cn, prb_lmask;
     bool prb_stamp_on = false;
     static constexpr size_t kPrbLds = 84 * 1024;  // > half of the CU's 160 KiB: 1 WG per CU
+    // persistent pbcd pass (spfm_pbprb.hip.h): its own workgroup count, hence its own entry
+    // stream when that differs from the pcd / cd_linear pass's
+    bool pb_persistent = true;
+    int pbprb_G = 128;
+    bool pb_stream_ready = false;
+    int pb_stream_G = 0, pb_stream_NG = 0;
+    DevBuf pb_sp, pb_erow, pb_eval, pb_meta, pb_slabA, pb_slabB, pb_slabC, pb_stamps;
+    bool pb_stamp_on = false;
+    int pbprb_active = 0;  // what the last pbcd epoch used
+    int pb_dbg = 0;
+    DevBuf pb_dbgbuf;
     std::map<std::string, hipGraphExec_t> graphs;
 
     // comm
@@ -701,6 +715,7 @@ struct spfm_engine {
         HIPC(hipStreamSynchronize(stream));
         have_schedule = true;
         prb_ready = false;
+        pb_stream_ready = false;
         ++sched_version;
         clear_graphs();
         return alloc_work();
@@ -1271,6 +1286,18 @@ struct spfm_engine {
         return SPFM_OK;
     }
 
+    int pb_check_abort() {
+        unsigned flag = 0;
+        HIPC(hipMemcpyAsync(&flag, prb_abort.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        HIPC(hipStreamSynchronize(stream));
+        if (flag) {
+            (void)hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream);
+            FAIL(SPFM_ERR_RUNTIME,
+                 "persistent pbcd pass timed out waiting for its workgroups (not all resident?)");
+        }
+        return SPFM_OK;
+    }
+
     // template parameter for a reference degree: -1 (all-subsets) -> 0
     static int kind_of(int degree) { return degree == -1 ? 0 : degree; }
     bool degree_ok(int degree) const {
@@ -1424,6 +1451,147 @@ struct spfm_engine {
         return SPFM_OK;
     }
 
+    // ------------------------------------------------ persistent pbcd pass (one launch)
+    static bool pbprb_degree_ok(int M) { return M == 0 || M == 2 || M == 3 || M == 4; }
+    bool pbprb_usable(int M) const {
+        return persistent && pb_persistent && !dist() && max_batch_cols <= 64 &&
+               nnz < ((int64_t)1 << 31) && n > 0 && k <= 62 && pbprb_degree_ok(M);
+    }
+
+    // entry stream (workgroup, step, slot, row) for G row blocks; shares the pcd pass's when
+    // the workgroup counts agree
+    template <typename T>
+    int ensure_pb_stream(int NG) {
+        int ncu = 0;
+        HIPC(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        int G = std::max(1, std::min(pbprb_G, ncu));
+        if (pb_stream_ready && pb_stream_G == G && pb_stream_NG == NG) return SPFM_OK;
+        std::vector<int32_t> gsp, src;
+        std::vector<uint8_t> meta;
+        build_pb_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, G, NG, gsp, src, meta);
+        DevBuf d_src;
+        HIPC(d_src.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+        HIPC(pb_sp.alloc(sizeof(int32_t) * gsp.size()));
+        HIPC(pb_erow.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1) + 256));
+        HIPC(pb_eval.alloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1) + 256));
+        HIPC(pb_meta.alloc((size_t)(nnz > 0 ? nnz : 1) + 256));
+        HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
+        HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
+        HIPC(pb_stamps.alloc(sizeof(long long) * 16 * (size_t)G));
+        HIPC(hipMemsetAsync(pb_stamps.p, 0, pb_stamps.bytes, stream));
+        HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
+        HIPC(hipMemcpyAsync(pb_sp.p, gsp.data(), sizeof(int32_t) * gsp.size(),
+                            hipMemcpyHostToDevice, stream));
+        if (nnz > 0) {
+            HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * (size_t)nnz,
+                                hipMemcpyHostToDevice, stream));
+            HIPC(hipMemcpyAsync(pb_meta.p, meta.data(), (size_t)nnz, hipMemcpyHostToDevice,
+                                stream));
+            hipLaunchKernelGGL((prb_gather_kernel<T>), dim3(cdiv(nnz, 256)), dim3(256), 0, stream,
+                               nnz, d_src.as<int32_t>(), cidx.as<int32_t>(), cval.as<T>(),
+                               pb_erow.as<int32_t>(), pb_eval.as<T>());
+            HIPC(hipGetLastError());
+        }
+        HIPC(hipStreamSynchronize(stream));
+        pb_stream_G = G;
+        pb_stream_NG = NG;
+        pb_stream_ready = true;
+        return SPFM_OK;
+    }
+
+    template <typename T, int M, int L>
+    int pbcd_prb_l(int order_idx, double beta, double gamma, double eta) {
+        const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
+        double* Po = Pt.as<double>() + (size_t)order_idx * k * d;  // (d,k)
+        RegState rs = regstate();
+        int rc = ensure_pb_stream<T>(kPbPrbThreads / L);
+        if (rc) return rc;
+        const int G = pb_stream_G;
+        hipLaunchKernelGGL((pbcd_precompute_kernel<T, M>), dim3(cdiv(n * k, kBlock)), dim3(kBlock),
+                           0, stream, n, k, rptr.as<int64_t>(), ridx.as<int32_t>(), rval.as<T>(),
+                           Po, A.as<T>());
+        const bool chained = (reg == SPFM_REG_SQUAREDL21 || reg == SPFM_REG_OMEGACS);
+        if (chained) {
+            hipLaunchKernelGGL(pbcd_norms_kernel, dim3(cdiv((int64_t)d * 64, kBlock)),
+                               dim3(kBlock), 0, stream, d, k, Po, rs.norms);
+            hipLaunchKernelGGL((pbcd_compute_cache_kernel<M>), dim3(1), dim3(kBlock), 0, stream, d,
+                               reg, rs);
+        }
+        HIPC(pb_slabA.alloc(sizeof(double) * 2 * 64 * (size_t)G * L));
+        HIPC(pb_slabB.alloc(sizeof(double) * 2 * 64 * L));
+        HIPC(hipMemsetAsync(pb_slabA.p, 0, sizeof(double) * 2 * 64 * (size_t)G * L, stream));
+        HIPC(hipMemsetAsync(pb_slabB.p, 0, sizeof(double) * 2 * 64 * L, stream));
+        PbPrbArgs a;
+        a.G = G;
+        a.nb = n_batches();
+        a.bptr = d_bptr.as<int32_t>();
+        a.jsched = d_order.as<int32_t>();
+        a.gsp = pb_sp.as<int32_t>();
+        a.erow = pb_erow.as<int32_t>();
+        a.emeta = pb_meta.as<uint8_t>();
+        a.slabA = pb_slabA.as<double>();
+        a.slabB = pb_slabB.as<double>();
+        a.rows_per = (int)std::max<int64_t>((n + G - 1) / G, 1);
+        a.n_rows = (int)n;
+        a.abort_flag = prb_abort.as<unsigned>();
+        a.n_ranks = 1;
+        a.rank = 0;
+        a.slabC = nullptr;
+        a.stamps = pb_stamp_on ? pb_stamps.as<long long>() : nullptr;
+        a.dbg = pb_dbg;
+        HIPC(pb_dbgbuf.alloc(sizeof(unsigned) * (16 + 4096)));
+        if (pb_dbg & 8) HIPC(hipMemsetAsync(pb_dbgbuf.p, 0, sizeof(unsigned) * (16 + 4096), stream));
+        if (pb_dbg & 8) {
+            unsigned init[16] = {0, 0, 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            HIPC(hipMemcpyAsync(pb_dbgbuf.p, init, sizeof init, hipMemcpyHostToDevice, stream));
+        }
+        a.dbg_out = pb_dbgbuf.as<unsigned>();
+        const int ncache = top_degree > 0 ? top_degree + 1 : 1;
+        prof_begin(2, nnz);
+        auto go = [&](auto stamp_tag) -> int {
+            constexpr bool STc = decltype(stamp_tag)::value;
+            const size_t lds = std::max(kPrbLds, pbcd_prb_lds_bytes<T, M, L>());
+            HIPC(hipFuncSetAttribute((const void*)pbcd_prb_kernel<T, M, L, STc>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((pbcd_prb_kernel<T, M, L, STc>), dim3(G), dim3(kPbPrbThreads),
+                               lds, stream, a, pb_eval.as<T>(), A.as<T>(), yy.as<T>(), Po, k, d,
+                               lams.as<double>(), loss, reg, rs, ncache, mu, beta, gamma, eta,
+                               prb_viol.as<double>());
+            return SPFM_OK;
+        };
+        constexpr bool can_stamp = std::is_same<T, float>::value && M == 2 && L == 32;
+        if (pb_stamp_on && !can_stamp)
+            FAIL(SPFM_ERR_UNSUPPORTED, "pbprb_stamps: built for float storage, degree 2, k <= 30");
+        if constexpr (can_stamp) {
+            rc = pb_stamp_on ? go(std::true_type{}) : go(std::false_type{});
+        } else {
+            rc = go(std::false_type{});
+        }
+        if (rc) return rc;
+        prof_end(2);
+        hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
+                           d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+
+    template <typename T, int M>
+    int pbcd_prb_m(int order_idx, double beta, double gamma, double eta) {
+        if (k <= 30) return pbcd_prb_l<T, M, 32>(order_idx, beta, gamma, eta);
+        return pbcd_prb_l<T, M, 64>(order_idx, beta, gamma, eta);
+    }
+
+    template <typename T>
+    int pbcd_prb_dispatch(int M, int order_idx, double beta, double gamma, double eta) {
+        switch (M) {
+            case 0: return pbcd_prb_m<T, 0>(order_idx, beta, gamma, eta);
+            case 2: return pbcd_prb_m<T, 2>(order_idx, beta, gamma, eta);
+            case 3: return pbcd_prb_m<T, 3>(order_idx, beta, gamma, eta);
+            case 4: return pbcd_prb_m<T, 4>(order_idx, beta, gamma, eta);
+        }
+        FAIL(SPFM_ERR_UNSUPPORTED, "persistent pbcd pass: degree outside {2,3,4,all-subsets}");
+    }
+
     template <typename T, int M>
     int pbcd_body(int order_idx, double beta, double gamma, double eta) {
         if (k <= 8) return pbcd_body_lc<T, M, 8, 1>(order_idx, beta, gamma, eta);
@@ -1457,6 +1625,17 @@ struct spfm_engine {
         rc = ensure_pt();
         if (rc) return rc;
         p_valid = false;
+        pbprb_active = 0;
+        if (pbprb_usable(kind_of(degree))) {
+            pbprb_active = 1;
+            rc = dtype == SPFM_F32
+                     ? pbcd_prb_dispatch<float>(kind_of(degree), order_idx, beta, gamma, eta)
+                     : pbcd_prb_dispatch<double>(kind_of(degree), order_idx, beta, gamma, eta);
+            if (rc) return rc;
+            rc = epoch_epilogue(viol);
+            if (rc) return rc;
+            return pb_check_abort();
+        }
         const std::string key = fkey("pbcd", {beta, gamma, eta},
                                      {order_idx, degree, loss, reg, sched_version});
         rc = run_cached(key, [&]() {
@@ -2101,6 +2280,19 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->psgd_force_eager = value != 0;
     } else if (k == "pbcd_fuse") {
         h->pbcd_fuse = value != 0;
+    } else if (k == "pbcd_persistent") {
+        h->pb_persistent = value != 0;
+    } else if (k == "pbprb_dbg") {
+        h->pb_dbg = value;
+    } else if (k == "pbprb_stamps") {
+        h->pb_stamp_on = value != 0;
+    } else if (k == "pbprb_groups") {
+        if (value < 1) {
+            h->err = "pbprb_groups must be >= 1";
+            return SPFM_ERR_INVALID;
+        }
+        h->pbprb_G = value;
+        h->pb_stream_ready = false;
     } else if (k == "prb_lds") {
         h->prb_lds = value != 0;
     } else if (k == "prb_groups") {
@@ -2135,6 +2327,9 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "prb_lds") *value = h->prb_lds;
     else if (k == "psgd_redone") *value = h->psgd_redone;
     else if (k == "prb_lds_active") *value = h->prb_lds_active;
+    else if (k == "pbcd_persistent") *value = h->pb_persistent;
+    else if (k == "pbprb_groups") *value = h->pbprb_G;
+    else if (k == "pbprb_active") *value = h->pbprb_active;
     else if (k == "persistent_active") *value = h->have_schedule && h->prb_usable();
     else {
         h->err = "unknown option: " + k;
@@ -2145,6 +2340,22 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
 
 int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap) {
     GUARD(h);
+    if ((h->pb_dbg & 8) && out && cap >= 8) {  // diagnostic counters of the persistent pbcd pass
+        static unsigned v[16 + 4096];
+        if (hipMemcpy(v, h->pb_dbgbuf.p, sizeof v, hipMemcpyDeviceToHost) != hipSuccess)
+            return SPFM_ERR_RUNTIME;
+        int i = 0;
+        for (; i < 16 + 4096 && i < cap; ++i) out[i] = (long long)v[i];
+        return i - (i % 16);
+    }
+    if (h->pb_stamp_on && h->pb_stream_ready && out) {  // persistent pbcd pass's timers
+        const int nv = 16 * h->pb_stream_G;
+        if (cap < nv) return SPFM_ERR_INVALID;
+        if (hipMemcpy(out, h->pb_stamps.p, sizeof(long long) * (size_t)nv,
+                      hipMemcpyDeviceToHost) != hipSuccess)
+            return SPFM_ERR_RUNTIME;
+        return nv;
+    }
     if (!h->prb_ready || !out) return SPFM_ERR_INVALID;
     const int nval = 16 * h->prb_G;
     if (cap < nval) return SPFM_ERR_INVALID;

@@ -288,236 +288,23 @@ __device__ __forceinline__ void pbcd_prep_col(
 // serial loop; writes the shrink factor f into scal[q][2] and the new block norm into
 // norms[j].  Fallback branches ("numerical error": squaredl21.py:48-49,
 // omegacs.py:75-76,90-96) recompute from all d norms with the whole wave.
-template <int M, bool COH>
-__device__ __forceinline__ void pbcd_chain_body(
-    int lane, const ColDesc* __restrict__ desc, int ncols, int d, int reg, RegState rs,
-    int top_ncache, double* __restrict__ scal) {
-    double cache[kMaxDegree + 2], dcache[kMaxDegree + 2];
-    {   // one vector load each, then broadcast (the state is wave-uniform)
-        const double cv = (lane < top_ncache) ? rs.cache[lane] : 0.0;
-        const double dv = (lane < top_ncache) ? rs.dcache[lane] : 0.0;
+// The wave-uniform regularizer state (cache, dcache) lives in registers: loaded by
+// pbcd_chain_load, advanced by pbcd_chain_core (one call per dependent step), written back by
+// pbcd_chain_store.  The per-step kernels do all three per launch; the persistent pass keeps
+// the state in the control wave's registers for the whole sweep.
+__device__ __forceinline__ void pbcd_chain_load(int lane, RegState rs, int top_ncache,
+                                                double* cache, double* dcache) {
+    // one vector load each, then broadcast (the state is wave-uniform)
+    const double cv = (lane < top_ncache) ? rs.cache[lane] : 0.0;
+    const double dv = (lane < top_ncache) ? rs.dcache[lane] : 0.0;
 #pragma unroll
-        for (int t = 0; t < kMaxDegree + 2; ++t) {
-            cache[t] = readlane_d(cv, t);
-            dcache[t] = readlane_d(dv, t);
-        }
+    for (int t = 0; t < kMaxDegree + 2; ++t) {
+        cache[t] = readlane_d(cv, t);
+        dcache[t] = readlane_d(dv, t);
     }
-    for (int base = 0; base < ncols; base += kWave) {
-        const int q = base + lane;
-        const bool valid = q < ncols;
-        const int cnt = min(kWave, ncols - base);
-        int j = 0;
-        double l2 = 0.0, st0 = 0.0, njl = 0.0;
-        if (valid) {
-            j = desc[q].j;
-            l2 = pb_ld<COH>(&scal[4 * q + 0]);
-            st0 = pb_ld<COH>(&scal[4 * q + 1]);
-            njl = rs.norms[j];
-        }
-        if constexpr (M == 2) {
-            // Degree 2: the cache is one scalar c (= sum of block norms) and column i maps it
-            // through c' = (c - n_i) + max(l2_i - t_i (c - n_i), 0), t_i = st0 (omegacs) or
-            // 2 st0 / (1 + 2 st0) (squaredl21): the same piecewise-affine recurrence as
-            // pcd's squaredl12, solved by the speculative affine scan.  If any column would
-            // take one of the reference's "numerical error" branches the chunk is redone by
-            // the serial loop below, which restates them.
-            const double c0 = (reg == REG_SQL21) ? cache[0] : cache[1];
-            const double tt = (reg == REG_SQL21) ? (2 * st0 / (1.0 + 2 * st0)) : st0;
-            bool nz = valid && (l2 - tt * (c0 - njl)) > 0;
-            double cb = c0, m = 0.0, al = 1.0, be = 0.0;
-            for (int round = 0; round <= kWave; ++round) {
-                al = valid ? (nz ? (1.0 - tt) : 1.0) : 1.0;
-                be = valid ? (nz ? (l2 - (1.0 - tt) * njl) : -njl) : 0.0;
-                affine_scan_inclusive(al, be, lane);
-                cb = affine_before(al, be, c0, lane);
-                m = l2 - tt * (cb - njl);
-                const bool nz2 = m > 0;
-                const unsigned long long bad = __ballot(valid && (nz2 != nz));
-                nz = nz2;
-                if (bad == 0ull) break;
-            }
-            const double l2n = (valid && nz) ? m : 0.0;
-            const double dc2 = cb - njl;  // dcache[2] (omegacs) / dcache (squaredl21)
-            // cache[2] += dcache[2] * l2n - dcache[2] * n_j per column (omegacs.py:71-73)
-            double c2term = (valid && reg == REG_OMEGACS) ? (dc2 * l2n - dc2 * njl) : 0.0;
-            double c2pre = c2term;  // inclusive prefix sum
-#pragma unroll
-            for (int o = 1; o < kWave; o <<= 1) {
-                const double v = __shfl_up(c2pre, o, kWave);
-                if (lane >= o) c2pre += v;
-            }
-            const double c_after = al * c0 + be;  // cache after this column
-            const bool trouble = valid && ((dc2 < 0) || (c_after < 0) ||
-                                           (reg == REG_OMEGACS && cache[2] + c2pre < 0));
-            if (__ballot(trouble) == 0ull) {
-                const double f = (valid && nz) ? (1.0 - (tt * dc2) / l2) : 0.0;
-                if (valid) {
-                    scal[4 * q + 2] = f;
-                    rs.norms[j] = l2n;  // = l2 - strength, the value the scan propagated
-                }
-                const double c_end = readlane_d(c_after, cnt - 1);
-                if (reg == REG_SQL21) {
-                    cache[0] = c_end;
-                } else {
-                    cache[1] = c_end;
-                    cache[2] += readlane_d(c2pre, cnt - 1);
-                    dcache[2] = readlane_d(dc2, cnt - 1);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                continue;
-            }
-        }
-        if constexpr (M == 0) {
-            // all-subsets OmegaCS (omegacs.py:99-106, 77-81): c /= 1 + n_j; strength = st0 c;
-            // shrink; c *= 1 + new norm.  Multiplicative: serial loop over the chunk.
-            double c = cache[0];
-            double f_m = 0.0, l2n_m = 0.0;
-            for (int i = 0; i < cnt; ++i) {
-                const double l2i = readlane_d(l2, i), si = readlane_d(st0, i),
-                             nj = readlane_d(njl, i);
-                c /= 1.0 + nj;
-                const double strength = si * c;
-                const double f = (l2i > strength) ? (1.0 - strength / l2i) : 0.0;
-                const double l2n = f * l2i;
-                c *= 1.0 + l2n;
-                if (lane == i) {
-                    f_m = f;
-                    l2n_m = l2n;
-                }
-            }
-            cache[0] = c;
-            if (valid) {
-                scal[4 * q + 2] = f_m;
-                rs.norms[j] = l2n_m;
-            }
-            continue;
-        }
-        double f_mine = 0.0, l2n_mine = 0.0;
-// rare fallback paths re-read all d norms from memory: first store the norms of the
-// columns of this chunk that were already processed (they live in registers)
-#define PBCD_FLUSH_NORMS                                            \
-    {                                                               \
-        if (valid && lane < i) rs.norms[j] = l2n_mine;              \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      \
-    }
-        for (int i = 0; i < cnt; ++i) {
-            const double l2i = readlane_d(l2, i), si = readlane_d(st0, i);
-            double nj = readlane_d(njl, i);
-            const int ji = __builtin_amdgcn_readlane(j, i);
-            double strength;
-            if (reg == REG_SQL21) {
-                if (cache[0] < nj) {  // squaredl21.py:48-49
-                    PBCD_FLUSH_NORMS
-                    double a = 0.0;
-                    for (int jj = lane; jj < d; jj += kWave) a += rs.norms[jj];
-                    cache[0] = wave_sum(a);
-                }
-                const double dc = cache[0] - nj;
-                strength = 2 * dc * si / (1.0 + 2 * si);
-            } else {  // REG_OMEGACS
-#pragma unroll
-                for (int deg = 2; deg <= M; ++deg) {
-                    dcache[deg] = cache[deg - 1];
-                    dcache[deg] -= dcache[deg - 1] * nj;
-                }
-                double mn = dcache[0];
-#pragma unroll
-                for (int t = 1; t < kMaxDegree + 2; ++t)
-                    if (t < top_ncache && dcache[t] < mn) mn = dcache[t];
-                if (mn < 0) {  // omegacs.py:90-96
-                    PBCD_FLUSH_NORMS
-                    double cc[kMaxDegree + 2];
-#pragma unroll
-                    for (int t = 0; t < kMaxDegree + 2; ++t) cc[t] = (t == 0) ? 1.0 : 0.0;
-                    for (int jj = lane; jj < d; jj += kWave) {
-                        const double v = (jj == ji) ? 0.0 : rs.norms[jj];
-#pragma unroll
-                        for (int t = M - 1; t >= 1; --t) cc[t] += cc[t - 1] * v;
-                    }
-                    for (int m2 = 32; m2 >= 1; m2 >>= 1) {
-                        double oth[kMaxDegree + 2], o[kMaxDegree + 2];
-#pragma unroll
-                        for (int t = 0; t < M; ++t) oth[t] = __shfl_xor(cc[t], m2, kWave);
-#pragma unroll
-                        for (int t = 0; t < M; ++t) {
-                            double acc = 0.0;
-#pragma unroll
-                            for (int u = 0; u <= t; ++u) acc += cc[u] * oth[t - u];
-                            o[t] = acc;
-                        }
-#pragma unroll
-                        for (int t = 0; t < M; ++t) cc[t] = o[t];
-                    }
-#pragma unroll
-                    for (int t = 0; t < kMaxDegree + 2; ++t) cache[t] = (t < M) ? cc[t] : 0.0;
-                    dcache[0] = 0.0;
-                    dcache[1] = 1.0;
-#pragma unroll
-                    for (int deg = 2; deg <= M; ++deg) dcache[deg] = cache[M - 1];
-                    nj = 0.0;  // self._norms[j] = 0.0
-                }
-                strength = si * dcache[M];
-            }
-            const double f = (l2i > strength) ? (1.0 - strength / l2i) : 0.0;
-            const double l2n = f * l2i;
-            if (reg == REG_SQL21) {  // squaredl21.py:40-43
-                cache[0] -= nj;
-                cache[0] += l2n;
-            } else {  // omegacs.py:68-76
-#pragma unroll
-                for (int deg = 1; deg <= M; ++deg) {
-                    cache[deg] += dcache[deg] * l2n;
-                    cache[deg] -= dcache[deg] * nj;
-                }
-                double mn = cache[0];
-#pragma unroll
-                for (int t = 1; t < kMaxDegree + 2; ++t)
-                    if (t < top_ncache && cache[t] < mn) mn = cache[t];
-                if (mn < 0) {  // __recompute_cache_bcd(degree)
-                    PBCD_FLUSH_NORMS
-                    double cc[kMaxDegree + 2];
-#pragma unroll
-                    for (int t = 0; t < kMaxDegree + 2; ++t) cc[t] = (t == 0) ? 1.0 : 0.0;
-                    for (int jj = lane; jj < d; jj += kWave) {
-                        double v = rs.norms[jj];
-                        if (jj == ji) v = l2n;
-#pragma unroll
-                        for (int t = M; t >= 1; --t) cc[t] += cc[t - 1] * v;
-                    }
-                    for (int m2 = 32; m2 >= 1; m2 >>= 1) {
-                        double oth[kMaxDegree + 2], o[kMaxDegree + 2];
-#pragma unroll
-                        for (int t = 0; t <= M; ++t) oth[t] = __shfl_xor(cc[t], m2, kWave);
-#pragma unroll
-                        for (int t = 0; t <= M; ++t) {
-                            double acc = 0.0;
-#pragma unroll
-                            for (int u = 0; u <= t; ++u) acc += cc[u] * oth[t - u];
-                            o[t] = acc;
-                        }
-#pragma unroll
-                        for (int t = 0; t <= M; ++t) cc[t] = o[t];
-                    }
-#pragma unroll
-                    for (int t = 0; t < kMaxDegree + 2; ++t) cache[t] = (t <= M) ? cc[t] : 0.0;
-                }
-            }
-            if (lane == i) {
-                f_mine = f;
-                l2n_mine = l2n;
-            }
-        }
-        if (valid) {
-            scal[4 * q + 2] = f_mine;
-            rs.norms[j] = l2n_mine;
-        }
-        // the next chunk (and its fallback paths) read rs.norms of this chunk's columns
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-#undef PBCD_FLUSH_NORMS
+}
+__device__ __forceinline__ void pbcd_chain_store(int lane, RegState rs, int top_ncache,
+                                                 const double* cache, const double* dcache) {
     if (lane == 0) {
 #pragma unroll
         for (int t = 0; t < kMaxDegree + 2; ++t)
@@ -526,6 +313,273 @@ __device__ __forceinline__ void pbcd_chain_body(
                 rs.dcache[t] = dcache[t];
             }
     }
+}
+
+// Degree 2, one chunk of <= 64 columns (lane = column): the cache is one scalar c (= sum of
+// block norms; csum) and column i maps it through c' = (c - n_i) + max(l2_i - t_i (c - n_i), 0),
+// t_i = st0 (omegacs) or 2 st0 / (1 + 2 st0) (squaredl21): the same piecewise-affine recurrence
+// as pcd's squaredl12, solved by the speculative affine scan.  csum = cache[0] (squaredl21) or
+// cache[1] (omegacs), c2acc = cache[2], dc2last = dcache[2] (omegacs).  Returns false --
+// nothing written -- if any column would take one of the reference's "numerical error"
+// branches: the caller then runs pbcd_chain_serial_chunk, which restates them.
+template <bool COH>
+__device__ __forceinline__ bool pbcd_chain_fast2_chunk(int lane, int cnt, bool valid, int q, int j,
+                                                       double l2, double st0, double njl, int reg,
+                                                       RegState rs, double* __restrict__ scal,
+                                                       double& csum, double& c2acc,
+                                                       double& dc2last) {
+    const double c0 = csum;
+    const double tt = (reg == REG_SQL21) ? (2 * st0 / (1.0 + 2 * st0)) : st0;
+    bool nz = valid && (l2 - tt * (c0 - njl)) > 0;
+    double cb = c0, m = 0.0, al = 1.0, be = 0.0;
+    for (int round = 0; round <= kWave; ++round) {
+        al = valid ? (nz ? (1.0 - tt) : 1.0) : 1.0;
+        be = valid ? (nz ? (l2 - (1.0 - tt) * njl) : -njl) : 0.0;
+        affine_scan_inclusive(al, be, lane);
+        cb = affine_before(al, be, c0, lane);
+        m = l2 - tt * (cb - njl);
+        const bool nz2 = m > 0;
+        const unsigned long long bad = __ballot(valid && (nz2 != nz));
+        nz = nz2;
+        if (bad == 0ull) break;
+    }
+    const double l2n = (valid && nz) ? m : 0.0;
+    const double dc2 = cb - njl;  // dcache[2] (omegacs) / dcache (squaredl21)
+    // cache[2] += dcache[2] * l2n - dcache[2] * n_j per column (omegacs.py:71-73)
+    double c2term = (valid && reg == REG_OMEGACS) ? (dc2 * l2n - dc2 * njl) : 0.0;
+    double c2pre = c2term;  // inclusive prefix sum
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const double v = __shfl_up(c2pre, o, kWave);
+        if (lane >= o) c2pre += v;
+    }
+    const double c_after = al * c0 + be;  // cache after this column
+    const bool trouble = valid && ((dc2 < 0) || (c_after < 0) ||
+                                   (reg == REG_OMEGACS && c2acc + c2pre < 0));
+    if (__ballot(trouble) == 0ull) {
+        const double f = (valid && nz) ? (1.0 - (tt * dc2) / l2) : 0.0;
+        if (valid) {
+            scal[4 * q + 2] = f;
+            rs.norms[j] = l2n;  // = l2 - strength, the value the scan propagated
+        }
+        const double c_end = readlane_d(c_after, cnt - 1);
+        csum = c_end;
+        if (reg != REG_SQL21) {
+            c2acc += readlane_d(c2pre, cnt - 1);
+            dc2last = readlane_d(dc2, cnt - 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return true;
+    }
+    return false;
+}
+
+// One chunk of <= 64 columns (lane = column) by the serial loop: the all-subsets recurrence
+// (multiplicative) or the degree-M cache recurrences with the reference's "numerical error"
+// branches (squaredl21.py:48-49, omegacs.py:75-76,90-96), which recompute from all d norms with
+// the whole wave.
+template <int M, bool COH>
+__device__ __forceinline__ void pbcd_chain_serial_chunk(int lane, int cnt, bool valid, int q, int j,
+                                                        double l2, double st0, double njl, int d,
+                                                        int reg, RegState rs, int top_ncache,
+                                                        double* __restrict__ scal, double* cache,
+                                                        double* dcache) {
+    if constexpr (M == 0) {
+        // all-subsets OmegaCS (omegacs.py:99-106, 77-81): c /= 1 + n_j; strength = st0 c;
+        // shrink; c *= 1 + new norm.  Multiplicative: serial loop over the chunk.
+        double c = cache[0];
+        double f_m = 0.0, l2n_m = 0.0;
+        for (int i = 0; i < cnt; ++i) {
+            const double l2i = readlane_d(l2, i), si = readlane_d(st0, i),
+                         nj = readlane_d(njl, i);
+            c /= 1.0 + nj;
+            const double strength = si * c;
+            const double f = (l2i > strength) ? (1.0 - strength / l2i) : 0.0;
+            const double l2n = f * l2i;
+            c *= 1.0 + l2n;
+            if (lane == i) {
+                f_m = f;
+                l2n_m = l2n;
+            }
+        }
+        cache[0] = c;
+        if (valid) {
+            scal[4 * q + 2] = f_m;
+            rs.norms[j] = l2n_m;
+        }
+        return;
+    }
+    double f_mine = 0.0, l2n_mine = 0.0;
+// rare fallback paths re-read all d norms from memory: first store the norms of the
+// columns of this chunk that were already processed (they live in registers)
+#define PBCD_FLUSH_NORMS                                            \
+{                                                               \
+    if (valid && lane < i) rs.norms[j] = l2n_mine;              \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      \
+}
+    for (int i = 0; i < cnt; ++i) {
+        const double l2i = readlane_d(l2, i), si = readlane_d(st0, i);
+        double nj = readlane_d(njl, i);
+        const int ji = __builtin_amdgcn_readlane(j, i);
+        double strength;
+        if (reg == REG_SQL21) {
+            if (cache[0] < nj) {  // squaredl21.py:48-49
+                PBCD_FLUSH_NORMS
+                double a = 0.0;
+                for (int jj = lane; jj < d; jj += kWave) a += rs.norms[jj];
+                cache[0] = wave_sum(a);
+            }
+            const double dc = cache[0] - nj;
+            strength = 2 * dc * si / (1.0 + 2 * si);
+        } else {  // REG_OMEGACS
+#pragma unroll
+            for (int deg = 2; deg <= M; ++deg) {
+                dcache[deg] = cache[deg - 1];
+                dcache[deg] -= dcache[deg - 1] * nj;
+            }
+            double mn = dcache[0];
+#pragma unroll
+            for (int t = 1; t < kMaxDegree + 2; ++t)
+                if (t < top_ncache && dcache[t] < mn) mn = dcache[t];
+            if (mn < 0) {  // omegacs.py:90-96
+                PBCD_FLUSH_NORMS
+                double cc[kMaxDegree + 2];
+#pragma unroll
+                for (int t = 0; t < kMaxDegree + 2; ++t) cc[t] = (t == 0) ? 1.0 : 0.0;
+                for (int jj = lane; jj < d; jj += kWave) {
+                    const double v = (jj == ji) ? 0.0 : rs.norms[jj];
+#pragma unroll
+                    for (int t = M - 1; t >= 1; --t) cc[t] += cc[t - 1] * v;
+                }
+                for (int m2 = 32; m2 >= 1; m2 >>= 1) {
+                    double oth[kMaxDegree + 2], o[kMaxDegree + 2];
+#pragma unroll
+                    for (int t = 0; t < M; ++t) oth[t] = __shfl_xor(cc[t], m2, kWave);
+#pragma unroll
+                    for (int t = 0; t < M; ++t) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int u = 0; u <= t; ++u) acc += cc[u] * oth[t - u];
+                        o[t] = acc;
+                    }
+#pragma unroll
+                    for (int t = 0; t < M; ++t) cc[t] = o[t];
+                }
+#pragma unroll
+                for (int t = 0; t < kMaxDegree + 2; ++t) cache[t] = (t < M) ? cc[t] : 0.0;
+                dcache[0] = 0.0;
+                dcache[1] = 1.0;
+#pragma unroll
+                for (int deg = 2; deg <= M; ++deg) dcache[deg] = cache[M - 1];
+                nj = 0.0;  // self._norms[j] = 0.0
+            }
+            strength = si * dcache[M];
+        }
+        const double f = (l2i > strength) ? (1.0 - strength / l2i) : 0.0;
+        const double l2n = f * l2i;
+        if (reg == REG_SQL21) {  // squaredl21.py:40-43
+            cache[0] -= nj;
+            cache[0] += l2n;
+        } else {  // omegacs.py:68-76
+#pragma unroll
+            for (int deg = 1; deg <= M; ++deg) {
+                cache[deg] += dcache[deg] * l2n;
+                cache[deg] -= dcache[deg] * nj;
+            }
+            double mn = cache[0];
+#pragma unroll
+            for (int t = 1; t < kMaxDegree + 2; ++t)
+                if (t < top_ncache && cache[t] < mn) mn = cache[t];
+            if (mn < 0) {  // __recompute_cache_bcd(degree)
+                PBCD_FLUSH_NORMS
+                double cc[kMaxDegree + 2];
+#pragma unroll
+                for (int t = 0; t < kMaxDegree + 2; ++t) cc[t] = (t == 0) ? 1.0 : 0.0;
+                for (int jj = lane; jj < d; jj += kWave) {
+                    double v = rs.norms[jj];
+                    if (jj == ji) v = l2n;
+#pragma unroll
+                    for (int t = M; t >= 1; --t) cc[t] += cc[t - 1] * v;
+                }
+                for (int m2 = 32; m2 >= 1; m2 >>= 1) {
+                    double oth[kMaxDegree + 2], o[kMaxDegree + 2];
+#pragma unroll
+                    for (int t = 0; t <= M; ++t) oth[t] = __shfl_xor(cc[t], m2, kWave);
+#pragma unroll
+                    for (int t = 0; t <= M; ++t) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int u = 0; u <= t; ++u) acc += cc[u] * oth[t - u];
+                        o[t] = acc;
+                    }
+#pragma unroll
+                    for (int t = 0; t <= M; ++t) cc[t] = o[t];
+                }
+#pragma unroll
+                for (int t = 0; t < kMaxDegree + 2; ++t) cache[t] = (t <= M) ? cc[t] : 0.0;
+            }
+        }
+        if (lane == i) {
+            f_mine = f;
+            l2n_mine = l2n;
+        }
+    }
+    if (valid) {
+        scal[4 * q + 2] = f_mine;
+        rs.norms[j] = l2n_mine;
+    }
+    // the next chunk (and its fallback paths) read rs.norms of this chunk's columns
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#undef PBCD_FLUSH_NORMS
+}
+
+// PRE = true: the column ids and their old block norms were loaded ahead of time by the
+// caller (lane = column, one chunk of <= 64 columns); desc is then unused.
+template <int M, bool COH, bool PRE = false>
+__device__ __forceinline__ void pbcd_chain_core(
+    int lane, const ColDesc* __restrict__ desc, int ncols, int d, int reg, RegState rs,
+    int top_ncache, double* __restrict__ scal, double* cache, double* dcache, int j_pre = 0,
+    double njl_pre = 0.0) {
+    for (int base = 0; base < ncols; base += kWave) {
+        const int q = base + lane;
+        const bool valid = q < ncols;
+        const int cnt = min(kWave, ncols - base);
+        int j = 0;
+        double l2 = 0.0, st0 = 0.0, njl = 0.0;
+        if (valid) {
+            j = PRE ? j_pre : desc[q].j;
+            l2 = pb_ld<COH>(&scal[4 * q + 0]);
+            st0 = pb_ld<COH>(&scal[4 * q + 1]);
+            njl = PRE ? njl_pre : rs.norms[j];
+        }
+        if constexpr (M == 2) {
+            const double ca = cache[0], cb1 = cache[1];
+            double csum = (reg == REG_SQL21) ? ca : cb1, c2acc = cache[2], dc2last = dcache[2];
+            if (pbcd_chain_fast2_chunk<COH>(lane, cnt, valid, q, j, l2, st0, njl, reg, rs, scal,
+                                            csum, c2acc, dc2last)) {
+                if (reg == REG_SQL21) cache[0] = csum;
+                else cache[1] = csum;
+                cache[2] = c2acc;
+                dcache[2] = dc2last;
+                continue;
+            }
+        }
+        pbcd_chain_serial_chunk<M, COH>(lane, cnt, valid, q, j, l2, st0, njl, d, reg, rs,
+                                        top_ncache, scal, cache, dcache);
+    }
+}
+
+template <int M, bool COH>
+__device__ __forceinline__ void pbcd_chain_body(
+    int lane, const ColDesc* __restrict__ desc, int ncols, int d, int reg, RegState rs,
+    int top_ncache, double* __restrict__ scal) {
+    double cache[kMaxDegree + 2], dcache[kMaxDegree + 2];
+    pbcd_chain_load(lane, rs, top_ncache, cache, dcache);
+    pbcd_chain_core<M, COH>(lane, desc, ncols, d, reg, rs, top_ncache, scal, cache, dcache);
+    pbcd_chain_store(lane, rs, top_ncache, cache, dcache);
 }
 
 // stand-alone forms

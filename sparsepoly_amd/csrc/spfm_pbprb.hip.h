@@ -1,0 +1,835 @@
+// spfm_pbprb.hip.h -- persistent row-block pass for pbcd (pbcd_prb_kernel)
+// Part of the gfx950 device code of the sparse-FM proximal CD core; see
+// spfm_kernels.hip.h for the execution model and DESIGN.md section 3c.
+#pragma once
+#include "spfm_common.hip.h"
+#include "spfm_pcd.hip.h"
+#include "spfm_prb.hip.h"
+#include "spfm_pbcd.hip.h"
+
+namespace spfm {
+
+// ---------------------------------------------------- persistent pbcd pass (PBPRB)
+//
+// pbcd.pbcd_epoch (optimizer/pbcd.py:82-148) as ONE launch.  Workgroup g owns the rows
+// [g*rows_per, (g+1)*rows_per): their state (A[i, :, :], yhat_i; 124 bytes per row at degree 2,
+// k = 30 -- no LDS residency) stays in global memory and is read and written by the owner only.
+//
+// Exchange.  A step's payload is k + 1 sums per column (pbcd.py:60-67: grad[s] and
+// sum_s inv_step_sizes[s]), too much for the flat all-to-all of the pcd pass, so it is a
+// REDUCE-SCATTER followed by an ALL-GATHER, both with tagged granules (spfm_prb.hip.h):
+//   1. every workgroup publishes, per slot, L granules (lanes = components; lane L-2 = its
+//      rows' sum of dA^2) into slabA[parity][slot][workgroup][L]                (sc1 stores)
+//   2. the slot's OWNER workgroup sums the G partial vectors in fixed order, takes
+//      pbcd._update's step (pbcd.py:68-78) with the cache-independent part of prox_bcd and
+//      publishes p_j' (lanes), ||p_j'|| (lane L-2), eta*gamma/inv (lane L-1) into
+//      slabB[parity][slot][L]
+//   3. every workgroup reads the vectors of all slots (ncols * L granules); its control wave
+//      runs the scalar cache recurrence of SquaredL21 / OmegaCS (pbcd_chain_core; L1 / L21
+//      need none) redundantly; the workgroup scatter-updates its rows (pbcd.py:135-144).
+// A slab word is always rewritten at the use of its buffer that precedes a read (slots of this
+// step AND of the step after next), so a reader can never meet a stale word with its tag.
+// Multi-GPU (n_ranks > 1): between 2's sum and step the owner writes its GPU's vector into
+// slabC[slot][rank] of EVERY GPU (peer-mapped stores over xGMI) and adds the n_ranks vectors
+// of its own slabC in rank order: every GPU's owner of a slot forms the identical global sum
+// and the identical update; nothing else crosses GPUs.
+//
+// Threads.  512 = NG groups of L lanes (L = 32 for k <= 30, 64 for k <= 62; lane =
+// component).  Slot q belongs to group q % NG; the host sorts a (workgroup, step)'s entries by
+// (group, slot, row), so a group's entries are one contiguous run (`gsp`).
+//
+// Software pipeline (everything a step needs is in registers when it starts):
+//   entries    lane-parallel (lane u <-> entry u of the group: row, x, slot, yhat_i, y_i),
+//              loaded two steps ahead; broadcast to the lanes through LDS
+//   row state  A[i, :, lane] of the group's first ER entries in LDS (double-buffered by step
+//              parity), fetched one step ahead right after the step's last poll by LDS-DMA
+//              (global_load_lds_dword: no staging registers) -- except rows the current step
+//              itself updates (host flag 0x80), fetched after the end-of-step barrier
+//   slot data  column ids two steps, P[j, :] / old block norms one step ahead
+// Entries beyond ER of a group take a slow path with loads at the point of use.
+// The per-row prediction update needs sum_s lam_s Delta_s dA_s for every entry: the ER sums of
+// a group are formed by transposing butterflies (8 swizzles per 8 entries instead of 8 x log L) and land
+// lane-parallel, where yhat_i lives.
+
+struct PbPrbArgs {
+    int G;                 // workgroups
+    int nb;                // steps in the sweep
+    const int32_t* bptr;   // [nb+1]
+    const int32_t* jsched; // [d] column ids in visiting order
+    const int32_t* gsp;    // [G][nb][NG+1] group boundaries into the entry stream
+    const int32_t* erow;   // entry rows, sorted by (workgroup, step, group, slot, row)
+    const uint8_t* emeta;  // slot index inside the group | 0x80 (row touched by previous step)
+    double* slabA;         // [2][64][G][L] partial vectors
+    double* slabB;         // [2][64][L]    published block updates
+    int rows_per, n_rows;
+    unsigned* abort_flag;
+    int n_ranks, rank;     // multi-GPU: ranks sharing the sweep
+    double* const* slabC;  // [n_ranks] slabC[r] = GPU r's [2][64][n_ranks][L] (peer-mapped)
+    long long* stamps;     // [G][16] diagnostic phase timers or nullptr
+    int dbg;               // diagnostic switches (bit 0: stage rows through registers, no LDS-DMA)
+    unsigned* dbg_out;     // [16] diagnostic counters
+};
+
+constexpr int kPbPrbThreads = 512;
+
+__device__ __forceinline__ bool pbprb_poll_fail(const PbPrbArgs& a, unsigned& spins) {
+    if ((++spins & 63u) == 0) {
+        if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+            spins > (1u << 21)) {
+            __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+    }
+    return false;
+}
+
+// owner slot of workgroup g in owner round r (-1: none).  G >= 64: one round, the 64 slots
+// spread evenly over the workgroups; G < 64: slot = g + r * G.
+__device__ __forceinline__ int pbprb_owned_slot(int G, int g, int r) {
+    if (G >= 64) {
+        const int stride = G / 64;
+        return (g % stride == 0 && g / stride < 64) ? g / stride : -1;
+    }
+    const int q = g + r * G;
+    return q < 64 ? q : -1;
+}
+
+// lane ^ XM inside 32-lane halves, no address register (ds_swizzle bit-mask mode)
+template <int XM>
+__device__ __forceinline__ double pb_swz_xor(double v) {
+    static_assert(XM >= 1 && XM < 32, "swizzle works inside 32 lanes");
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    constexpr int pat = (XM << 10) | 0x1F;
+    lo = __builtin_amdgcn_ds_swizzle(lo, pat);
+    hi = __builtin_amdgcn_ds_swizzle(hi, pat);
+    return __hiloint2double(hi, lo);
+}
+
+// Transposing butterfly: v[0..N) per lane -> lane l ends with the sum over the group's lanes
+// of v[l & (N-1)].  Stage MASK halves the number of live values: the lane whose bit is set
+// keeps the odd entries and hands the even ones to its partner.  Fixed order.
+template <int N, int MASK>
+__device__ __forceinline__ void pb_mr_stage(double* v, int lane) {
+    if constexpr (N > 1) {
+        const bool hi = (lane & MASK) != 0;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const double keep = hi ? v[2 * i + 1] : v[2 * i];
+            const double send = hi ? v[2 * i] : v[2 * i + 1];
+            v[i] = keep + pb_swz_xor<MASK>(send);
+        }
+        pb_mr_stage<N / 2, MASK * 2>(v, lane);
+    }
+}
+template <int N, int L>
+__device__ __forceinline__ double pb_multi_reduce(double* v, int lane) {
+    static_assert(N <= 16 && N >= 1 && (N & (N - 1)) == 0, "N: power of two <= 16");
+    pb_mr_stage<N, 1>(v, lane);
+    double r = v[0];
+    if constexpr (N <= 1) r += pb_swz_xor<1>(r);
+    if constexpr (N <= 2) r += pb_swz_xor<2>(r);
+    if constexpr (N <= 4) r += pb_swz_xor<4>(r);
+    if constexpr (N <= 8) r += pb_swz_xor<8>(r);
+    r += pb_swz_xor<16>(r);
+    if constexpr (L == 64) r += __shfl_xor(r, 32, kWave);
+    return r;
+}
+
+// v[qi] without a dynamically indexed array (which would live in scratch): a select tree on
+// the bits of qi, all indices compile-time constants
+template <int QM>
+__device__ __forceinline__ double pb_sel(const double (&v)[QM], int qi) {
+    static_assert(QM == 4 || QM == 8, "4 or 8 slots per group");
+    // values first: `c ? v[1] : v[0]` on lvalues selects the ADDRESS and loads once, which
+    // pins the array in scratch
+    const double v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+    const bool b0 = (qi & 1) != 0, b1 = (qi & 2) != 0;
+    const double lo01 = b0 ? v1 : v0, lo23 = b0 ? v3 : v2;
+    const double lo = b1 ? lo23 : lo01;
+    if constexpr (QM == 4) {
+        return lo;
+    } else {
+        const double v4 = v[4], v5 = v[5], v6 = v[6], v7 = v[7];
+        const double hi45 = b0 ? v5 : v4, hi67 = b0 ? v7 : v6;
+        const double hi = b1 ? hi67 : hi45;
+        return (qi & 4) ? hi : lo;
+    }
+}
+// v[qi] += x, same constraint
+template <int QM, int I = 0>
+__device__ __forceinline__ void pb_acc(double (&v)[QM], int qi, double x) {
+    if constexpr (I < QM) {
+        v[I] += (qi == I) ? x : 0.0;
+        pb_acc<QM, I + 1>(v, qi, x);
+    }
+}
+
+// One step of the SquaredL21 / OmegaCS cache recurrence for the persistent pass (<= 64
+// columns, lane = column; column ids and old norms preloaded).  The regularizer state lives in
+// LDS (`state`: cache[kMaxDegree+2], dcache[kMaxDegree+2]).  Degree 2 takes the affine-scan
+// path on three scalars; everything else -- and a degree-2 step that would hit one of the
+// reference's "numerical error" branches -- goes through the serial loop, kept out of line so
+// that its register needs (product trees over all d norms) do not weigh on every step.
+template <int M>
+__device__ __attribute__((noinline)) void pbprb_chain_slow(int lane, int ncols, int j, double njl,
+                                                           double l2, double st0, int d, int reg,
+                                                           RegState rs, int top_ncache,
+                                                           double* scal, double* state) {
+    double cache[kMaxDegree + 2], dcache[kMaxDegree + 2];
+#pragma unroll
+    for (int t = 0; t < kMaxDegree + 2; ++t) {
+        cache[t] = state[t];
+        dcache[t] = state[kMaxDegree + 2 + t];
+    }
+    pbcd_chain_serial_chunk<M, false>(lane, ncols, lane < ncols, lane, j, l2, st0, njl, d, reg, rs,
+                                      top_ncache, scal, cache, dcache);
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < kMaxDegree + 2; ++t) {
+            state[t] = cache[t];
+            state[kMaxDegree + 2 + t] = dcache[t];
+        }
+    }
+}
+template <int M>
+__device__ __forceinline__ void pbprb_chain_step(int lane, int ncols, int j, double njl, int d,
+                                                 int reg, RegState rs, int top_ncache, double* scal,
+                                                 double* state) {
+    const bool valid = lane < ncols;
+    const double l2 = valid ? scal[4 * lane + 0] : 0.0, st0 = valid ? scal[4 * lane + 1] : 0.0;
+    if constexpr (M == 2) {
+        const int ci = (reg == REG_SQL21) ? 0 : 1;
+        double csum = state[ci], c2acc = state[2], dc2last = state[kMaxDegree + 2 + 2];
+        if (pbcd_chain_fast2_chunk<false>(lane, ncols, valid, lane, j, l2, st0, njl, reg, rs, scal,
+                                          csum, c2acc, dc2last)) {
+            if (lane == 0) {
+                state[ci] = csum;
+                state[2] = c2acc;
+                state[kMaxDegree + 2 + 2] = dc2last;
+            }
+            return;
+        }
+    }
+    pbprb_chain_slow<M>(lane, ncols, j, njl, l2, st0, d, reg, rs, top_ncache, scal, state);
+}
+
+template <typename T>
+struct PbESet {  // lane u <-> entry e0 + u of the group (u < min(cnt, L))
+    int e0, cnt;
+    int row, meta;
+    T x;
+    T yh, yt;
+};
+
+template <typename T, int M, int L, bool STAMP = false>
+__global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
+    PbPrbArgs a, const T* __restrict__ eval, T* __restrict__ A, T* __restrict__ yy,
+    double* __restrict__ P /* (d,k) */, int k, int d, const double* __restrict__ lams, int loss,
+    int reg, RegState rs, int top_ncache, double mu, double beta, double gamma, double eta,
+    double* __restrict__ viol_pos) {
+    constexpr int NG = kPbPrbThreads / L;  // slot groups per workgroup
+    constexpr int QM = 64 / NG;            // slots per group (<= 64 slots per step)
+    constexpr int AS = Kind<M>::AS;
+    constexpr int NW = kPbPrbThreads / 64;  // waves
+    // entries of a group whose rows are staged in LDS: 64 KB for the two row buffers
+    constexpr int ER0 = (int)(16 * 4 / sizeof(T)) / AS;
+    constexpr int ER = ER0 >= 8 ? (ER0 / 8) * 8 : (ER0 >= 4 ? 4 : (ER0 >= 2 ? 2 : 1));
+    constexpr int CH = ER < 8 ? ER : 8;  // entries per transposing butterfly
+    using ESet = PbESet<T>;
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    double* sh_red = dyn_lds;                    // [2][NG][L] owner part sums
+    double* sh_pt = dyn_lds + 2 * NG * L;        // [64][L] published vectors of the step
+    double* sh_scal = sh_pt + 64 * L;            // [64][4] l2, st0, f, -
+    double* sh_edl = sh_scal + 256;              // [NG][L] dloss of the group's entries
+    double* sh_ex = sh_edl + NG * L;             // [NG][L] x of the group's entries
+    double* sh_cache = sh_ex + NG * L;           // [2][kMaxDegree+2] regularizer cache, dcache
+    int* sh_rowbuf = reinterpret_cast<int*>(sh_cache + 2 * (kMaxDegree + 2));  // [2][NG][L] rows
+    int* sh_metabuf = sh_rowbuf + 2 * NG * L;                                  // [2][NG][L] meta
+    int* sh_ok = sh_metabuf + 2 * NG * L;
+    // row buffers [2][NW][ER][AS][64]: a wave's slice is written lane-linearly by LDS-DMA
+    T* sh_rows = reinterpret_cast<T*>(sh_ok + 4);
+    const typename Vec2<T>::type* yy2 = reinterpret_cast<const typename Vec2<T>::type*>(yy);
+    const int g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid % L, grp = tid / L;
+    const int wlane = tid & 63, wave = tid >> 6;
+    const int gb = grp * L;  // the group's slice of the per-entry LDS arrays
+    const size_t rowlen = (size_t)AS * k;
+    const bool kl = lane < k;
+    const double lam = kl ? lams[lane] : 0.0;
+    const bool chained = (reg == REG_SQL21 || reg == REG_OMEGACS);
+    const bool fixed_owner = a.G >= 64;
+    const int oq = fixed_owner ? pbprb_owned_slot(a.G, g, 0) : -1;  // the slot this WG owns
+    if (wave == 0 && wlane < 2 * (kMaxDegree + 2)) {
+        const int t = wlane % (kMaxDegree + 2);
+        const double* srcp = (wlane < kMaxDegree + 2) ? rs.cache : rs.dcache;
+        sh_cache[wlane] = (t < top_ncache) ? srcp[t] : 0.0;
+    }
+    if (tid == 0) *sh_ok = 1;
+
+    long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = STAMP ? clock64() : 0;
+#define PB_STAMP(kk)                        \
+    if constexpr (STAMP) {                  \
+        if (tid == 0) {                     \
+            const long long tn = clock64(); \
+            acc[kk] += tn - tprev;          \
+            tprev = tn;                     \
+        }                                   \
+    }
+
+    // ---- pipeline helpers ----------------------------------------------------------------
+    auto bounds = [&](int b, int& e0, int& e1) __attribute__((always_inline)) {
+        e0 = 0;
+        e1 = 0;
+        if (b < a.nb) {
+            const int32_t* p = a.gsp + ((size_t)g * a.nb + b) * (NG + 1) + grp;
+            e0 = p[0];
+            e1 = p[1];
+        }
+    };
+    auto load_entries = [&](ESet& s, int e0, int e1) __attribute__((always_inline)) {
+        s.e0 = e0;
+        s.cnt = e1 - e0;
+        const bool v = lane < s.cnt;
+        s.row = v ? a.erow[e0 + lane] : 0;
+        s.meta = v ? (int)a.emeta[e0 + lane] : 0;
+        s.x = v ? eval[e0 + lane] : (T)0;
+        s.yh = (T)0;
+        s.yt = (T)0;
+    };
+    auto rows_at = [&](int par, int u, int t) __attribute__((always_inline)) -> T* {
+        return sh_rows + ((((size_t)par * NW + wave) * ER + u) * AS + t) * 64;
+    };
+    // rows (-> LDS buffer `par`) and lane-parallel (yhat, y) of a set; hz = 0: the entries not
+    // flagged, 1: the flagged ones (after the barrier that ends the step which updated them)
+    auto fetch_rows = [&](ESet& s, int par, int hz) __attribute__((always_inline)) {
+        if (lane < s.cnt && ((s.meta >> 7) & 1) == hz) {
+            const typename Vec2<T>::type yv = yy2[s.row];
+            s.yh = yv.x;
+            s.yt = yv.y;
+        }
+        const int* srow_ = sh_rowbuf + par * NG * L;
+        const int* smeta_ = sh_metabuf + par * NG * L;
+        const int nf = min(s.cnt, ER);
+        // wave-uniform trip count (the two groups of a wave differ in nf): the LDS-DMA's
+        // destination goes through M0, i.e. it is taken from ONE lane -- with per-lane trip
+        // counts the compiler's unrolled remainder loop runs the halves at different u
+        const int nfw = (L == 64) ? __builtin_amdgcn_readfirstlane(nf)
+                                  : max(__builtin_amdgcn_readlane(nf, 0),
+                                        __builtin_amdgcn_readlane(nf, 32));
+        for (int u = 0; u < nfw; ++u) {
+            if (u < nf && ((smeta_[gb + u] >> 7) & 1) == hz && kl) {
+                const size_t base = (size_t)srow_[gb + u] * rowlen + lane;
+#pragma unroll
+                for (int t = 0; t < AS; ++t) {
+                    if constexpr (sizeof(T) == 4) {
+                        if (a.dbg & 1)
+                            rows_at(par, u, t)[wlane] = A[base + (size_t)t * k];
+                        else
+                            // sc1: served by L2, past the CU's L1 -- a plain LDS-DMA read of a
+                            // row this CU rewrote a few steps ago returned the old bytes
+                            __builtin_amdgcn_global_load_lds(A + base + (size_t)t * k,
+                                                             rows_at(par, u, t), 4, 0, 16);
+                    } else {
+                        rows_at(par, u, t)[wlane] = A[base + (size_t)t * k];
+                    }
+                }
+            }
+        }
+    };
+    auto publish_meta = [&](const ESet& s, int par) __attribute__((always_inline)) {
+        sh_rowbuf[par * NG * L + gb + lane] = s.row;  // lane-parallel -> LDS (own group reads)
+        sh_metabuf[par * NG * L + gb + lane] = s.meta;
+    };
+    auto wave_lds_sync = [&]() __attribute__((always_inline)) {
+        // LDS writes of this wave visible to its own later reads (the LDS queue is in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto col_id = [&](int c, int ncols_of, int q) __attribute__((always_inline)) -> int {
+        return (q >= 0 && q < ncols_of) ? a.jsched[c + q] : -1;
+    };
+
+    int c0 = a.bptr[0], c1 = a.bptr[min(1, a.nb)];
+    int c2 = a.bptr[min(2, a.nb)], c3 = a.bptr[min(3, a.nb)];
+    ESet cur, nxt, nn;
+    int b2e0, b2e1;  // group bounds of step b+2
+    {
+        int e0, e1;
+        bounds(0, e0, e1);
+        load_entries(cur, e0, e1);
+        bounds(1, e0, e1);
+        load_entries(nxt, e0, e1);
+        bounds(2, b2e0, b2e1);
+        nn = nxt;
+        publish_meta(cur, 0);
+        publish_meta(nxt, 1);
+        wave_lds_sync();
+        fetch_rows(cur, 0, 0);  // step 0: nothing is flagged
+    }
+    // slot data: column ids of steps b, b+1 (b+2 loaded inside the loop); P rows of step b
+    int j0[QM], j1[QM];
+    double po[QM], pon[QM];
+#pragma unroll
+    for (int t = 0; t < QM; ++t) {
+        j0[t] = col_id(c0, c1 - c0, grp + t * NG);
+        j1[t] = col_id(c1, c2 - c1, grp + t * NG);
+        po[t] = (j0[t] >= 0 && kl) ? P[(size_t)j0[t] * k + lane] : 0.0;
+        pon[t] = 0.0;
+    }
+    int oj1 = col_id(c1, c2 - c1, oq);  // owner's column of step b+1
+    double opo = 0.0, opon = 0.0;       // its P row (group 0's lanes)
+    {
+        const int oj0 = col_id(c0, c1 - c0, oq);
+        opo = (oj0 >= 0 && grp == 0 && kl) ? P[(size_t)oj0 * k + lane] : 0.0;
+    }
+    int cj0 = (wave == 0) ? col_id(c0, c1 - c0, wlane) : -1;  // chain: lane = slot
+    int cj1 = (wave == 0) ? col_id(c1, c2 - c1, wlane) : -1;
+    double cn0 = (cj0 >= 0 && chained) ? rs.norms[cj0] : 0.0, cn1 = 0.0;
+    __syncthreads();
+
+    for (int b = 0; b < a.nb; ++b) {
+        const int ncols = c1 - c0;
+        const int c4 = a.bptr[min(b + 4, a.nb)];  // used from the next iteration on
+        // slots written this step: this step's and those of the buffer's next use, so that a
+        // word read at step b+2 was rewritten at step b (its tag is never tag(b+2))
+        const int nw = max(ncols, c3 - c2);
+        const unsigned long long tag = prb_tag(b);
+        const int par = b & 1;
+        double* slabA = a.slabA + (size_t)par * 64 * a.G * L;
+        double* slabB = a.slabB + (size_t)par * 64 * L;
+        const int* srow = sh_rowbuf + par * NG * L;
+        const int* smeta = sh_metabuf + par * NG * L;
+        const int nfast = min(cur.cnt, ER);
+
+        // ---- phase 0: rows this step shares with the previous one (after its barrier)
+        fetch_rows(cur, par, 1);
+        {   // lane-parallel dloss and x -> LDS for the group's broadcast reads
+            const double dl = (lane < cur.cnt) ? dloss_dev(loss, (double)cur.yh, (double)cur.yt)
+                                                : 0.0;
+            sh_edl[gb + lane] = dl;
+            sh_ex[gb + lane] = (double)cur.x;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed in LDS
+        if (a.dbg & 2) __builtin_amdgcn_s_sleep(8);
+        if (a.dbg & 4) __syncthreads();
+        wave_lds_sync();
+        // ---- phase 1: partial sums of the own rows (pbcd.py:56-67), published per slot
+        double gs[QM], hs[QM];
+#pragma unroll
+        for (int t = 0; t < QM; ++t) {
+            gs[t] = 0.0;
+            hs[t] = 0.0;
+        }
+        for (int u = 0; u < nfast; ++u) {
+            const double x = sh_ex[gb + u], dl = sh_edl[gb + u];
+            const int qi = smeta[gb + u] & 7;
+            if ((a.dbg & 8) && kl) {  // staged row == memory?  (all stores of the last step drained)
+                const T ref = A[(size_t)srow[gb + u] * rowlen + lane];
+                const T got = rows_at(par, u, 0)[wlane];
+                const int hzf = (smeta[gb + u] >> 7) & 1;
+                atomicAdd(a.dbg_out + 2, 1u);
+                if (g == 3 && b == 0 && wave == 1) {  // dump: [u][lane] -> (ref, got)
+                    float* dump = reinterpret_cast<float*>(a.dbg_out + 16);
+                    dump[(u * 64 + wlane) * 2] = (float)ref;
+                    dump[(u * 64 + wlane) * 2 + 1] = (float)got;
+                }
+                if (ref != got) {
+                    atomicAdd(a.dbg_out + hzf, 1u);
+                    atomicMin(a.dbg_out + 3, (unsigned)b);
+                    atomicMax(a.dbg_out + 4, (unsigned)u);
+                    atomicAdd(a.dbg_out + 5 + (wave & 7), 1u);
+                }
+            }
+            const double p = pb_sel(po, qi);
+            double ad[AS];
+#pragma unroll
+            for (int t = 0; t < AS; ++t) ad[t] = kl ? (double)rows_at(par, u, t)[wlane] : 0.0;
+            const double dprev = kl ? grad_factor<M>(ad, x, p) : 0.0;
+            const double tg = dl * dprev, th = dprev * dprev;
+            pb_acc<QM>(gs, qi, tg);
+            pb_acc<QM>(hs, qi, th);
+        }
+        for (int u = ER; u < cur.cnt; ++u) {  // slow path: beyond the LDS-staged rows
+            const int e = cur.e0 + u;
+            const int i = a.erow[e];
+            const int qi = (int)a.emeta[e] & 7;
+            const double x = (double)eval[e];
+            const typename Vec2<T>::type yv = yy2[i];
+            const double dl = dloss_dev(loss, (double)yv.x, (double)yv.y);
+            double ad[AS];
+#pragma unroll
+            for (int t = 0; t < AS; ++t)
+                ad[t] = kl ? (double)A[(size_t)i * rowlen + (size_t)t * k + lane] : 0.0;
+            const double p = pb_sel(po, qi);
+            const double dprev = kl ? grad_factor<M>(ad, x, p) : 0.0;
+            pb_acc<QM>(gs, qi, dl * dprev);
+            pb_acc<QM>(hs, qi, dprev * dprev);
+        }
+#pragma unroll
+        for (int t = 0; t < QM; ++t) {
+            const int q = grp + t * NG;
+            if (q < nw) {
+                const double hsum = group_sum(hs[t], L);  // sum_s inv_step_sizes[s] (pbcd.py:68-70)
+                const double v = (lane == L - 2) ? hsum : (kl ? gs[t] : 0.0);
+                prb_store_granule(slabA + ((size_t)q * a.G + g) * L + lane, v, tag);
+            }
+        }
+        PB_STAMP(0)
+
+        // ---- phase 2: owners reduce their slot over the workgroups and take the step
+        const int n_rounds = fixed_owner ? 1 : (nw + a.G - 1) / a.G;
+        for (int r = 0; r < n_rounds; ++r) {
+            const int q = fixed_owner ? oq : pbprb_owned_slot(a.G, g, r);
+            const bool own = q >= 0 && q < ncols;
+            double* red = sh_red + (size_t)(r & 1) * NG * L;
+            if (own) {
+                // group `grp` sums the source workgroups grp, grp + NG, ... in that order
+                double tot = 0.0;
+                constexpr int GU = 8;
+                for (int s0 = grp; s0 < a.G; s0 += NG * GU) {
+                    unsigned long long t[GU];
+                    unsigned spins = 0;
+                    bool ok = true;
+                    for (;;) {
+                        bool all = true;
+#pragma unroll
+                        for (int u = 0; u < GU; ++u) {
+                            const int src = s0 + u * NG;
+                            t[u] = (src < a.G)
+                                       ? prb_load_granule(slabA + ((size_t)q * a.G + src) * L + lane)
+                                       : tag;
+                            all = all && ((t[u] & 3ull) == tag);
+                        }
+                        if (all) break;
+                        if (pbprb_poll_fail(a, spins)) {
+                            ok = false;
+                            break;
+                        }
+                    }
+                    if (!ok) {
+                        *sh_ok = 0;
+                        break;
+                    }
+#pragma unroll
+                    for (int u = 0; u < GU; ++u)
+                        if (s0 + u * NG < a.G)
+                            tot += __longlong_as_double((long long)(t[u] & ~3ull));
+                }
+                red[grp * L + lane] = tot;
+            }
+            __syncthreads();
+            if (q >= ncols && q < nw && grp == 0) {
+                // slot unused in this step but read at the buffer's next use: rewritten now
+                prb_store_granule(slabB + (size_t)q * L + lane, 0.0, tag);
+                if (a.n_ranks > 1) {
+                    const size_t off = ((size_t)par * 64 + q) * a.n_ranks * L;
+                    for (int rr = 0; rr < a.n_ranks; ++rr)
+                        prb_store_granule(a.slabC[rr] + off + (size_t)a.rank * L + lane, 0.0, tag);
+                }
+            }
+            if (own && grp == 0) {
+                double tot = red[lane];
+#pragma unroll
+                for (int w = 1; w < NG; ++w) tot += red[w * L + lane];
+                if (a.n_ranks > 1) {
+                    // one xGMI hop: this GPU's vector into every GPU's slabC[slot][rank], then
+                    // the n_ranks vectors of the own slabC summed in rank order
+                    const size_t off = ((size_t)par * 64 + q) * a.n_ranks * L;
+                    for (int rr = 0; rr < a.n_ranks; ++rr)
+                        prb_store_granule(a.slabC[rr] + off + (size_t)a.rank * L + lane, tot, tag);
+                    double gt = 0.0;
+                    bool ok = true;
+                    const double* mine = a.slabC[a.rank];
+                    for (int rr = 0; rr < a.n_ranks && ok; ++rr) {
+                        unsigned long long t;
+                        unsigned spins = 0;
+                        for (;;) {
+                            t = prb_load_granule(mine + off + (size_t)rr * L + lane);
+                            if ((t & 3ull) == tag) break;
+                            if (pbprb_poll_fail(a, spins)) {
+                                ok = false;
+                                break;
+                            }
+                        }
+                        gt += __longlong_as_double((long long)(t & ~3ull));
+                    }
+                    if (!ok) *sh_ok = 0;
+                    tot = gt;
+                }
+                // pbcd._update (pbcd.py:68-79) up to the cache-dependent part of prox_bcd
+                double pold = opo;
+                if (!fixed_owner) {
+                    const int j = a.jsched[c0 + q];
+                    pold = kl ? P[(size_t)j * k + lane] : 0.0;
+                }
+                const double hsum = __shfl(tot, L - 2, L);
+                double inv = hsum * mu;
+                inv += beta;
+                const double st0 = eta * gamma / inv;
+                double v = 0.0;
+                if (kl) {
+                    double gr = tot * lam;
+                    gr += beta * pold;
+                    gr /= inv;
+                    v = pold - eta * gr;
+                    if (reg == REG_L1) {  // l1.py:44-45, element-wise
+                        const double sg = (v > 0) ? 1.0 : ((v < 0) ? -1.0 : 0.0);
+                        const double m = fabs(v) - st0;
+                        v = sg * (m > 0.0 ? m : 0.0);
+                    } else if (reg == REG_SQL21) {
+                        v /= 1 + 2 * st0;  // squaredl21.py:46
+                    }
+                }
+                const double l2 = sqrt(group_sum(v * v, L));
+                const double outv = (lane == L - 2) ? l2 : ((lane == L - 1) ? st0 : v);
+                prb_store_granule(slabB + (size_t)q * L + lane, outv, tag);
+            }
+        }
+        PB_STAMP(1)
+
+        // ---- phase 3: every workgroup collects the published vectors of all slots
+        {
+            const int total = ncols * L;
+            constexpr int RU = 64 * L / kPbPrbThreads;  // granules per thread at most
+            unsigned long long t[RU];
+            unsigned spins = 0;
+            bool ok = true;
+            for (;;) {
+                bool all = true;
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int idx = tid + u * kPbPrbThreads;
+                    t[u] = (idx < total) ? prb_load_granule(slabB + idx) : tag;
+                    all = all && ((t[u] & 3ull) == tag);
+                }
+                if (all) break;
+                if (pbprb_poll_fail(a, spins)) {
+                    ok = false;
+                    break;
+                }
+            }
+            if (!ok) *sh_ok = 0;
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int idx = tid + u * kPbPrbThreads;
+                if (idx < total) {
+                    const double v = __longlong_as_double((long long)(t[u] & ~3ull));
+                    sh_pt[idx] = v;
+                    const int q = idx / L, l = idx % L;
+                    if (l == L - 2) sh_scal[4 * q + 0] = v;
+                    if (l == L - 1) sh_scal[4 * q + 1] = v;
+                }
+            }
+        }
+        // ---- prefetch (behind the step's last poll: vmcnt retires in order, earlier loads
+        // would delay every tag check): entries of step b+2, rows of step b+1 that this step
+        // does not touch, column ids / P rows / old norms of the coming steps
+        int b3e0, b3e1;
+        bounds(b + 3, b3e0, b3e1);
+        load_entries(nn, b2e0, b2e1);
+        fetch_rows(nxt, par ^ 1, 0);
+        int j2[QM];
+#pragma unroll
+        for (int t = 0; t < QM; ++t) {
+            j2[t] = col_id(c2, c3 - c2, grp + t * NG);
+            pon[t] = (j1[t] >= 0 && kl) ? P[(size_t)j1[t] * k + lane] : 0.0;
+        }
+        const int oj2 = col_id(c2, c3 - c2, oq);
+        opon = (oj1 >= 0 && grp == 0 && kl) ? P[(size_t)oj1 * k + lane] : 0.0;
+        const int cj2 = (wave == 0) ? col_id(c2, c3 - c2, wlane) : -1;
+        cn1 = (cj1 >= 0 && chained) ? rs.norms[cj1] : 0.0;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // sh_pt / sh_scal
+        if (!*sh_ok) break;
+        PB_STAMP(2)
+
+        // ---- phase 4: shrink factors.  L1: none; L21: from (l2, st0); SquaredL21 / OmegaCS:
+        // the scalar cache recurrence in step order (every workgroup redundantly; every
+        // workgroup also writes the new block norms, so its own later reads are consistent)
+        if (wave == 0) {
+            if (chained) {
+                pbprb_chain_step<M>(wlane, ncols, cj0, cn0, d, reg, rs, top_ncache, sh_scal,
+                                    sh_cache);
+            } else if (wlane < ncols) {
+                double f = 1.0;
+                if (reg == REG_L21) {  // l21.py:33-38
+                    const double l2 = sh_scal[4 * wlane], st0 = sh_scal[4 * wlane + 1];
+                    f = (l2 > st0) ? (1.0 - st0 / l2) : 0.0;
+                }
+                sh_scal[4 * wlane + 2] = f;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // factors in LDS
+        PB_STAMP(3)
+
+        // ---- phase 5: p_j = f * p_j', write-back, scatter over the own rows (pbcd.py:135-146)
+        double pn[QM], up[QM], lu[QM], mv[QM];
+#pragma unroll
+        for (int t = 0; t < QM; ++t) {
+            const int q = grp + t * NG;
+            pn[t] = 0.0;
+            up[t] = 0.0;
+            lu[t] = 0.0;
+            mv[t] = 0.0;
+            if (q < ncols) {
+                const double f = sh_scal[4 * q + 2];
+                pn[t] = kl ? sh_pt[q * L + lane] * f : 0.0;
+                up[t] = kl ? po[t] - pn[t] : 0.0;
+                lu[t] = lam * up[t];
+                mv[t] = group_sum((up[t] != 0.0) ? 1.0 : 0.0, L);  // 0: block did not move
+                if (g == 0) {
+                    if (kl) P[(size_t)j0[t] * k + lane] = pn[t];
+                    const double va = group_sum(fabs(up[t]), L);
+                    if (lane == 0) viol_pos[c0 + q] = va;
+                }
+            }
+        }
+        {
+            // the sums over components of CH entries at a time land lane-parallel: after the
+            // butterfly lane l holds the sum of entry (l & (CH-1)) of the chunk
+            double s1 = 0.0, s2 = 0.0;
+            for (int cb = 0; cb < nfast; cb += CH) {
+                double term[CH], term2[M == 0 ? CH : 1];
+#pragma unroll
+                for (int uu = 0; uu < CH; ++uu) {
+                    const int u = cb + uu;
+                    term[uu] = 0.0;
+                    if constexpr (M == 0) term2[uu] = 0.0;
+                    if (u < nfast) {
+                        const double x = sh_ex[gb + u];
+                        const int qi = smeta[gb + u] & 7;
+                        const double mvl = pb_sel(mv, qi);
+                        if (mvl != 0.0) {  // group-uniform; a block that did not move: no-op
+                            const double pol = pb_sel(po, qi), upl = pb_sel(up, qi);
+                            const size_t base = (size_t)srow[gb + u] * rowlen;
+                            if constexpr (M == 0) {  // pbcd_all.py:121-127
+                                const double pnl = pb_sel(pn, qi);
+                                const double a0 = kl ? (double)rows_at(par, u, 0)[wlane] : 0.0;
+                                double a1 = a0 / (1.0 + x * pol);
+                                a1 *= 1.0 + x * pnl;
+                                if (kl) A[base + lane] = (T)a1;
+                                term[uu] = kl ? lam * a0 : 0.0;
+                                term2[uu] = kl ? lam * a1 : 0.0;
+                            } else {
+                                const double lul = pb_sel(lu, qi);
+                                double dprev = x;
+#pragma unroll
+                                for (int t = 1; t < M; ++t) {
+                                    const double avv =
+                                        kl ? (double)rows_at(par, u, t - 1)[wlane] : 0.0;
+                                    const double dcur = x * (avv - pol * dprev);
+                                    if (kl)
+                                        A[base + (size_t)(t - 1) * k + lane] =
+                                            (T)(avv - upl * dprev);
+                                    dprev = dcur;
+                                }
+                                term[uu] = kl ? lul * dprev : 0.0;
+                            }
+                        }
+                    }
+                }
+                const double r1 = pb_multi_reduce<CH, L>(term, lane);
+                const bool mine = (lane >= cb) && (lane < cb + CH);
+                s1 = mine ? r1 : s1;
+                if constexpr (M == 0) {
+                    const double r2 = pb_multi_reduce<CH, L>(term2, lane);
+                    s2 = mine ? r2 : s2;
+                }
+            }
+            if (lane < nfast) {
+                const double mvl = pb_sel(mv, cur.meta & 7);
+                const double ynew = (M == 0) ? (((double)cur.yh - s1) + s2) : ((double)cur.yh - s1);
+                if (mvl != 0.0) yy[2 * (size_t)cur.row] = (T)ynew;
+            }
+        }
+        for (int u = ER; u < cur.cnt; ++u) {  // slow path
+            const int e = cur.e0 + u;
+            const int i = a.erow[e];
+            const int qi = (int)a.emeta[e] & 7;
+            if (pb_sel(mv, qi) == 0.0) continue;
+            const double x = (double)eval[e];
+            const double y0 = (double)yy[2 * (size_t)i];
+            const double pol = pb_sel(po, qi), upl = pb_sel(up, qi);
+            const size_t base = (size_t)i * rowlen;
+            if constexpr (M == 0) {
+                const double pnl = pb_sel(pn, qi);
+                double d_old = 0.0, d_new = 0.0;
+                if (kl) {
+                    const double a0 = (double)A[base + lane];
+                    double a1 = a0 / (1.0 + x * pol);
+                    a1 *= 1.0 + x * pnl;
+                    A[base + lane] = (T)a1;
+                    d_old = lam * a0;
+                    d_new = lam * a1;
+                }
+                d_old = group_sum(d_old, L);
+                d_new = group_sum(d_new, L);
+                if (lane == 0) yy[2 * (size_t)i] = (T)((y0 - d_old) + d_new);
+            } else {
+                const double lul = pb_sel(lu, qi);
+                double accv = 0.0;
+                if (kl) {
+                    double dprev = x;
+#pragma unroll
+                    for (int t = 1; t < M; ++t) {
+                        const double avv = (double)A[base + (size_t)(t - 1) * k + lane];
+                        const double dcur = x * (avv - pol * dprev);
+                        A[base + (size_t)(t - 1) * k + lane] = (T)(avv - upl * dprev);
+                        dprev = dcur;
+                    }
+                    accv = lul * dprev;
+                }
+                accv = group_sum(accv, L);
+                if (lane == 0) yy[2 * (size_t)i] = (T)(y0 - accv);
+            }
+        }
+        // ---- rotate the pipeline
+        cur = nxt;
+        nxt = nn;
+        publish_meta(nxt, par);  // step b+2's slice (parity b&1): step b is done with it
+        b2e0 = b3e0;
+        b2e1 = b3e1;
+#pragma unroll
+        for (int t = 0; t < QM; ++t) {
+            j0[t] = j1[t];
+            j1[t] = j2[t];
+            po[t] = pon[t];
+        }
+        oj1 = oj2;
+        opo = opon;
+        cj0 = cj1;
+        cj1 = cj2;
+        cn0 = cn1;
+        c0 = c1;
+        c1 = c2;
+        c2 = c3;
+        c3 = c4;
+        __syncthreads();  // rows move between groups from step to step (stores drained)
+        PB_STAMP(4)
+    }
+#undef PB_STAMP
+    if (wave == 0 && g == 0 && wlane < 2 * (kMaxDegree + 2)) {
+        const int t = wlane % (kMaxDegree + 2);
+        double* dstp = (wlane < kMaxDegree + 2) ? rs.cache : rs.dcache;
+        if (t < top_ncache) dstp[t] = sh_cache[wlane];
+    }
+    if (STAMP && a.stamps != nullptr && tid == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a.stamps[(size_t)g * 16 + q] = acc[q];
+    }
+}
+
+// dynamic LDS the kernel needs (bytes)
+template <typename T, int M, int L>
+constexpr size_t pbcd_prb_lds_bytes() {
+    constexpr int NG = kPbPrbThreads / L;
+    constexpr int AS = Kind<M>::AS;
+    constexpr int ER0 = (int)(16 * 4 / sizeof(T)) / AS;
+    constexpr int ER = ER0 >= 8 ? (ER0 / 8) * 8 : (ER0 >= 4 ? 4 : (ER0 >= 2 ? 2 : 1));
+    return sizeof(double) * (2 * NG * L + 64 * L + 256 + 2 * NG * L + 2 * (kMaxDegree + 2)) +
+           sizeof(int) * (4 * NG * L + 4) +
+           sizeof(T) * (size_t)2 * (kPbPrbThreads / 64) * ER * AS * 64;
+}
+
+}  // namespace spfm

@@ -190,4 +190,57 @@ void build_rowblock_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
         }
 }
 
+// Entry stream of the persistent pbcd pass: entries sorted by (row block g, batch b, slot
+// group q % NG, slot, row).  gsp[(g*nb + b)*(NG+1) + grp] = first entry of group grp (NG+1
+// boundaries per (g, b)), src[e] = position in the CSC arrays, meta[e] = slot index inside the
+// group (q / NG, < 8) | 0x80 if the entry's row was touched by the previous step (its row
+// state must be read after that step's scatter, not prefetched).  Batches of <= 64 columns,
+// nnz < 2^31.
+void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
+                     const std::vector<int32_t>& order, const std::vector<int32_t>& batch_ptr,
+                     int G, int NG, std::vector<int32_t>& gsp, std::vector<int32_t>& src,
+                     std::vector<uint8_t>& meta) {
+    const int nb = (int)batch_ptr.size() - 1;
+    const int64_t rows_per = (n + G - 1) / G > 0 ? (n + G - 1) / G : 1;
+    const size_t stride = (size_t)NG + 1;
+    gsp.assign((size_t)G * nb * stride + 1, 0);
+    for (int b = 0; b < nb; ++b)
+        for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
+            const int32_t j = order[(size_t)batch_ptr[b] + q];
+            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                const int g = (int)(cidx[ii] / rows_per);
+                gsp[((size_t)g * nb + b) * stride + (size_t)(q % NG)]++;
+            }
+        }
+    int64_t run = 0;
+    for (size_t t = 0; t < gsp.size(); ++t) {  // exclusive prefix sum; the pad word of each
+        const int64_t c = gsp[t];              // (g, b) holds 0 entries = end of the last group
+        gsp[t] = (int32_t)run;
+        run += c;
+    }
+    src.resize((size_t)run);
+    meta.resize((size_t)run);
+    std::vector<int32_t> fill(gsp.begin(), gsp.end());
+    std::vector<int32_t> last((size_t)n, -2);  // last step that touched the row
+    // slots of one group in ascending order: q = grp, grp + NG, ... -> walk q ascending and the
+    // per-group fill pointers keep (slot, row) order inside each group
+    for (int b = 0; b < nb; ++b) {
+        for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
+            const int32_t j = order[(size_t)batch_ptr[b] + q];
+            const uint8_t qi = (uint8_t)(q / NG);
+            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                const int32_t i = cidx[ii];
+                const int g = (int)(i / rows_per);
+                const size_t e = (size_t)fill[((size_t)g * nb + b) * stride + (size_t)(q % NG)]++;
+                src[e] = (int32_t)ii;
+                meta[e] = (uint8_t)(qi | (last[(size_t)i] == b - 1 ? 0x80 : 0));
+            }
+        }
+        for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
+            const int32_t j = order[(size_t)batch_ptr[b] + q];
+            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) last[(size_t)cidx[ii]] = b;
+        }
+    }
+}
+
 }  // namespace spfm

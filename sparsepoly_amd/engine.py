@@ -294,7 +294,7 @@ class HipEngine(object):
         return ns.value
 
     def debug_prb_stamps(self):
-        buf = np.zeros(16 * 256, dtype=np.int64)
+        buf = np.zeros(16 * 512, dtype=np.int64)
         nv = self._lib.spfm_debug_prb_stamps(self._h, buf.ctypes.data_as(_capi._lp), buf.size)
         if nv < 0:
             self._check(nv)

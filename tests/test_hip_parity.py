@@ -120,6 +120,7 @@ class _Run(object):
         self.P, self.w = eng.get_params()
         self.y_pred = eng.get_y_pred()
         self.n_batches = eng.n_batches
+        self.pbprb_active = eng.get_option("pbprb_active")
         eng.close()
 
 
@@ -239,6 +240,40 @@ def test_engine_options_do_not_change_results(oracle, case, options):
         np.testing.assert_array_equal(a.order, b.order)
         np.testing.assert_allclose(a.viol, b.viol, rtol=1e-10)
         np.testing.assert_allclose(a.P, b.P, rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("options", [{"pbprb_groups": 1}, {"pbprb_groups": 3},
+                                     {"pbprb_groups": 64}, {"pbprb_groups": 100},
+                                     {"pbprb_groups": 256}])
+@pytest.mark.parametrize("case", ["c4|squared", "c4|logistic", "c4d3|squared_hinge",
+                                  "l21|logistic", "sql21|squared", "l1b|squared_hinge"])
+def test_persistent_pbcd_pass_equals_multi_kernel_engine(oracle, case, options):
+    """The persistent pbcd pass (one launch per epoch, reduce-scatter / all-gather exchange)
+    against the four-launches-per-step engine and the oracle in the same order, for several
+    workgroup counts (owner rounds, more owners than slots, empty row blocks)."""
+    z = load_golden("g3_small_configs.npz")
+    X = golden_csr(z)
+    meta = json.loads(str(z["meta|" + case]))
+    y = z["y"]
+    if meta["loss"] != "squared":
+        y = np.where(y > np.median(y), 1.0, -1.0)
+    assert meta["solver"] == "pbcd"
+    a = _Run(X, y, meta, z["P0|" + case], z["lams|" + case], "f64", schedule="colored",
+             options={"pbcd_persistent": 0})
+    b = _Run(X, y, meta, z["P0|" + case], z["lams|" + case], "f64", schedule="colored",
+             options=options)
+    assert b.pbprb_active == 1 and a.pbprb_active == 0
+    np.testing.assert_array_equal(a.order, b.order)
+    np.testing.assert_allclose(a.viol, b.viol, rtol=1e-10)
+    np.testing.assert_allclose(a.P, b.P, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(a.y_pred, b.y_pred, rtol=0, atol=1e-9)
+    fm = oracle.OracleFM(degree=meta["degree"], loss=meta["loss"], n_components=meta["k"],
+                         solver="pbcd", regularizer=meta["regularizer"], alpha=meta["alpha"],
+                         beta=meta["beta"], gamma=meta["gamma"], tol=0, fit_linear=True,
+                         max_iter=4, feature_order=b.order)
+    fm.fit(X, y, P_init=z["P0|" + case], lams_init=z["lams|" + case])
+    np.testing.assert_allclose(b.viol, [h[0] for h in fm.history], rtol=1e-9)
+    np.testing.assert_allclose(b.P, fm.P_, rtol=0, atol=1e-8)
 
 
 @pytest.mark.parametrize("degree", [2, 3, 4, 5])

@@ -7,6 +7,10 @@
 #include "spfm_prb.hip.h"
 #include "spfm_pbcd.hip.h"
 
+#ifndef PBPRB_SLOW_ATTR
+#define PBPRB_SLOW_ATTR __forceinline__
+#endif
+
 namespace spfm {
 
 // ---------------------------------------------------- persistent pbcd pass (PBPRB)
@@ -47,9 +51,11 @@ namespace spfm {
 //              itself updates (host flag 0x80), fetched after the end-of-step barrier
 //   slot data  column ids two steps, P[j, :] / old block norms one step ahead
 // Entries beyond ER of a group take a slow path with loads at the point of use.
-// The per-row prediction update needs sum_s lam_s Delta_s dA_s for every entry: the ER sums of
-// a group are formed by transposing butterflies (8 swizzles per 8 entries instead of 8 x log L) and land
-// lane-parallel, where yhat_i lives.
+// A group's entries are sorted by slot, so phases 1 and 5 run one static loop over the slots
+// (the slot's P row, Delta, lam*Delta are plain registers) with a dynamic loop over the slot's
+// entries inside; the per-row prediction decrement sum_s lam_s Delta_s dA_s is one DPP
+// all-reduce over the group's lanes, applied by the lane that holds the entry's yhat.  The
+// per-slot scalar sums (sum dA^2, did-the-block-move, ||Delta||_1) use a transposing butterfly.
 
 struct PbPrbArgs {
     int G;                 // workgroups
@@ -103,6 +109,20 @@ __device__ __forceinline__ double pb_swz_xor(double v) {
     lo = __builtin_amdgcn_ds_swizzle(lo, pat);
     hi = __builtin_amdgcn_ds_swizzle(hi, pat);
     return __hiloint2double(hi, lo);
+}
+
+// Sum over the L lanes of a group, result in every lane: quad_perm / row_ror moves inside the
+// rows of 16 lanes (DPP: one issue slot each, no LDS crossbar round trip), one swizzle across
+// the two rows of a 32-lane half, one cross-half shuffle for L = 64.  Fixed order.
+template <int L>
+__device__ __forceinline__ double pb_group_allsum(double v) {
+    v += dpp_move_d<0xB1, 0xf>(0.0, v);   // quad_perm [1,0,3,2]
+    v += dpp_move_d<0x4E, 0xf>(0.0, v);   // quad_perm [2,3,0,1]
+    v += dpp_move_d<0x124, 0xf>(0.0, v);  // row_ror:4
+    v += dpp_move_d<0x128, 0xf>(0.0, v);  // row_ror:8
+    v += pb_swz_xor<16>(v);
+    if constexpr (L == 64) v += __shfl_xor(v, 32, kWave);
+    return v;
 }
 
 // Transposing butterfly: v[0..N) per lane -> lane l ends with the sum over the group's lanes
@@ -171,7 +191,7 @@ __device__ __forceinline__ void pb_acc(double (&v)[QM], int qi, double x) {
 // reference's "numerical error" branches -- goes through the serial loop, kept out of line so
 // that its register needs (product trees over all d norms) do not weigh on every step.
 template <int M>
-__device__ __attribute__((noinline)) void pbprb_chain_slow(int lane, int ncols, int j, double njl,
+__device__ PBPRB_SLOW_ATTR void pbprb_chain_slow(int lane, int ncols, int j, double njl,
                                                            double l2, double st0, int d, int reg,
                                                            RegState rs, int top_ncache,
                                                            double* scal, double* state) {
@@ -234,18 +254,15 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     // entries of a group whose rows are staged in LDS: 64 KB for the two row buffers
     constexpr int ER0 = (int)(16 * 4 / sizeof(T)) / AS;
     constexpr int ER = ER0 >= 8 ? (ER0 / 8) * 8 : (ER0 >= 4 ? 4 : (ER0 >= 2 ? 2 : 1));
-    constexpr int CH = ER < 8 ? ER : 8;  // entries per transposing butterfly
     using ESet = PbESet<T>;
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
     double* sh_red = dyn_lds;                    // [2][NG][L] owner part sums
     double* sh_pt = dyn_lds + 2 * NG * L;        // [64][L] published vectors of the step
     double* sh_scal = sh_pt + 64 * L;            // [64][4] l2, st0, f, -
-    double* sh_edl = sh_scal + 256;              // [NG][L] dloss of the group's entries
-    double* sh_ex = sh_edl + NG * L;             // [NG][L] x of the group's entries
-    double* sh_cache = sh_ex + NG * L;           // [2][kMaxDegree+2] regularizer cache, dcache
-    int* sh_rowbuf = reinterpret_cast<int*>(sh_cache + 2 * (kMaxDegree + 2));  // [2][NG][L] rows
-    int* sh_metabuf = sh_rowbuf + 2 * NG * L;                                  // [2][NG][L] meta
-    int* sh_ok = sh_metabuf + 2 * NG * L;
+    double2* sh_xd = reinterpret_cast<double2*>(sh_scal + 256);  // [NG][L] (x, dloss) per entry
+    double* sh_cache = sh_scal + 256 + 2 * NG * L;  // [2][kMaxDegree+2] regularizer cache, dcache
+    int2* sh_rm = reinterpret_cast<int2*>(sh_cache + 2 * (kMaxDegree + 2));  // [2][NG][L] (row, meta)
+    int* sh_ok = reinterpret_cast<int*>(sh_rm + 2 * NG * L);
     // row buffers [2][NW][ER][AS][64]: a wave's slice is written lane-linearly by LDS-DMA
     T* sh_rows = reinterpret_cast<T*>(sh_ok + 4);
     const typename Vec2<T>::type* yy2 = reinterpret_cast<const typename Vec2<T>::type*>(yy);
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     }
     if (tid == 0) *sh_ok = 1;
 
-    long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = STAMP ? clock64() : 0;
 #define PB_STAMP(kk)                        \
     if constexpr (STAMP) {                  \
@@ -308,8 +325,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             s.yh = yv.x;
             s.yt = yv.y;
         }
-        const int* srow_ = sh_rowbuf + par * NG * L;
-        const int* smeta_ = sh_metabuf + par * NG * L;
+        const int2* rm_ = sh_rm + par * NG * L + gb;
         const int nf = min(s.cnt, ER);
         // wave-uniform trip count (the two groups of a wave differ in nf): the LDS-DMA's
         // destination goes through M0, i.e. it is taken from ONE lane -- with per-lane trip
@@ -317,29 +333,32 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         const int nfw = (L == 64) ? __builtin_amdgcn_readfirstlane(nf)
                                   : max(__builtin_amdgcn_readlane(nf, 0),
                                         __builtin_amdgcn_readlane(nf, 32));
-        for (int u = 0; u < nfw; ++u) {
-            if (u < nf && ((smeta_[gb + u] >> 7) & 1) == hz && kl) {
-                const size_t base = (size_t)srow_[gb + u] * rowlen + lane;
+        for (int ub = 0; ub < nfw; ub += 4) {
+            int2 rm[4];
 #pragma unroll
-                for (int t = 0; t < AS; ++t) {
-                    if constexpr (sizeof(T) == 4) {
-                        if (a.dbg & 1)
-                            rows_at(par, u, t)[wlane] = A[base + (size_t)t * k];
-                        else
-                            // sc1: served by L2, past the CU's L1 -- a plain LDS-DMA read of a
-                            // row this CU rewrote a few steps ago returned the old bytes
+            for (int uu = 0; uu < 4; ++uu) rm[uu] = rm_[min(ub + uu, ER - 1)];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int u = ub + uu;
+                if (u < nf && ((rm[uu].y >> 7) & 1) == hz && kl) {
+                    const size_t base = (size_t)rm[uu].x * rowlen + lane;
+#pragma unroll
+                    for (int t = 0; t < AS; ++t) {
+                        if constexpr (sizeof(T) == 4) {
+                            // sc1: served by L2, past the CU's L1 (rows are read once)
                             __builtin_amdgcn_global_load_lds(A + base + (size_t)t * k,
-                                                             rows_at(par, u, t), 4, 0, 16);
-                    } else {
-                        rows_at(par, u, t)[wlane] = A[base + (size_t)t * k];
+                                                             rows_at(par, min(u, ER - 1), t), 4, 0,
+                                                             16);
+                        } else {
+                            rows_at(par, min(u, ER - 1), t)[wlane] = A[base + (size_t)t * k];
+                        }
                     }
                 }
             }
         }
     };
     auto publish_meta = [&](const ESet& s, int par) __attribute__((always_inline)) {
-        sh_rowbuf[par * NG * L + gb + lane] = s.row;  // lane-parallel -> LDS (own group reads)
-        sh_metabuf[par * NG * L + gb + lane] = s.meta;
+        sh_rm[par * NG * L + gb + lane] = make_int2(s.row, s.meta);  // lane-parallel -> LDS
     };
     auto wave_lds_sync = [&]() __attribute__((always_inline)) {
         // LDS writes of this wave visible to its own later reads (the LDS queue is in order)
@@ -399,8 +418,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         const int par = b & 1;
         double* slabA = a.slabA + (size_t)par * 64 * a.G * L;
         double* slabB = a.slabB + (size_t)par * 64 * L;
-        const int* srow = sh_rowbuf + par * NG * L;
-        const int* smeta = sh_metabuf + par * NG * L;
+        const int2* srm = sh_rm + par * NG * L + gb;  // (row, meta) of the group's entries
         const int nfast = min(cur.cnt, ER);
 
         // ---- phase 0: rows this step shares with the previous one (after its barrier)
@@ -408,13 +426,11 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         {   // lane-parallel dloss and x -> LDS for the group's broadcast reads
             const double dl = (lane < cur.cnt) ? dloss_dev(loss, (double)cur.yh, (double)cur.yt)
                                                 : 0.0;
-            sh_edl[gb + lane] = dl;
-            sh_ex[gb + lane] = (double)cur.x;
+            sh_xd[gb + lane] = make_double2((double)cur.x, dl);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed in LDS
-        if (a.dbg & 2) __builtin_amdgcn_s_sleep(8);
-        if (a.dbg & 4) __syncthreads();
         wave_lds_sync();
+        PB_STAMP(0)
         // ---- phase 1: partial sums of the own rows (pbcd.py:56-67), published per slot
         double gs[QM], hs[QM];
 #pragma unroll
@@ -422,34 +438,31 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             gs[t] = 0.0;
             hs[t] = 0.0;
         }
-        for (int u = 0; u < nfast; ++u) {
-            const double x = sh_ex[gb + u], dl = sh_edl[gb + u];
-            const int qi = smeta[gb + u] & 7;
-            if ((a.dbg & 8) && kl) {  // staged row == memory?  (all stores of the last step drained)
-                const T ref = A[(size_t)srow[gb + u] * rowlen + lane];
-                const T got = rows_at(par, u, 0)[wlane];
-                const int hzf = (smeta[gb + u] >> 7) & 1;
-                atomicAdd(a.dbg_out + 2, 1u);
-                if (g == 3 && b == 0 && wave == 1) {  // dump: [u][lane] -> (ref, got)
-                    float* dump = reinterpret_cast<float*>(a.dbg_out + 16);
-                    dump[(u * 64 + wlane) * 2] = (float)ref;
-                    dump[(u * 64 + wlane) * 2 + 1] = (float)got;
-                }
-                if (ref != got) {
-                    atomicAdd(a.dbg_out + hzf, 1u);
-                    atomicMin(a.dbg_out + 3, (unsigned)b);
-                    atomicMax(a.dbg_out + 4, (unsigned)u);
-                    atomicAdd(a.dbg_out + 5 + (wave & 7), 1u);
-                }
-            }
-            const double p = pb_sel(po, qi);
-            double ad[AS];
+        // the group's fast entries are sorted by slot: segment t = [seg[t], seg[t+1]) (one ballot
+        // per slot on the lane-parallel slot indices), so the slot's p_j is a static register
+        int seg[QM + 1];
+        seg[0] = 0;
 #pragma unroll
-            for (int t = 0; t < AS; ++t) ad[t] = kl ? (double)rows_at(par, u, t)[wlane] : 0.0;
-            const double dprev = kl ? grad_factor<M>(ad, x, p) : 0.0;
-            const double tg = dl * dprev, th = dprev * dprev;
-            pb_acc<QM>(gs, qi, tg);
-            pb_acc<QM>(hs, qi, th);
+        for (int t = 0; t < QM; ++t) {
+            const unsigned long long bal = __ballot(lane < nfast && (cur.meta & 7) <= t);
+            seg[t + 1] = (L == 64) ? __builtin_popcountll(bal)
+                                   : __builtin_popcount((unsigned)(bal >> (32 * (grp & 1))));
+        }
+#pragma unroll
+        for (int t = 0; t < QM; ++t) {
+            double gacc = 0.0, hacc = 0.0;
+            const double p = po[t];
+            for (int u = seg[t]; u < seg[t + 1]; ++u) {
+                const double2 xd = sh_xd[gb + u];
+                double ad[AS];
+#pragma unroll
+                for (int tt = 0; tt < AS; ++tt) ad[tt] = (double)rows_at(par, u, tt)[wlane];
+                const double dprev = kl ? grad_factor<M>(ad, xd.x, p) : 0.0;
+                gacc += xd.y * dprev;
+                hacc += dprev * dprev;
+            }
+            gs[t] = gacc;
+            hs[t] = hacc;
         }
         for (int u = ER; u < cur.cnt; ++u) {  // slow path: beyond the LDS-staged rows
             const int e = cur.e0 + u;
@@ -467,16 +480,24 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             pb_acc<QM>(gs, qi, dl * dprev);
             pb_acc<QM>(hs, qi, dprev * dprev);
         }
+        {
+            // sum_s inv_step_sizes[s] (pbcd.py:68-70) of the QM slots by one butterfly: lane l
+            // ends with the sum of slot (l & (QM-1)); lane L-2 of slot t's vector needs slot t
+            double hv[QM];
 #pragma unroll
-        for (int t = 0; t < QM; ++t) {
-            const int q = grp + t * NG;
-            if (q < nw) {
-                const double hsum = group_sum(hs[t], L);  // sum_s inv_step_sizes[s] (pbcd.py:68-70)
-                const double v = (lane == L - 2) ? hsum : (kl ? gs[t] : 0.0);
-                prb_store_granule(slabA + ((size_t)q * a.G + g) * L + lane, v, tag);
+            for (int t = 0; t < QM; ++t) hv[t] = hs[t];
+            const double hr = pb_multi_reduce<QM, L>(hv, lane);
+#pragma unroll
+            for (int t = 0; t < QM; ++t) {
+                const int q = grp + t * NG;
+                const double hsum = __shfl(hr, t, L);
+                if (q < nw) {
+                    const double v = (lane == L - 2) ? hsum : (kl ? gs[t] : 0.0);
+                    prb_store_granule(slabA + ((size_t)q * a.G + g) * L + lane, v, tag);
+                }
             }
         }
-        PB_STAMP(0)
+        PB_STAMP(1)
 
         // ---- phase 2: owners reduce their slot over the workgroups and take the step
         const int n_rounds = fixed_owner ? 1 : (nw + a.G - 1) / a.G;
@@ -519,7 +540,8 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 }
                 red[grp * L + lane] = tot;
             }
-            __syncthreads();
+            PB_STAMP(2)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // part sums in LDS
             if (q >= ncols && q < nw && grp == 0) {
                 // slot unused in this step but read at the buffer's next use: rewritten now
                 prb_store_granule(slabB + (size_t)q * L + lane, 0.0, tag);
@@ -582,13 +604,32 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                         v /= 1 + 2 * st0;  // squaredl21.py:46
                     }
                 }
-                const double l2 = sqrt(group_sum(v * v, L));
+                const double l2 = sqrt(pb_group_allsum<L>(v * v));
                 const double outv = (lane == L - 2) ? l2 : ((lane == L - 1) ? st0 : v);
                 prb_store_granule(slabB + (size_t)q * L + lane, outv, tag);
             }
         }
-        PB_STAMP(1)
+        PB_STAMP(3)
 
+        // ---- prefetch: entries of step b+2, rows of step b+1 that this step does not touch,
+        // column ids / P rows / old norms of the coming steps.  Issued before the collect poll:
+        // vmcnt retires in order, so the first tag check waits for these loads too -- but the
+        // owners need about that long to reduce and publish anyway
+        int b3e0, b3e1;
+        bounds(b + 3, b3e0, b3e1);
+        load_entries(nn, b2e0, b2e1);
+        fetch_rows(nxt, par ^ 1, 0);
+        int j2[QM];
+#pragma unroll
+        for (int t = 0; t < QM; ++t) {
+            j2[t] = col_id(c2, c3 - c2, grp + t * NG);
+            pon[t] = (j1[t] >= 0 && kl) ? P[(size_t)j1[t] * k + lane] : 0.0;
+        }
+        const int oj2 = col_id(c2, c3 - c2, oq);
+        opon = (oj1 >= 0 && grp == 0 && kl) ? P[(size_t)oj1 * k + lane] : 0.0;
+        const int cj2 = (wave == 0) ? col_id(c2, c3 - c2, wlane) : -1;
+        cn1 = (cj1 >= 0 && chained) ? rs.norms[cj1] : 0.0;
+        PB_STAMP(4)
         // ---- phase 3: every workgroup collects the published vectors of all slots
         {
             const int total = ncols * L;
@@ -623,26 +664,10 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 }
             }
         }
-        // ---- prefetch (behind the step's last poll: vmcnt retires in order, earlier loads
-        // would delay every tag check): entries of step b+2, rows of step b+1 that this step
-        // does not touch, column ids / P rows / old norms of the coming steps
-        int b3e0, b3e1;
-        bounds(b + 3, b3e0, b3e1);
-        load_entries(nn, b2e0, b2e1);
-        fetch_rows(nxt, par ^ 1, 0);
-        int j2[QM];
-#pragma unroll
-        for (int t = 0; t < QM; ++t) {
-            j2[t] = col_id(c2, c3 - c2, grp + t * NG);
-            pon[t] = (j1[t] >= 0 && kl) ? P[(size_t)j1[t] * k + lane] : 0.0;
-        }
-        const int oj2 = col_id(c2, c3 - c2, oq);
-        opon = (oj1 >= 0 && grp == 0 && kl) ? P[(size_t)oj1 * k + lane] : 0.0;
-        const int cj2 = (wave == 0) ? col_id(c2, c3 - c2, wlane) : -1;
-        cn1 = (cj1 >= 0 && chained) ? rs.norms[cj1] : 0.0;
+        PB_STAMP(5)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // sh_pt / sh_scal
         if (!*sh_ok) break;
-        PB_STAMP(2)
+        PB_STAMP(9)
 
         // ---- phase 4: shrink factors.  L1: none; L21: from (l2, st0); SquaredL21 / OmegaCS:
         // the scalar cache recurrence in step order (every workgroup redundantly; every
@@ -661,87 +686,80 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // factors in LDS
-        PB_STAMP(3)
+        PB_STAMP(6)
 
         // ---- phase 5: p_j = f * p_j', write-back, scatter over the own rows (pbcd.py:135-146)
         double pn[QM], up[QM], lu[QM], mv[QM];
+        {
+            double mvv[QM], vav[QM];
 #pragma unroll
-        for (int t = 0; t < QM; ++t) {
-            const int q = grp + t * NG;
-            pn[t] = 0.0;
-            up[t] = 0.0;
-            lu[t] = 0.0;
-            mv[t] = 0.0;
-            if (q < ncols) {
+            for (int t = 0; t < QM; ++t) {
+                const int q = min(grp + t * NG, 63);
+                const bool vq = grp + t * NG < ncols;
                 const double f = sh_scal[4 * q + 2];
-                pn[t] = kl ? sh_pt[q * L + lane] * f : 0.0;
-                up[t] = kl ? po[t] - pn[t] : 0.0;
+                const double pt = sh_pt[q * L + lane];
+                pn[t] = (vq && kl) ? pt * f : 0.0;
+                up[t] = (vq && kl) ? po[t] - pn[t] : 0.0;
                 lu[t] = lam * up[t];
-                mv[t] = group_sum((up[t] != 0.0) ? 1.0 : 0.0, L);  // 0: block did not move
-                if (g == 0) {
-                    if (kl) P[(size_t)j0[t] * k + lane] = pn[t];
-                    const double va = group_sum(fabs(up[t]), L);
-                    if (lane == 0) viol_pos[c0 + q] = va;
-                }
+                mvv[t] = (up[t] != 0.0) ? 1.0 : 0.0;
+                vav[t] = fabs(up[t]);
+                if (g == 0 && vq && kl) P[(size_t)j0[t] * k + lane] = pn[t];
+            }
+            // per slot: did the block move (exact no-op otherwise), ||Delta||_1: one butterfly
+            // each; lane t of the group ends with slot t's sum
+            const double mr = pb_multi_reduce<QM, L>(mvv, lane);
+#pragma unroll
+            for (int t = 0; t < QM; ++t) mv[t] = __shfl(mr, t, L);
+            if (g == 0) {
+                const double vr = pb_multi_reduce<QM, L>(vav, lane);
+                if (lane < QM && grp + lane * NG < ncols) viol_pos[c0 + grp + lane * NG] = vr;
             }
         }
         {
-            // the sums over components of CH entries at a time land lane-parallel: after the
-            // butterfly lane l holds the sum of entry (l & (CH-1)) of the chunk
-            double s1 = 0.0, s2 = 0.0;
-            for (int cb = 0; cb < nfast; cb += CH) {
-                double term[CH], term2[M == 0 ? CH : 1];
+            // per slot (static registers po / up / lu), per entry: new cache row, then the
+            // prediction decrement sum_s lam_s Delta_s dA_s by one DPP all-reduce; the lane that
+            // holds the entry's yhat (lane u) applies it
+            double ynew = (double)cur.yh;
+            bool ymoved = false;
 #pragma unroll
-                for (int uu = 0; uu < CH; ++uu) {
-                    const int u = cb + uu;
-                    term[uu] = 0.0;
-                    if constexpr (M == 0) term2[uu] = 0.0;
-                    if (u < nfast) {
-                        const double x = sh_ex[gb + u];
-                        const int qi = smeta[gb + u] & 7;
-                        const double mvl = pb_sel(mv, qi);
-                        if (mvl != 0.0) {  // group-uniform; a block that did not move: no-op
-                            const double pol = pb_sel(po, qi), upl = pb_sel(up, qi);
-                            const size_t base = (size_t)srow[gb + u] * rowlen;
-                            if constexpr (M == 0) {  // pbcd_all.py:121-127
-                                const double pnl = pb_sel(pn, qi);
-                                const double a0 = kl ? (double)rows_at(par, u, 0)[wlane] : 0.0;
-                                double a1 = a0 / (1.0 + x * pol);
-                                a1 *= 1.0 + x * pnl;
-                                if (kl) A[base + lane] = (T)a1;
-                                term[uu] = kl ? lam * a0 : 0.0;
-                                term2[uu] = kl ? lam * a1 : 0.0;
-                            } else {
-                                const double lul = pb_sel(lu, qi);
-                                double dprev = x;
+            for (int t = 0; t < QM; ++t) {
+                if (mv[t] == 0.0) continue;  // block did not move: exact no-op (group-uniform)
+                const double pol = po[t], upl = up[t], lul = lu[t], pnl = pn[t];
+                for (int u = seg[t]; u < seg[t + 1]; ++u) {
+                    const double x = sh_xd[gb + u].x;
+                    const size_t base = (size_t)srm[u].x * rowlen + lane;
+                    double ad[AS];
 #pragma unroll
-                                for (int t = 1; t < M; ++t) {
-                                    const double avv =
-                                        kl ? (double)rows_at(par, u, t - 1)[wlane] : 0.0;
-                                    const double dcur = x * (avv - pol * dprev);
-                                    if (kl)
-                                        A[base + (size_t)(t - 1) * k + lane] =
-                                            (T)(avv - upl * dprev);
-                                    dprev = dcur;
-                                }
-                                term[uu] = kl ? lul * dprev : 0.0;
-                            }
+                    for (int tt = 0; tt < AS; ++tt) ad[tt] = (double)rows_at(par, u, tt)[wlane];
+                    if constexpr (M == 0) {  // pbcd_all.py:121-127
+                        const double a0 = kl ? ad[0] : 0.0;
+                        double a1 = a0 / (1.0 + x * pol);
+                        a1 *= 1.0 + x * pnl;
+                        if (kl) A[base] = (T)a1;
+                        const double d_old = pb_group_allsum<L>(kl ? lam * a0 : 0.0);
+                        const double d_new = pb_group_allsum<L>(kl ? lam * a1 : 0.0);
+                        if (lane == u) {
+                            ynew = (ynew - d_old) + d_new;
+                            ymoved = true;
+                        }
+                    } else {
+                        double dprev = x;
+#pragma unroll
+                        for (int tt = 1; tt < M; ++tt) {
+                            const double avv = ad[tt - 1];
+                            const double dcur = x * (avv - pol * dprev);
+                            if (kl) A[base + (size_t)(tt - 1) * k] = (T)(avv - upl * dprev);
+                            dprev = dcur;
+                        }
+                        const double dec = pb_group_allsum<L>(kl ? lul * dprev : 0.0);
+                        if (lane == u) {
+                            ynew -= dec;
+                            ymoved = true;
                         }
                     }
                 }
-                const double r1 = pb_multi_reduce<CH, L>(term, lane);
-                const bool mine = (lane >= cb) && (lane < cb + CH);
-                s1 = mine ? r1 : s1;
-                if constexpr (M == 0) {
-                    const double r2 = pb_multi_reduce<CH, L>(term2, lane);
-                    s2 = mine ? r2 : s2;
-                }
             }
-            if (lane < nfast) {
-                const double mvl = pb_sel(mv, cur.meta & 7);
-                const double ynew = (M == 0) ? (((double)cur.yh - s1) + s2) : ((double)cur.yh - s1);
-                if (mvl != 0.0) yy[2 * (size_t)cur.row] = (T)ynew;
-            }
+            if (ymoved) yy[2 * (size_t)cur.row] = (T)ynew;
         }
         for (int u = ER; u < cur.cnt; ++u) {  // slow path
             const int e = cur.e0 + u;
@@ -784,6 +802,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 if (lane == 0) yy[2 * (size_t)i] = (T)(y0 - accv);
             }
         }
+        PB_STAMP(7)
         // ---- rotate the pipeline
         cur = nxt;
         nxt = nn;
@@ -806,7 +825,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         c2 = c3;
         c3 = c4;
         __syncthreads();  // rows move between groups from step to step (stores drained)
-        PB_STAMP(4)
+        PB_STAMP(8)
     }
 #undef PB_STAMP
     if (wave == 0 && g == 0 && wlane < 2 * (kMaxDegree + 2)) {
@@ -816,7 +835,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     }
     if (STAMP && a.stamps != nullptr && tid == 0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a.stamps[(size_t)g * 16 + q] = acc[q];
+        for (int q = 0; q < 12; ++q) a.stamps[(size_t)g * 16 + q] = acc[q];
     }
 }
 

@@ -21,7 +21,8 @@ X, y = make_problem(n, d, 50, 0)
 Xc = X.tocsc()
 Xc.sort_indices()
 k = 30
-PHASES = ["gather+publish", "owner reduce+step", "collect", "chain", "scatter+barrier"]
+PHASES = ["p0 hazard+wait", "p1 sums+publish", "p2 owner poll", "p2 barrier+step+publish", "prefetch issue",
+          "p3 collect poll", "p4 chain+barrier", "p5 scatter", "rotate+end barrier", "p3 barrier"]
 for G in groups:
     for stamps in (0, 1):
         eng = HipEngine(0, "f32")
@@ -45,10 +46,11 @@ for G in groups:
         if int(os.environ.get("PB_DBG", 0)) & 8:
             out["dbg"] = [int(x) for x in eng.debug_prb_stamps().ravel()[:16]]
         elif stamps:
-            st = eng.debug_prb_stamps()[:, :5].astype(np.float64) / eng.n_batches
+            st = eng.debug_prb_stamps()[:, :10].astype(np.float64) / eng.n_batches
             scale = (dt * 1e9 / eng.n_batches) / st[0].sum()  # cycles -> ns via the wall time
             out["cycles_per_step_wg0"] = round(float(st[0].sum()))
             out["phase_ns_wg0"] = dict(zip(PHASES, [round(float(x * scale)) for x in st[0]]))
+            out["phase_ns_wg1"] = dict(zip(PHASES, [round(float(x * scale)) for x in st[min(1, len(st) - 1)]]))
             out["phase_ns_mean"] = dict(zip(PHASES, [round(float(x * scale)) for x in st.mean(0)]))
             out["phase_ns_max"] = dict(zip(PHASES, [round(float(x * scale)) for x in st.max(0)]))
         print(json.dumps(out), flush=True)

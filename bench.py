@@ -2,22 +2,27 @@
 """Headline benchmark: PCD epochs/sec on BASELINE config 2 (degree=2, n_components=30,
 regularizer='squaredl12', solver='pcd', 1M x 100k synthetic CSR, ~50 nnz/row).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4}]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one full training iteration of the reference's _fit_pcd loop
-(sparse_factorization_machines.py:196-256): one cd_linear epoch + one pcd epoch
-over all k components, on data already resident in HBM.  The timed region calls
-exactly what ``SparseFactorizationMachineRegressor.fit`` calls per iteration
-(``HipEngine.cd_linear_epoch`` + ``HipEngine.pcd_epoch`` through the C ABI).
+A "step" is one full training iteration of the reference's fit loop
+(sparse_factorization_machines.py:196-256 / :287-350): one cd_linear epoch, the lower-order
+epochs (fit_lower='explicit') and the top-order epoch, on data already resident in HBM.  The
+timed region calls exactly what the estimators call per iteration (``HipEngine.*_epoch`` through
+the C ABI).  ``--config 3`` / ``4`` run the other BASELINE configurations on the same matrix
+(degree 3 / omegati / pcd / k=16; degree 2 / omegacs / pbcd / k=30).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel (pcd_grad): algorithmic bytes per launch / average
-                launch duration (HIP events on the engine's stream) vs 8 TB/s HBM
-  cpu_baseline  the CPU oracle (float64, 1 thread) on a bounded sample of the same
-                workload, timed on this host
-N > 1: rows are sharded over the ranks (strong scaling on the same matrix); the
-column partial sums of every step are all-reduced with RCCL.
+  roofline        dominant kernel: algorithmic bytes per launch / average launch duration (HIP
+                  events on the engine's stream) vs 8 TB/s HBM.  `traffic` = HBM bytes per
+                  launch from the rocprofv3 --pmc passes committed under profiles/ -- only if
+                  that file was collected with this engine version, else null
+  cpu_baseline    the CPU oracle (float64, 1 thread) on ONE FULL iteration of the same workload
+                  in the same column order, timed on this host
+  exact_schedule  the estimators' default schedule (reference order, parity at fit() level):
+                  dependent steps per sweep and ms per iteration from 3 component passes
+  f64             ms per iteration with float64 storage (the reference's own arithmetic)
+N > 1: rows are sharded over the ranks (strong scaling on the same matrix).
 """
 import argparse
 import json
@@ -31,23 +36,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# workload = BASELINE.json configs[1]
 N_SAMPLES = int(os.environ.get("SPFM_BENCH_N", 1_000_000))
 N_FEATURES = int(os.environ.get("SPFM_BENCH_D", 100_000))
 NNZ_PER_ROW = 50
-K = 30
-DEGREE = 2
-REG = "squaredl12"
-# hyper-parameters: well conditioned and such that P does NOT collapse
-# to zero (squaredl12's threshold scales with sum_j |P[s,j]| ~ 800 here: gamma = 1 would zero
-# every coordinate in the first epoch, after which the scatter half of every step is a
-# no-op).  The fraction of non-zero P entries after the run is reported.
-ALPHA, BETA, GAMMA, ETA0 = 1.0, 10.0, 1e-4, 1.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# bumped whenever a hot kernel changes; profiles/<round>_traffic.json records the tag it was
+# collected with, and `traffic` is only reported when the two agree
+ENGINE_TAG = "r02-e3"
+
+# hyper-parameters: well conditioned and such that P does NOT collapse to
+# zero (with gamma = 1 every coordinate is thresholded away in the first epoch and the scatter
+# half of every later step is a no-op).  The non-zero fraction of P after the run is reported.
+CONFIGS = {
+    2: dict(name="BASELINE configs[1]", solver="pcd", reg="squaredl12", degree=2, k=30,
+            alpha=1.0, beta=10.0, gamma=1e-4),
+    3: dict(name="BASELINE configs[2]", solver="pcd", reg="omegati", degree=3, k=16,
+            alpha=1.0, beta=10.0, gamma=1e-6),
+    4: dict(name="BASELINE configs[3]", solver="pbcd", reg="omegacs", degree=2, k=30,
+            alpha=1.0, beta=1.0, gamma=1e-3),
+}
+ETA0 = 1.0
 
 
 def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def alg_bytes(cfg, n, nnz, tsz=4):
+    """Compulsory traffic of one iteration, SURVEY.md section 8(d) (T-byte values, int32 ids)."""
+    m, k = cfg["degree"], cfg["k"]
+    lin = (4 + 4 * tsz) * nnz
+    if cfg["solver"] == "pcd":
+        return lin + sum(2 * 4 * nnz + tsz * (mm - 1) * n * k
+                         + k * nnz * (4 + 4 * tsz + 2 * tsz * (mm - 1)) for mm in range(2, m + 1))
+    return lin + 2 * 4 * nnz + tsz * (m - 1) * n * k + nnz * (4 + 4 * tsz + 2 * tsz * (m - 1) * k)
 
 
 def main():
@@ -55,10 +77,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the exact-schedule and f64 measurements")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--schedule", default="colored", choices=["colored", "exact"])
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    K, DEGREE = cfg["k"], cfg["degree"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -73,7 +100,7 @@ def main():
         import torch.distributed as dist
 
         # torch.distributed only carries control messages (unique id, barrier, max of the
-        # timings): gloo.  The data path's collectives are the engine's own RCCL calls.
+        # timings): gloo.  The data path's collectives are the engine's own.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -92,38 +119,50 @@ def main():
     nnz = Xc.nnz
     if rank == 0:
         log("data %dx%d nnz=%d generated in %.1fs" % (n, d, nnz, time.time() - t0))
-
-    eng = HipEngine(local_rank, args.precision)
-    for kv in filter(None, os.environ.get("SPFM_OPTS", "").split(",")):  # e.g. prb_groups=32
-        key, val = kv.split("=")
-        eng.set_option(key, int(val))
-    conflict = None
-    if world > 1:
-        lo, hi = spdist.row_block(n, rank, world)
-        Xl = canonical_csc(X[lo:hi])
-        spdist.init_engine_comm(eng)  # RCCL unique id shipped over the gloo group
-        eng.set_data(Xl, y[lo:hi])
-        conflict = Xc
-    else:
-        eng.set_data(Xc, y)
-    P0 = 0.01 * np.random.RandomState(0).randn(1, K, d)
+    n_orders = DEGREE - 1
+    P0 = 0.01 * np.random.RandomState(0).randn(n_orders, K, d)
     lams = np.ones(K)
-    eng.set_params(P0, np.zeros(d), lams)
-    eng.configure("pcd", "squared", REG, DEGREE)
-    eng.init_pred(DEGREE, True, False)
+    ic = np.arange(K, dtype=np.int32)
+    jf0 = np.arange(d, dtype=np.int32)
+
+    def make_engine(precision, schedule):
+        eng = HipEngine(local_rank, precision)
+        for kv in filter(None, os.environ.get("SPFM_OPTS", "").split(",")):  # e.g. prb_groups=32
+            key, val = kv.split("=")
+            eng.set_option(key, int(val))
+        conflict = None
+        if world > 1:
+            lo, hi = spdist.row_block(n, rank, world)
+            spdist.init_engine_comm(eng)
+            eng.set_data(canonical_csc(X[lo:hi]), y[lo:hi])
+            conflict = Xc
+        else:
+            eng.set_data(Xc, y)
+        eng.set_params(P0, np.zeros(d), lams)
+        eng.configure(cfg["solver"], "squared", cfg["reg"], DEGREE)
+        eng.init_pred(DEGREE, True, DEGREE == 3)
+        t1 = time.time()
+        order = eng.set_schedule(schedule, jf0, conflict)
+        return eng, order, time.time() - t1
+
+    def iteration(eng, comps=None):
+        """One pass of the reference's iteration body; `comps` limits the pcd component loop."""
+        v = eng.cd_linear_epoch(cfg["alpha"])
+        for deg in list(range(2, DEGREE)) + [DEGREE]:
+            o = DEGREE - deg if deg != DEGREE else 0
+            if cfg["solver"] == "pcd":
+                v += eng.pcd_epoch(o, deg, cfg["beta"], cfg["gamma"], ETA0,
+                                   ic if comps is None else ic[:comps])
+            else:
+                v += eng.pbcd_epoch(o, deg, cfg["beta"], cfg["gamma"], ETA0)
+        return v
+
+    eng, order, t_sched = make_engine(args.precision, args.schedule)
     y_pred0 = eng.get_y_pred() if (world == 1 and not args.no_cpu_baseline) else None
-    t0 = time.time()
-    order = eng.set_schedule(args.schedule, np.arange(d, dtype=np.int32), conflict)
     n_batches = eng.n_batches
     if rank == 0:
         log("schedule '%s': %d dependent steps per sweep (%.1fs)" % (args.schedule, n_batches,
-                                                                     time.time() - t0))
-    ic = np.arange(K, dtype=np.int32)
-
-    def one_step():
-        v = eng.cd_linear_epoch(ALPHA)
-        v += eng.pcd_epoch(0, DEGREE, BETA, GAMMA, ETA0, ic)
-        return v
+                                                                     t_sched))
 
     def fence():
         torch.cuda.synchronize()
@@ -133,11 +172,11 @@ def main():
 
     viols = []
     for _ in range(args.warmup):
-        viols.append(one_step())
+        viols.append(iteration(eng))
     fence()
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        viols.append(one_step())
+        viols.append(iteration(eng))
     fence()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
@@ -150,94 +189,138 @@ def main():
     P_end, _ = eng.get_params()
     nnz_frac_P = float((P_end != 0).mean())
 
-    # ---- roofline of the dominant kernel (profiled pass, outside the timed region):
-    # HIP events on the engine's stream around every launch of that kernel
+    # ---- roofline of the dominant kernel (profiled epoch, outside the timed region): HIP
+    # events on the engine's stream around every launch of that kernel
+    tsz = 4 if args.precision == "f32" else 8
     roof = None
-    persistent = bool(eng.get_option("persistent_active"))
     eng.profile_reset()
     eng.profile_enable(True)
-    eng.pcd_epoch(0, DEGREE, BETA, GAMMA, ETA0, ic[:4] if persistent else ic[:2])
-    eng.profile_enable(False)
-    g_ms, g_launch, g_nnz = eng.profile_get(0)
-    s_ms, s_launch, s_nnz = eng.profile_get(1)
-    tsz = 4 if args.precision == "f32" else 8
-    if persistent:
-        # pcd_prb_kernel = one whole component pass (gather + exchange + chain + scatter);
-        # per column entry: row 4 + value T + (yhat, y) read 2T + yhat write T +
-        # A[i,1..m-1] read and write 2T(m-1)  (= SURVEY 8d's k*nnz*(20 + 8(m-1)) term)
-        kname, bytes_per_nnz = "pcd_prb_kernel", 4 + tsz + 3 * tsz + 2 * tsz * (DEGREE - 1)
+    if cfg["solver"] == "pcd":
+        persistent = bool(eng.get_option("persistent_active"))
+        eng.pcd_epoch(0, DEGREE, cfg["beta"], cfg["gamma"], ETA0, ic[:4] if persistent else ic[:2])
+        which = 0
+        if persistent:
+            # one launch = one component pass; per column entry: row 4 + value T + (yhat, y)
+            # read 2T + yhat write T + A[i,1..m-1] read and write 2T(m-1)
+            kname, bytes_per_nnz = "pcd_prb_kernel", 4 + 4 * tsz + 2 * tsz * (DEGREE - 1)
+        else:
+            kname, bytes_per_nnz = "pcd_grad_kernel", 4 + 3 * tsz + tsz * (DEGREE - 1)
     else:
-        # pcd_grad_kernel reads per column entry: row 4 + value T + A[i,1..m-1] T(m-1) +
-        # (yhat, y) 2T
-        kname, bytes_per_nnz = "pcd_grad_kernel", 4 + tsz + tsz * (DEGREE - 1) + 2 * tsz
+        persistent = True
+        eng.pbcd_epoch(0, DEGREE, cfg["beta"], cfg["gamma"], ETA0)
+        persistent = bool(eng.get_option("pbprb_active"))
+        which = 2
+        # one launch = one pbcd epoch; per entry: row 4 + value T + (yhat, y) 2T + yhat write T
+        # + A[i,1..m-1,:] read and write 2T(m-1)k
+        kname = "pbcd_prb_kernel" if persistent else "pbcd_grad_kernel"
+        bytes_per_nnz = (4 + 4 * tsz + 2 * tsz * (DEGREE - 1) * K) if persistent else \
+            (4 + 3 * tsz + tsz * (DEGREE - 1) * K)
+    eng.profile_enable(False)
+    g_ms, g_launch, g_nnz = eng.profile_get(which)
     if g_launch > 0 and g_ms > 0:
         avg_us = 1e3 * g_ms / g_launch
         bytes_per_launch = bytes_per_nnz * g_nnz / g_launch
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
-        # measured HBM-side traffic per launch: PMC counters cannot be read from inside
-        # this process; the value comes from the committed rocprofv3 --pmc passes of the
-        # same command (profiles/r01_traffic.json, collected per MI355X_MICROARCH.md HBM)
-        traffic = None
+        traffic, traffic_src = None, "not collected for this engine version (%s)" % ENGINE_TAG
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if kname in tj and N_SAMPLES == 1_000_000 and N_FEATURES == 100_000 and world == 1:
-                traffic = round(1024.0 * (tj[kname]["fetch_kb_per_launch"]
-                                          + tj[kname]["write_kb_per_launch"]), 1)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            ent = tj.get("config%d" % args.config, {}).get(kname)
+            if (ent and tj.get("engine_tag") == ENGINE_TAG and N_SAMPLES == 1_000_000
+                    and N_FEATURES == 100_000 and world == 1 and args.precision == "f32"):
+                traffic = round(1024.0 * (ent["fetch_kb_per_launch"]
+                                          + ent["write_kb_per_launch"]), 1)
+                traffic_src = "profiles/r02_traffic.json (rocprofv3 --pmc passes, engine %s)" \
+                    % ENGINE_TAG
         except Exception:
-            traffic = None
+            pass
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "avg_launch_us": round(avg_us, 3),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_us": round(avg_us, 3),
                 "alg_bytes_per_launch": round(bytes_per_launch, 1),
                 "launches_timed": int(g_launch)}
         if persistent:
-            # 0 = row state in global memory, 1 / 2 = row block resident in LDS:
-            # then `traffic` is below the algorithmic bytes, which charge every gather / scatter
-            roof["row_block_in_lds"] = int(eng.get_option("prb_lds_active"))
             roof["dependent_steps_per_launch"] = n_batches
             roof["us_per_dependent_step_in_kernel"] = round(avg_us / n_batches, 3)
-        else:
-            roof["sync_kernel_avg_us"] = round(1e3 * s_ms / max(s_launch, 1), 3)
-    # whole-iteration algorithmic traffic, f32 layout
-    nnz_glob = nnz
-    b_alg = 8 * nnz_glob + 4 * (DEGREE - 1) * n * K + K * nnz_glob * (20 + 8 * (DEGREE - 1)) \
-        + 20 * nnz_glob
+            if cfg["solver"] == "pcd":
+                # 0 = row state in global memory, 1 / 2 = row block resident in LDS
+                roof["row_block_in_lds"] = int(eng.get_option("prb_lds_active"))
+    b_alg = alg_bytes(cfg, n, nnz)
     iter_gbs = b_alg / (ms_per_step * 1e-3) / 1e9
+    steps_per_iter = (1 + (K * (DEGREE - 1) if cfg["solver"] == "pcd" else (DEGREE - 1))) * n_batches
+    eng.close()
 
-    # ---- CPU baseline: the oracle on a bounded sample of the same workload
+    # ---- the estimators' default schedule ('exact': the reference's own order) and f64 storage
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras and cfg["solver"] == "pcd":
+        e2, _, ts = make_engine(args.precision, "exact")
+        nb2 = e2.n_batches
+        iteration(e2, comps=1)  # builds the entry stream, warms up
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        e2.cd_linear_epoch(cfg["alpha"])
+        torch.cuda.synchronize()
+        t_lin = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        e2.pcd_epoch(0, DEGREE, cfg["beta"], cfg["gamma"], ETA0, ic[:3])
+        torch.cuda.synchronize()
+        t_pass = (time.perf_counter() - t1) / 3
+        e2.close()
+        extras["exact_schedule"] = {
+            "dependent_steps_per_sweep": nb2, "schedule_build_s": round(ts, 2),
+            "ms_per_iteration": round(1e3 * (t_lin + K * t_pass * (DEGREE - 1)), 1),
+            "measured": "1 cd_linear epoch (%.0f ms) + 3 top-order component passes (%.0f ms "
+                        "each), extrapolated to %d passes per order" % (1e3 * t_lin, 1e3 * t_pass, K),
+            "is_estimator_default": True}
+    if rank == 0 and world == 1 and not args.no_extras and args.precision == "f32":
+        e3, _, _ = make_engine("f64", args.schedule)
+        iteration(e3)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        iteration(e3)
+        torch.cuda.synchronize()
+        extras["f64"] = {"ms_per_iteration": round(1e3 * (time.perf_counter() - t1), 2),
+                         "schedule": args.schedule}
+        e3.close()
+
+    # ---- CPU baseline: the oracle on one full iteration of the same workload
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
 
         orc.build()
         ds = orc.CSC(Xc)
-        Pc = np.ascontiguousarray(P0[0].copy())
+        Pc = np.ascontiguousarray(P0.copy())
         wc = np.zeros(d)
         yp = np.ascontiguousarray(y_pred0)
         cn = np.asarray(Xc.multiply(Xc).sum(axis=0)).ravel()
-        regc = orc.Regularizer(REG)
-        regc.init_cache_pcd(DEGREE, d, K)
-        A = np.zeros((n, DEGREE + 1))
+        regc = orc.Regularizer(cfg["reg"])
         jf = np.ascontiguousarray(order)
         t1 = time.perf_counter()
-        orc.cd_linear_epoch(wc, ds, y, yp, cn, ALPHA, "squared", jf)
-        t_lin = time.perf_counter() - t1
-        n_pass = 1
-        t1 = time.perf_counter()
-        orc.pcd_epoch(Pc, ds, y, yp, lams, DEGREE, BETA, GAMMA, ETA0, regc, "squared", A,
-                      ic[:n_pass], jf)
-        t_pass = (time.perf_counter() - t1) / n_pass
-        cpu_epoch_s = t_lin + K * t_pass
-        cpu = {"value": round(1.0 / cpu_epoch_s, 6), "unit": "epochs/s", "cores": 1,
-               "kind": "port",
-               "sample": "1 cd_linear epoch (%.2fs) + %d of %d pcd component passes (%.2fs each) "
-                         "of the same 1Mx100k workload in the same column order, extrapolated "
-                         "to %d passes" % (t_lin, n_pass, K, t_pass, K),
+        orc.cd_linear_epoch(wc, ds, y, yp, cn, cfg["alpha"], "squared", jf)
+        if cfg["solver"] == "pcd":
+            regc.init_cache_pcd(DEGREE, d, K)
+            A = np.zeros((n, DEGREE + 1))
+            for deg in list(range(2, DEGREE)) + [DEGREE]:
+                o = DEGREE - deg if deg != DEGREE else 0
+                orc.pcd_epoch(Pc[o], ds, y, yp, lams, deg, cfg["beta"], cfg["gamma"], ETA0, regc,
+                              "squared", A, ic, jf)
+        else:
+            regc.init_cache_pbcd(DEGREE, d, K)
+            A = np.zeros((n, DEGREE + 1, K))
+            dA = np.zeros((n, DEGREE, K))
+            Pt = np.ascontiguousarray(Pc[0].T)
+            orc.pbcd_epoch(Pt, ds, y, yp, lams, DEGREE, cfg["beta"], cfg["gamma"], ETA0, regc,
+                           "squared", A, dA, jf)
+        cpu_s = time.perf_counter() - t1
+        cpu = {"value": round(1.0 / cpu_s, 6), "unit": "epochs/s", "cores": 1, "kind": "port",
+               "sample": "one full iteration (cd_linear + every component pass / block epoch) of "
+                         "the same %dx%d workload in the same column order: %.1f s" % (n, d, cpu_s),
                "host_cpus": os.cpu_count()}
 
     if rank == 0:
         out = {
-            "metric": "pcd_epochs_per_sec",
+            "metric": "pcd_epochs_per_sec" if cfg["solver"] == "pcd" else "pbcd_epochs_per_sec",
             "value": round(epochs_per_s, 4),
             "unit": "epochs/s",
             "n_gpus": world,
@@ -249,12 +332,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: degree=2 n_components=30 "
-                                   "regularizer=squaredl12 solver=pcd fit_linear=True on "
-                                   "%dx%d CSR nnz=%d (~50/row)" % (n, d, nnz),
+            "config": {"workload": "%s: degree=%d n_components=%d regularizer=%s solver=%s "
+                                   "fit_linear=True fit_lower=explicit on %dx%d CSR nnz=%d "
+                                   "(~50/row)" % (cfg["name"], DEGREE, K, cfg["reg"],
+                                                  cfg["solver"], n, d, nnz),
                        "schedule": args.schedule, "dependent_steps_per_sweep": n_batches,
-                       "alpha": ALPHA, "beta": BETA, "gamma": GAMMA,
-                       "parallelism": ("rows sharded x%d, per-step %s all-reduce"
+                       "alpha": cfg["alpha"], "beta": cfg["beta"], "gamma": cfg["gamma"],
+                       "parallelism": ("rows sharded x%d, per-step %s exchange"
                                        % (world, "host-shm (rehearsal)"
                                           if os.environ.get("SPFM_COMM") == "shm" else "RCCL"))
                        if world > 1 else "single GPU"},
@@ -262,13 +346,14 @@ def main():
             "cpu_baseline": cpu,
             "iteration_alg_GBs": round(iter_gbs, 2),
             "iteration_alg_frac_of_hbm_peak": round(iter_gbs / HBM_PEAK_GBS, 5),
-            "us_per_dependent_step": round(1e3 * ms_per_step / ((K + 1) * n_batches), 3),
+            "us_per_dependent_step": round(1e3 * ms_per_step / steps_per_iter, 3),
             "viol": [round(float(v), 6) for v in viols],
             "sum_loss_after": round(float(loss_after), 6),
             "nonzero_frac_P_after": round(nnz_frac_P, 4),
+            "engine_tag": ENGINE_TAG,
         }
+        out.update(extras)
         print(json.dumps(out), flush=True)
-    eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

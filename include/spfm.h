@@ -249,6 +249,12 @@ int spfm_debug_hop_latency(spfm_handle h, int partner, int rounds, double* ns_pe
 int spfm_debug_exchange_cost(spfm_handle h, int groups, int ncols, int readers_mod, int rounds,
                              double* ns_per_round);
 
+/* diagnostic: how often the device chains took the reference's "numerical error" branches
+ * since the last reset -- out[0] omegati.py:97-98 (clip), out[1] omegacs.py:90-96, out[2]
+ * omegacs.py:75-76, out[3] squaredl21.py:48-49 (out[4..7] reserved).  reset != 0 clears the
+ * counters after reading.  Counters are per process (all handles of the device). */
+int spfm_debug_branch_counts(spfm_handle h, unsigned* out8, int reset);
+
 #ifdef __cplusplus
 }
 #endif

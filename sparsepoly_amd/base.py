@@ -1,6 +1,11 @@
-"""Estimator base classes -- mirror of reference ``sparsepoly/base.py``."""
-from abc import ABCMeta
+"""Input validation and the regressor / classifier faces of the estimators.
 
+Behavioural contract (reference ``sparsepoly/base.py:17-142``): same class names, same error
+types and texts, same target handling (regressors: numeric 1-d targets cast to float64;
+classifiers: binary targets only, mapped to -1 / +1 by a ``LabelBinarizer`` kept as
+``label_binarizer_``).  The code is organised around two module-level helpers -- a registry
+look-up and a target validator -- with the mixins as thin shells.
+"""
 import numpy as np
 from sklearn.base import BaseEstimator, ClassifierMixin, RegressorMixin
 from sklearn.preprocessing import LabelBinarizer
@@ -9,78 +14,78 @@ from sklearn.utils.validation import check_X_y
 
 from .loss import CLASSIFICATION_LOSSES, REGRESSION_LOSSES
 
+_NOT_BINARY = ("Only binary targets supported. For training multiclass or multilabel models, "
+               "you may use the OneVsRest or OneVsAll metaestimators in scikit-learn.")
+_NO_PROBA = ("Probability estimates only available for loss='logistic'. You may use "
+             "probability calibration methods from scikit-learn instead.")
 
-class BaseSparsePoly(BaseEstimator, metaclass=ABCMeta):
+
+def _registry_lookup(kind, name, table):
+    """``table[name]`` or the reference's ValueError listing the valid names
+    (``base.py:19-24`` for losses, ``:28-33`` for regularizers)."""
+    try:
+        return table[name]
+    except KeyError:
+        options = '", "'.join(table)
+        raise ValueError('%s %s not supported. The available options are: "%s".'
+                         % (kind, name, options)) from None
+
+
+def _validated_xy(X, y, binary):
+    """``check_X_y`` as the reference calls it (``base.py:41-49,138``); for ``binary`` the
+    target must be a 1-d two-class vector (``:130-136``).  Returns X, y and -- for binary
+    targets -- the fitted ``LabelBinarizer``."""
+    if binary:
+        two_d = getattr(y, "ndim", None) is not None and np.ndim(y) > 1 and np.shape(y)[1] >= 2
+        if two_d or type_of_target(y) != "binary":
+            raise TypeError(_NOT_BINARY)
+        X, y = check_X_y(X, y, dtype=np.double, accept_sparse=True, multi_output=False)
+        binarizer = LabelBinarizer(pos_label=1, neg_label=-1)
+        return X, binarizer.fit_transform(y).ravel().astype(np.double), binarizer
+    X, y = check_X_y(X, y, accept_sparse=True, multi_output=False, dtype=np.double,
+                     y_numeric=True)
+    return X, np.asarray(y, dtype=np.double).ravel(), None
+
+
+class BaseSparsePoly(BaseEstimator):
+    """Registry access shared by every estimator (``_LOSSES`` / ``_REGULARIZERS`` are class
+    attributes of the concrete estimators)."""
+
     def _get_loss(self, loss):
-        """base.py:18-25"""
-        if loss not in self._LOSSES:
-            losses_str = '", "'.join(self._LOSSES)
-            raise ValueError(
-                f"Loss function {loss} not supported. The available options are:"
-                f' "{losses_str}".'
-            )
-        return self._LOSSES[loss]
+        return _registry_lookup("Loss function", loss, self._LOSSES)
 
     def _get_regularizer(self, regularizer):
-        """base.py:27-34"""
-        if regularizer not in self._REGULARIZERS:
-            regularizers_str = '", "'.join(self._REGULARIZERS)
-            raise ValueError(
-                f"Regularizer {regularizer} not supported. The available options are:"
-                f' "{regularizers_str}".'
-            )
-        return self._REGULARIZERS[regularizer]()
+        return _registry_lookup("Regularizer", regularizer, self._REGULARIZERS)()
 
 
 class SparsePolyRegressorMixin(RegressorMixin):
     _LOSSES = REGRESSION_LOSSES
 
     def _check_X_y(self, X, y):
-        """base.py:40-50"""
-        X, y = check_X_y(X, y, accept_sparse=True, multi_output=False, dtype=np.double,
-                         y_numeric=True)
-        y = y.astype(np.double).ravel()
-        return X, y
+        return _validated_xy(X, y, binary=False)[:2]
 
     def predict(self, X):
-        """base.py:52-65"""
+        """Predicted targets, shape (n_samples,) (``base.py:52-65``)."""
         return self._predict(X)
 
 
 class SparsePolyClassifierMixin(ClassifierMixin):
     _LOSSES = CLASSIFICATION_LOSSES
 
+    def _check_X_y(self, X, y):
+        X, y, self.label_binarizer_ = _validated_xy(X, y, binary=True)
+        return X, y
+
     def decision_function(self, X):
-        """base.py:70-84"""
+        """Raw model output; positive means the positive class (``base.py:70-84``)."""
         return self._predict(X)
 
     def predict(self, X):
-        """base.py:86-100"""
-        y_pred = self.decision_function(X) > 0
-        return self.label_binarizer_.inverse_transform(y_pred)
+        """Class labels as seen in ``fit`` (``base.py:86-100``)."""
+        return self.label_binarizer_.inverse_transform(self.decision_function(X) > 0)
 
     def predict_proba(self, X):
-        """base.py:102-124"""
-        if self.loss == "logistic":
-            return 1 / (1 + np.exp(-self.decision_function(X)))
-        else:
-            raise ValueError(
-                "Probability estimates only available for "
-                "loss='logistic'. You may use probability "
-                "calibration methods from scikit-learn instead."
-            )
-
-    def _check_X_y(self, X, y):
-        """base.py:126-142"""
-        is_2d = hasattr(y, "shape") and len(y.shape) > 1 and y.shape[1] >= 2
-        if is_2d or type_of_target(y) != "binary":
-            raise TypeError(
-                "Only binary targets supported. For training "
-                "multiclass or multilabel models, you may use the "
-                "OneVsRest or OneVsAll metaestimators in "
-                "scikit-learn."
-            )
-        X, Y = check_X_y(X, y, dtype=np.double, accept_sparse=True, multi_output=False)
-        self.label_binarizer_ = LabelBinarizer(pos_label=1, neg_label=-1)
-        y = self.label_binarizer_.fit_transform(Y).ravel().astype(np.double)
-        return X, y
+        """P(y = +1 | x) under the logistic loss (``base.py:102-124``)."""
+        if self.loss != "logistic":
+            raise ValueError(_NO_PROBA)
+        return 1 / (1 + np.exp(-self.decision_function(X)))

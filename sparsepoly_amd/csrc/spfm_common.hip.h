@@ -38,6 +38,21 @@ struct RegState {
     double* dcache;  // (kMaxDegree+2) OmegaCS _dcache (persists between calls)
 };
 
+// Diagnostic: how often the device chains took one of the reference's "numerical error"
+// branches (a handful of atomic adds on paths that are rare by construction).  Read and reset
+// through spfm_debug_branch_counts; used by the tests that force those branches.
+enum {
+    BR_OMEGATI_CLIP = 0,     // omegati.py:97-98   _dcache[t] clipped at 0
+    BR_OMEGACS_DCACHE = 1,   // omegacs.py:90-96   negative _dcache: recompute with degree-1
+    BR_OMEGACS_CACHE = 2,    // omegacs.py:75-76   negative _cache after the update: recompute
+    BR_SQL21_RESUM = 3,      // squaredl21.py:48-49 _cache < _norms[j]: re-sum the norms
+    BR_COUNT = 8
+};
+__device__ unsigned g_branch_count[BR_COUNT];
+__device__ __forceinline__ void count_branch(int which, int lane) {
+    if (lane == 0) atomicAdd(&g_branch_count[which], 1u);
+}
+
 // ------------------------------------------------------------------ helpers
 
 // loss.py:23-24, :44-51, :67-71

@@ -2458,6 +2458,21 @@ int spfm_debug_exchange_cost(spfm_handle h, int groups, int ncols, int readers_m
     return SPFM_OK;
 }
 
+int spfm_debug_branch_counts(spfm_handle h, unsigned* out8, int reset) {
+    GUARD(h);
+    if (!out8) return SPFM_ERR_INVALID;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return SPFM_ERR_RUNTIME;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_branch_count), sizeof(unsigned) * BR_COUNT) !=
+        hipSuccess)
+        return SPFM_ERR_RUNTIME;
+    if (reset) {
+        const unsigned zero[BR_COUNT] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_branch_count), zero, sizeof zero) != hipSuccess)
+            return SPFM_ERR_RUNTIME;
+    }
+    return SPFM_OK;
+}
+
 int spfm_set_use_graph(spfm_handle h, int on) {
     if (!h) return SPFM_ERR_INVALID;
     h->use_graph = on != 0;

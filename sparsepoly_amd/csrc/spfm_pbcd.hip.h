@@ -322,12 +322,16 @@ __device__ __forceinline__ void pbcd_chain_store(int lane, RegState rs, int top_
 // cache[1] (omegacs), c2acc = cache[2], dc2last = dcache[2] (omegacs).  Returns false --
 // nothing written -- if any column would take one of the reference's "numerical error"
 // branches: the caller then runs pbcd_chain_serial_chunk, which restates them.
-template <bool COH>
+// PRIV = true (persistent pass, where EVERY workgroup runs the chain redundantly): the new block
+// norms are returned in l2n_out instead of being stored -- the caller stores them one step
+// later, when no workgroup can still be reading this step's old norms (see
+// pbcd_chain_serial_chunk).
+template <bool COH, bool PRIV = false>
 __device__ __forceinline__ bool pbcd_chain_fast2_chunk(int lane, int cnt, bool valid, int q, int j,
                                                        double l2, double st0, double njl, int reg,
                                                        RegState rs, double* __restrict__ scal,
                                                        double& csum, double& c2acc,
-                                                       double& dc2last) {
+                                                       double& dc2last, double* l2n_out = nullptr) {
     const double c0 = csum;
     const double tt = (reg == REG_SQL21) ? (2 * st0 / (1.0 + 2 * st0)) : st0;
     bool nz = valid && (l2 - tt * (c0 - njl)) > 0;
@@ -360,8 +364,9 @@ __device__ __forceinline__ bool pbcd_chain_fast2_chunk(int lane, int cnt, bool v
         const double f = (valid && nz) ? (1.0 - (tt * dc2) / l2) : 0.0;
         if (valid) {
             scal[4 * q + 2] = f;
-            rs.norms[j] = l2n;  // = l2 - strength, the value the scan propagated
+            if constexpr (!PRIV) rs.norms[j] = l2n;  // = l2 - strength, the value the scan propagated
         }
+        if constexpr (PRIV) *l2n_out = l2n;
         const double c_end = readlane_d(c_after, cnt - 1);
         csum = c_end;
         if (reg != REG_SQL21) {
@@ -379,12 +384,28 @@ __device__ __forceinline__ bool pbcd_chain_fast2_chunk(int lane, int cnt, bool v
 // (multiplicative) or the degree-M cache recurrences with the reference's "numerical error"
 // branches (squaredl21.py:48-49, omegacs.py:75-76,90-96), which recompute from all d norms with
 // the whole wave.
-template <int M, bool COH>
+// PRIV = true: nothing is stored to rs.norms here (every workgroup of the persistent pass runs
+// this redundantly, and a slower workgroup's fallback must still find this step's OLD norms in
+// memory); the fallback sums read memory and substitute the values of the step's columns
+// already processed from registers; the new norms are returned in l2n_out.
+template <int M, bool COH, bool PRIV = false>
 __device__ __forceinline__ void pbcd_chain_serial_chunk(int lane, int cnt, bool valid, int q, int j,
                                                         double l2, double st0, double njl, int d,
                                                         int reg, RegState rs, int top_ncache,
                                                         double* __restrict__ scal, double* cache,
-                                                        double* dcache) {
+                                                        double* dcache, double* l2n_out = nullptr) {
+    // block norm of column jj as the sequential sweep sees it at position i of this chunk
+    auto norm_at = [&](int jj, int i, double l2n_mine_) __attribute__((always_inline)) -> double {
+        double v = rs.norms[jj];
+        if constexpr (PRIV) {
+            for (int ii = 0; ii < i; ++ii) {
+                const int jx = __builtin_amdgcn_readlane(j, ii);
+                const double vx = readlane_d(l2n_mine_, ii);
+                v = (jj == jx) ? vx : v;
+            }
+        }
+        return v;
+    };
     if constexpr (M == 0) {
         // all-subsets OmegaCS (omegacs.py:99-106, 77-81): c /= 1 + n_j; strength = st0 c;
         // shrink; c *= 1 + new norm.  Multiplicative: serial loop over the chunk.
@@ -406,8 +427,9 @@ __device__ __forceinline__ void pbcd_chain_serial_chunk(int lane, int cnt, bool 
         cache[0] = c;
         if (valid) {
             scal[4 * q + 2] = f_m;
-            rs.norms[j] = l2n_m;
+            if constexpr (!PRIV) rs.norms[j] = l2n_m;
         }
+        if constexpr (PRIV) *l2n_out = l2n_m;
         return;
     }
     double f_mine = 0.0, l2n_mine = 0.0;
@@ -415,7 +437,9 @@ __device__ __forceinline__ void pbcd_chain_serial_chunk(int lane, int cnt, bool 
 // columns of this chunk that were already processed (they live in registers)
 #define PBCD_FLUSH_NORMS                                            \
 {                                                               \
-    if (valid && lane < i) rs.norms[j] = l2n_mine;              \
+    if constexpr (!PRIV) {                                          \
+        if (valid && lane < i) rs.norms[j] = l2n_mine;              \
+    }                                                               \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      \
 }
@@ -426,9 +450,10 @@ __device__ __forceinline__ void pbcd_chain_serial_chunk(int lane, int cnt, bool 
         double strength;
         if (reg == REG_SQL21) {
             if (cache[0] < nj) {  // squaredl21.py:48-49
+                count_branch(BR_SQL21_RESUM, lane);
                 PBCD_FLUSH_NORMS
                 double a = 0.0;
-                for (int jj = lane; jj < d; jj += kWave) a += rs.norms[jj];
+                for (int jj = lane; jj < d; jj += kWave) a += norm_at(jj, i, l2n_mine);
                 cache[0] = wave_sum(a);
             }
             const double dc = cache[0] - nj;
@@ -444,12 +469,13 @@ __device__ __forceinline__ void pbcd_chain_serial_chunk(int lane, int cnt, bool 
             for (int t = 1; t < kMaxDegree + 2; ++t)
                 if (t < top_ncache && dcache[t] < mn) mn = dcache[t];
             if (mn < 0) {  // omegacs.py:90-96
+                count_branch(BR_OMEGACS_DCACHE, lane);
                 PBCD_FLUSH_NORMS
                 double cc[kMaxDegree + 2];
 #pragma unroll
                 for (int t = 0; t < kMaxDegree + 2; ++t) cc[t] = (t == 0) ? 1.0 : 0.0;
                 for (int jj = lane; jj < d; jj += kWave) {
-                    const double v = (jj == ji) ? 0.0 : rs.norms[jj];
+                    const double v = (jj == ji) ? 0.0 : norm_at(jj, i, l2n_mine);
 #pragma unroll
                     for (int t = M - 1; t >= 1; --t) cc[t] += cc[t - 1] * v;
                 }
@@ -493,12 +519,13 @@ __device__ __forceinline__ void pbcd_chain_serial_chunk(int lane, int cnt, bool 
             for (int t = 1; t < kMaxDegree + 2; ++t)
                 if (t < top_ncache && cache[t] < mn) mn = cache[t];
             if (mn < 0) {  // __recompute_cache_bcd(degree)
+                count_branch(BR_OMEGACS_CACHE, lane);
                 PBCD_FLUSH_NORMS
                 double cc[kMaxDegree + 2];
 #pragma unroll
                 for (int t = 0; t < kMaxDegree + 2; ++t) cc[t] = (t == 0) ? 1.0 : 0.0;
                 for (int jj = lane; jj < d; jj += kWave) {
-                    double v = rs.norms[jj];
+                    double v = norm_at(jj, i, l2n_mine);
                     if (jj == ji) v = l2n;
 #pragma unroll
                     for (int t = M; t >= 1; --t) cc[t] += cc[t - 1] * v;
@@ -528,8 +555,9 @@ __device__ __forceinline__ void pbcd_chain_serial_chunk(int lane, int cnt, bool 
     }
     if (valid) {
         scal[4 * q + 2] = f_mine;
-        rs.norms[j] = l2n_mine;
+        if constexpr (!PRIV) rs.norms[j] = l2n_mine;
     }
+    if constexpr (PRIV) *l2n_out = l2n_mine;
     // the next chunk (and its fallback paths) read rs.norms of this chunk's columns
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -194,15 +194,16 @@ template <int M>
 __device__ PBPRB_SLOW_ATTR void pbprb_chain_slow(int lane, int ncols, int j, double njl,
                                                            double l2, double st0, int d, int reg,
                                                            RegState rs, int top_ncache,
-                                                           double* scal, double* state) {
+                                                           double* scal, double* state,
+                                                           double* l2n_out) {
     double cache[kMaxDegree + 2], dcache[kMaxDegree + 2];
 #pragma unroll
     for (int t = 0; t < kMaxDegree + 2; ++t) {
         cache[t] = state[t];
         dcache[t] = state[kMaxDegree + 2 + t];
     }
-    pbcd_chain_serial_chunk<M, false>(lane, ncols, lane < ncols, lane, j, l2, st0, njl, d, reg, rs,
-                                      top_ncache, scal, cache, dcache);
+    pbcd_chain_serial_chunk<M, false, true>(lane, ncols, lane < ncols, lane, j, l2, st0, njl, d,
+                                            reg, rs, top_ncache, scal, cache, dcache, l2n_out);
     if (lane == 0) {
 #pragma unroll
         for (int t = 0; t < kMaxDegree + 2; ++t) {
@@ -214,14 +215,14 @@ __device__ PBPRB_SLOW_ATTR void pbprb_chain_slow(int lane, int ncols, int j, dou
 template <int M>
 __device__ __forceinline__ void pbprb_chain_step(int lane, int ncols, int j, double njl, int d,
                                                  int reg, RegState rs, int top_ncache, double* scal,
-                                                 double* state) {
+                                                 double* state, double* l2n_out) {
     const bool valid = lane < ncols;
     const double l2 = valid ? scal[4 * lane + 0] : 0.0, st0 = valid ? scal[4 * lane + 1] : 0.0;
     if constexpr (M == 2) {
         const int ci = (reg == REG_SQL21) ? 0 : 1;
         double csum = state[ci], c2acc = state[2], dc2last = state[kMaxDegree + 2 + 2];
-        if (pbcd_chain_fast2_chunk<false>(lane, ncols, valid, lane, j, l2, st0, njl, reg, rs, scal,
-                                          csum, c2acc, dc2last)) {
+        if (pbcd_chain_fast2_chunk<false, true>(lane, ncols, valid, lane, j, l2, st0, njl, reg, rs,
+                                                scal, csum, c2acc, dc2last, l2n_out)) {
             if (lane == 0) {
                 state[ci] = csum;
                 state[2] = c2acc;
@@ -230,7 +231,7 @@ __device__ __forceinline__ void pbprb_chain_step(int lane, int ncols, int j, dou
             return;
         }
     }
-    pbprb_chain_slow<M>(lane, ncols, j, njl, l2, st0, d, reg, rs, top_ncache, scal, state);
+    pbprb_chain_slow<M>(lane, ncols, j, njl, l2, st0, d, reg, rs, top_ncache, scal, state, l2n_out);
 }
 
 template <typename T>
@@ -406,6 +407,8 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     int cj0 = (wave == 0) ? col_id(c0, c1 - c0, wlane) : -1;  // chain: lane = slot
     int cj1 = (wave == 0) ? col_id(c1, c2 - c1, wlane) : -1;
     double cn0 = (cj0 >= 0 && chained) ? rs.norms[cj0] : 0.0, cn1 = 0.0;
+    int cjp = -1;           // chain: column of the previous step held by this lane ...
+    double l2n_prev = 0.0;  // ... and its new block norm, stored one step late
     __syncthreads();
 
     for (int b = 0; b < a.nb; ++b) {
@@ -671,11 +674,19 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
 
         // ---- phase 4: shrink factors.  L1: none; L21: from (l2, st0); SquaredL21 / OmegaCS:
         // the scalar cache recurrence in step order (every workgroup redundantly; every
-        // workgroup also writes the new block norms, so its own later reads are consistent)
+        // workgroup also writes the new block norms -- one step late -- so that its own later
+        // reads are consistent)
         if (wave == 0) {
             if (chained) {
+                // the previous step's new block norms go to memory now: every workgroup has
+                // finished that step's chain (it published this step's partial sums since), so
+                // none can still need the old values
+                if (cjp >= 0) rs.norms[cjp] = l2n_prev;
+                double l2n_new = 0.0;
                 pbprb_chain_step<M>(wlane, ncols, cj0, cn0, d, reg, rs, top_ncache, sh_scal,
-                                    sh_cache);
+                                    sh_cache, &l2n_new);
+                cjp = cj0;
+                l2n_prev = l2n_new;
             } else if (wlane < ncols) {
                 double f = 1.0;
                 if (reg == REG_L21) {  // l21.py:33-38
@@ -828,6 +839,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         PB_STAMP(8)
     }
 #undef PB_STAMP
+    if (wave == 0 && chained && cjp >= 0) rs.norms[cjp] = l2n_prev;  // the last step's norms
     if (wave == 0 && g == 0 && wlane < 2 * (kMaxDegree + 2)) {
         const int t = wlane % (kMaxDegree + 2);
         double* dstp = (wlane < kMaxDegree + 2) ? rs.cache : rs.dcache;

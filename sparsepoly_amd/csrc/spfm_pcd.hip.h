@@ -437,6 +437,7 @@ __device__ __forceinline__ double pcd_chain_lanes(int reg, int lane, int last, b
                 if (bad == 0ull) break;
             }
             const double r = act ? ((m > 0) ? m : 0.0) : 0.0;
+            if (__ballot(act && !pos) != 0ull) count_branch(BR_OMEGATI_CLIP, lane);
             cache[1] = readlane_d(al, last) * c0 + readlane_d(be, last);
             return sg * r;
         }
@@ -449,6 +450,7 @@ __device__ __forceinline__ double pcd_chain_lanes(int reg, int lane, int last, b
             for (int deg = 2; deg <= M; ++deg) {
                 double v = cache[deg - 1];
                 v -= dc[deg - 1] * ai;
+                if (v < 0) count_branch(BR_OMEGATI_CLIP, lane);
                 dc[deg] = (v < 0) ? 0.0 : v;
             }
             const double m = pi - si * dc[M];

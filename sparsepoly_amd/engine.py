@@ -300,6 +300,16 @@ class HipEngine(object):
             self._check(nv)
         return buf[:nv].reshape(-1, 16)
 
+    def debug_branch_counts(self, reset=True):
+        """How often the device chains took the reference's "numerical error" branches since
+        the last reset: dict with keys omegati_clip (omegati.py:97-98), omegacs_dcache
+        (omegacs.py:90-96), omegacs_cache (omegacs.py:75-76), squaredl21_resum
+        (squaredl21.py:48-49)."""
+        buf = (C.c_uint32 * 8)()
+        self._check(self._lib.spfm_debug_branch_counts(self._h, buf, int(bool(reset))))
+        return dict(omegati_clip=buf[0], omegacs_dcache=buf[1], omegacs_cache=buf[2],
+                    squaredl21_resum=buf[3])
+
     def get_option(self, key):
         v = C.c_int()
         self._check(self._lib.spfm_get_option(self._h, key.encode(), C.byref(v)))

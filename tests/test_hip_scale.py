@@ -132,6 +132,53 @@ def test_fullsize_incremental_state_equals_recompute(config2_matrix, solver, reg
     np.testing.assert_allclose(out["f32"][1], out["f64"][1], rtol=2e-5)
 
 
+@pytest.mark.parametrize("solver,reg", [("pcd", "squaredl12"), ("pbcd", "omegacs")])
+def test_fullsize_vs_oracle(oracle, config2_matrix, solver, reg):
+    """Full BASELINE config-2 size against the CPU oracle in the reported (coloured) order:
+    one cd_linear epoch, then 3 pcd component passes (k = 30; ~1.1 s each on the CPU) or the
+    whole pbcd epoch, f32 storage.  Stated tolerance (north_star): violation sums 1e-5
+    relative, |P - P_ref| <= 1e-4, y_pred 2e-4 of its scale."""
+    Xc, y = config2_matrix
+    n, d = Xc.shape
+    k = 30
+    beta, gamma = (10.0, 1e-4) if solver == "pcd" else (1.0, 1e-3)
+    eng, order, P0 = _engine(Xc, y, k, 2, solver, reg, "f32", "colored")
+    y0 = eng.get_y_pred()
+    ic = np.arange(3, dtype=np.int32)
+    v_lin = eng.cd_linear_epoch(1.0)
+    v = (eng.pcd_epoch(0, 2, beta, gamma, 1.0, ic) if solver == "pcd"
+         else eng.pbcd_epoch(0, 2, beta, gamma, 1.0))
+    P, w = eng.get_params()
+    yp = eng.get_y_pred()
+    eng.close()
+    ds = oracle.CSC(Xc)
+    regc = oracle.Regularizer(reg)
+    wo = np.zeros(d)
+    ypo = np.ascontiguousarray(y0.copy())
+    cn = np.asarray(Xc.multiply(Xc).sum(axis=0)).ravel()
+    jf = np.ascontiguousarray(order)
+    vo_lin = oracle.cd_linear_epoch(wo, ds, y, ypo, cn, 1.0, "squared", jf)
+    lams = np.ones(k)
+    if solver == "pcd":
+        regc.init_cache_pcd(2, d, k)
+        Po = np.ascontiguousarray(P0[0].copy())
+        A = np.zeros((n, 3))
+        vo = oracle.pcd_epoch(Po, ds, y, ypo, lams, 2, beta, gamma, 1.0, regc, "squared", A, ic, jf)
+    else:
+        regc.init_cache_pbcd(2, d, k)
+        Pt = np.ascontiguousarray(P0[0].T.copy())
+        A = np.zeros((n, 3, k))
+        dA = np.zeros((n, 2, k))
+        vo = oracle.pbcd_epoch(Pt, ds, y, ypo, lams, 2, beta, gamma, 1.0, regc, "squared", A, dA,
+                               jf)
+        Po = np.ascontiguousarray(Pt.T)
+    np.testing.assert_allclose(v_lin, vo_lin, rtol=1e-5)
+    np.testing.assert_allclose(v, vo, rtol=1e-5)
+    np.testing.assert_allclose(w, wo, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(P[0], Po, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(yp, ypo, rtol=0, atol=2e-4 * max(1.0, np.abs(ypo).max()))
+
+
 def test_estimator_augment_and_warm_start(oracle):
     """fit_lower='augment' (dummy columns, sparse_factorization_machines.py:86-92) and
     warm_start=True (P_, w_, lams_ reused, y_pred recomputed: :380-391,408)."""

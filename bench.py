@@ -134,6 +134,7 @@ def main():
         if world > 1:
             lo, hi = spdist.row_block(n, rank, world)
             spdist.init_engine_comm(eng)
+            spdist.connect_peers(eng)  # persistent passes with the in-kernel xGMI exchange
             eng.set_data(canonical_csc(X[lo:hi]), y[lo:hi])
             conflict = Xc
         else:
@@ -338,9 +339,11 @@ def main():
                                                   cfg["solver"], n, d, nnz),
                        "schedule": args.schedule, "dependent_steps_per_sweep": n_batches,
                        "alpha": cfg["alpha"], "beta": cfg["beta"], "gamma": cfg["gamma"],
-                       "parallelism": ("rows sharded x%d, per-step %s exchange"
-                                       % (world, "host-shm (rehearsal)"
-                                          if os.environ.get("SPFM_COMM") == "shm" else "RCCL"))
+                       "parallelism": ("rows sharded x%d, per-step exchange: %s"
+                                       % (world, "in-kernel peer-mapped slabs"
+                                          if os.environ.get("SPFM_PEER", "1") != "0" else
+                                          ("host-shm (rehearsal)"
+                                           if os.environ.get("SPFM_COMM") == "shm" else "RCCL")))
                        if world > 1 else "single GPU"},
             "roofline": roof,
             "cpu_baseline": cpu,

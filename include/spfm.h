@@ -198,6 +198,18 @@ int spfm_comm_init(spfm_handle h, const char* id128, int n_ranks, int rank);
  * bring-up facility, orders of magnitude slower than RCCL over xGMI. */
 int spfm_comm_init_shm(spfm_handle h, const char* shm_name, int n_ranks, int rank);
 
+/* In-kernel cross-GPU exchange for the persistent passes (replaces the per-step collective;
+ * SURVEY.md section 5 "one-hop direct-write exchange").  Every rank allocates one exchange
+ * slab (spfm_peer_alloc returns its 64-byte hipIpc handle), the caller ships the handles to all
+ * ranks (any channel: torch.distributed, MPI, a file) and every rank maps its peers' slabs
+ * (spfm_peer_connect; handles = n_ranks x 64 bytes in rank order, n_ranks <= 8).  Requires a
+ * communicator with the same ranks (spfm_comm_init / _shm): it carries the one-off set-up
+ * reductions and the barrier between launches.  After connecting, set the schedule (again):
+ * the persistent passes cap a step at 64 columns.  Works across the GPUs of one node (xGMI)
+ * and -- for tests -- between processes that share one GPU. */
+int spfm_peer_alloc(spfm_handle h, char* handle64);
+int spfm_peer_connect(spfm_handle h, int n_ranks, int rank, const char* handles);
+
 /* -- instrumentation ----------------------------------------------------------
  * Device time (ms, HIP events on the handle's stream) and launch count of the
  * dominant kernel family since the last reset: which = 0 pcd gather (persistent

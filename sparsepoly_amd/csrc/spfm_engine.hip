@@ -209,7 +209,7 @@ struct spfm_engine {
     // persistent pbcd pass (spfm_pbprb.hip.h): its own workgroup count, hence its own entry
     // stream when that differs from the pcd / cd_linear pass's
     bool pb_persistent = true;
-    int pbprb_G = 128;
+    int pbprb_G = 256;
     bool pb_stream_ready = false;
     int pb_stream_G = 0, pb_stream_NG = 0;
     DevBuf pb_sp, pb_erow, pb_eval, pb_meta, pb_slabA, pb_slabB, pb_slabC, pb_stamps;
@@ -239,6 +239,17 @@ struct spfm_engine {
     std::vector<double> shm_host;
     bool dist() const { return comm != nullptr || shm.hdr != nullptr; }
     int n_ranks = 1, rank = 0;
+    // In-kernel cross-GPU exchange of the persistent passes (spfm_peer_alloc / _connect): one
+    // exchange slab per GPU, mapped into every rank (hipIpc); the kernels write their GPU's
+    // per-step totals into every GPU's slab and poll their own -- no per-step collective.
+    // Layout (doubles): [0, 16K) pcd / cd_linear [2][n_ranks][64][2]; [16K, ...) pbcd
+    // [2][64][n_ranks][64].
+    static constexpr size_t kPeerPcdOff = 0, kPeerPbOff = 16 * 1024;
+    static constexpr size_t kPeerDoubles = kPeerPbOff + (size_t)2 * 64 * 8 * 64;
+    void* peer_own = nullptr;
+    std::vector<void*> peer_ptr;     // [n_ranks] mapped bases ([rank] = own)
+    DevBuf peer_tab_pcd, peer_tab_pb;  // device tables of the per-kernel region pointers
+    bool peer_ready = false;
 
     // profile
     bool prof_on = false;
@@ -249,6 +260,9 @@ struct spfm_engine {
         for (auto& ps : prof)
             for (auto e : ps.ev) (void)hipEventDestroy(e);
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+        for (size_t r = 0; r < peer_ptr.size(); ++r)
+            if (peer_ptr[r] && peer_ptr[r] != peer_own) (void)hipIpcCloseMemHandle(peer_ptr[r]);
+        if (peer_own) (void)hipFree(peer_own);
         if (shm.hdr) munmap((void*)shm.hdr, shm.bytes);
         if (h_scalar) (void)hipHostFree(h_scalar);
         if (stream) (void)hipStreamDestroy(stream);
@@ -674,7 +688,8 @@ struct spfm_engine {
         const int64_t rows = cf_indptr ? cf_rows : n;
         if (cf_indptr && (!cf_indices || cf_rows <= 0))
             FAIL(SPFM_ERR_INVALID, "set_schedule: bad conflict structure");
-        const int max_batch = (persistent && !dist()) ? std::min(max_batch_opt, 64) : max_batch_opt;
+        const int max_batch =
+            (persistent && (!dist() || peer_ready)) ? std::min(max_batch_opt, 64) : max_batch_opt;
         if (mode == SPFM_SCHED_EXACT) {
             order.assign(indices_feature, indices_feature + d);
             schedule_exact(rows, d, cp, ci, indices_feature, max_batch, batch_ptr);
@@ -981,6 +996,10 @@ struct spfm_engine {
         hipLaunchKernelGGL(gather_sched_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
                            d_desc.as<ColDesc>(), w.as<double>(), prow_old.as<double>());
         HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));
+        {
+            int prc = peer_clear(kPeerPcdOff, kPeerPbOff);
+            if (prc) return prc;
+        }
         prof_begin(4, nnz);
         bool launched = false;
         if constexpr (can_lr) {
@@ -1087,8 +1106,10 @@ struct spfm_engine {
     }
 
     // ---------------------------------------------------- persistent row-block pass
+    // (several ranks: the persistent passes need the peer-mapped exchange slabs)
     bool prb_usable() const {
-        return persistent && !dist() && max_batch_cols <= 64 && nnz < ((int64_t)1 << 31) && n > 0;
+        return persistent && (!dist() || peer_ready) && max_batch_cols <= 64 &&
+               nnz < ((int64_t)1 << 31) && n > 0;
     }
 
     template <typename T>
@@ -1154,6 +1175,9 @@ struct spfm_engine {
         a.n_rows = (int)n;
         a.abort_flag = prb_abort.as<unsigned>();
         a.stamps = prb_stamp_on ? prb_stamps.as<long long>() : nullptr;
+        a.n_ranks = peer_ready ? n_ranks : 1;
+        a.rank = rank;
+        a.xslab = peer_ready ? peer_tab_pcd.as<double*>() : nullptr;
         return a;
     }
 
@@ -1195,6 +1219,10 @@ struct spfm_engine {
         hipLaunchKernelGGL(snapshot_row_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, c, Po, d,
                            d_desc.as<ColDesc>(), prow_old.as<double>());
         HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));  // tag 0 = "not yet"
+        {
+            int prc = peer_clear(kPeerPcdOff, kPeerPbOff);
+            if (prc) return prc;
+        }
         prof_begin(0, nnz);
         // one instantiation per (rows in LDS?, timers?, regularizer): the fast configuration
         // (float, one cache value per row) gets the regularizer as a compile-time constant
@@ -1271,6 +1299,28 @@ struct spfm_engine {
             case 6: return pcd_prb_loss<T, 6>(order_idx, beta, gamma, eta);
         }
         FAIL(SPFM_ERR_UNSUPPORTED, "degree outside 2..6");
+    }
+
+    // tag 0 = "not yet" in the own exchange slab; all ranks must have passed the previous launch
+    // before anybody clears (the caller's epochs are collective: one clear per launch, and a
+    // rank only starts writing to a peer after that peer's clear because the first remote store
+    // of a launch follows a local sweep that needs ... nothing remote).  To be safe the clear is
+    // followed by a barrier over the host communicator.
+    int peer_clear(size_t off_doubles, size_t n_doubles) {
+        if (!peer_ready) return SPFM_OK;
+        HIPC(hipMemsetAsync(reinterpret_cast<double*>(peer_own) + off_doubles, 0,
+                            sizeof(double) * n_doubles, stream));
+        HIPC(hipStreamSynchronize(stream));
+        return host_barrier();
+    }
+    int host_barrier() {
+        if (shm.hdr) return shm_barrier();
+        if (comm) {  // a 1-element all-reduce doubles as the barrier
+            int rc = allreduce(scalar.as<double>() + 4, 1);
+            if (rc) return rc;
+            HIPC(hipStreamSynchronize(stream));
+        }
+        return SPFM_OK;
     }
 
     int prb_check_abort() {
@@ -1454,7 +1504,7 @@ struct spfm_engine {
     // ------------------------------------------------ persistent pbcd pass (one launch)
     static bool pbprb_degree_ok(int M) { return M == 0 || M == 2 || M == 3 || M == 4; }
     bool pbprb_usable(int M) const {
-        return persistent && pb_persistent && !dist() && max_batch_cols <= 64 &&
+        return persistent && pb_persistent && (!dist() || peer_ready) && max_batch_cols <= 64 &&
                nnz < ((int64_t)1 << 31) && n > 0 && k <= 62 && pbprb_degree_ok(M);
     }
 
@@ -1521,6 +1571,10 @@ struct spfm_engine {
         HIPC(pb_slabB.alloc(sizeof(double) * 2 * 64 * L));
         HIPC(hipMemsetAsync(pb_slabA.p, 0, sizeof(double) * 2 * 64 * (size_t)G * L, stream));
         HIPC(hipMemsetAsync(pb_slabB.p, 0, sizeof(double) * 2 * 64 * L, stream));
+        {
+            int prc = peer_clear(kPeerPbOff, kPeerDoubles - kPeerPbOff);
+            if (prc) return prc;
+        }
         PbPrbArgs a;
         a.G = G;
         a.nb = n_batches();
@@ -1534,9 +1588,11 @@ struct spfm_engine {
         a.rows_per = (int)std::max<int64_t>((n + G - 1) / G, 1);
         a.n_rows = (int)n;
         a.abort_flag = prb_abort.as<unsigned>();
-        a.n_ranks = 1;
-        a.rank = 0;
-        a.slabC = nullptr;
+        a.n_ranks = peer_ready ? n_ranks : 1;
+        a.rank = rank;
+        a.slabC = peer_ready ? peer_tab_pb.as<double*>() : nullptr;
+        if (peer_ready && L * n_ranks > 64 * 8)
+            FAIL(SPFM_ERR_UNSUPPORTED, "persistent pbcd pass: more than 8 ranks");
         a.stamps = pb_stamp_on ? pb_stamps.as<long long>() : nullptr;
         a.dbg = pb_dbg;
         HIPC(pb_dbgbuf.alloc(sizeof(unsigned) * (16 + 4096)));
@@ -2222,6 +2278,90 @@ int spfm_comm_init_shm(spfm_handle h, const char* shm_name, int n_ranks, int ran
     h->n_ranks = n_ranks;
     h->rank = rank;
     h->col_norm_reduced = false;
+    h->clear_graphs();
+    return SPFM_OK;
+}
+
+int spfm_peer_alloc(spfm_handle h, char* handle64) {
+    GUARD(h);
+    if (!handle64) return SPFM_ERR_INVALID;
+    if (!h->peer_own) {
+        void* p = nullptr;
+        // fine-grained device memory: remote stores become visible to local polling loads
+        // without a kernel boundary; plain hipMalloc is the fall-back
+        if (hipExtMallocWithFlags(&p, sizeof(double) * spfm_engine::kPeerDoubles,
+                                  hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipMalloc(&p, sizeof(double) * spfm_engine::kPeerDoubles) != hipSuccess) {
+                h->err = "peer slab allocation failed";
+                return SPFM_ERR_RUNTIME;
+            }
+        }
+        if (hipMemset(p, 0, sizeof(double) * spfm_engine::kPeerDoubles) != hipSuccess) {
+            (void)hipFree(p);
+            h->err = "peer slab memset failed";
+            return SPFM_ERR_RUNTIME;
+        }
+        h->peer_own = p;
+    }
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    hipIpcMemHandle_t ih;
+    hipError_t e = hipIpcGetMemHandle(&ih, h->peer_own);
+    if (e != hipSuccess) {
+        h->err = std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e);
+        return SPFM_ERR_RUNTIME;
+    }
+    std::memcpy(handle64, &ih, 64);
+    return SPFM_OK;
+}
+
+int spfm_peer_connect(spfm_handle h, int n_ranks, int rank, const char* handles) {
+    GUARD(h);
+    if (!handles || n_ranks < 2 || n_ranks > 8 || rank < 0 || rank >= n_ranks)
+        return SPFM_ERR_INVALID;
+    if (!h->peer_own) {
+        h->err = "spfm_peer_connect: call spfm_peer_alloc first";
+        return SPFM_ERR_INVALID;
+    }
+    if (!h->dist() || h->n_ranks != n_ranks || h->rank != rank) {
+        h->err = "spfm_peer_connect: attach the communicator (spfm_comm_init[_shm]) with the "
+                 "same ranks first";
+        return SPFM_ERR_INVALID;
+    }
+    h->peer_ptr.assign((size_t)n_ranks, nullptr);
+    for (int r = 0; r < n_ranks; ++r) {
+        if (r == rank) {
+            h->peer_ptr[(size_t)r] = h->peer_own;
+            continue;
+        }
+        hipIpcMemHandle_t ih;
+        std::memcpy(&ih, handles + (size_t)r * 64, 64);
+        void* p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            h->err = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e);
+            return SPFM_ERR_RUNTIME;
+        }
+        h->peer_ptr[(size_t)r] = p;
+    }
+    std::vector<double*> t1((size_t)n_ranks), t2((size_t)n_ranks);
+    for (int r = 0; r < n_ranks; ++r) {
+        t1[(size_t)r] = reinterpret_cast<double*>(h->peer_ptr[(size_t)r]) + spfm_engine::kPeerPcdOff;
+        t2[(size_t)r] = reinterpret_cast<double*>(h->peer_ptr[(size_t)r]) + spfm_engine::kPeerPbOff;
+    }
+    if (h->peer_tab_pcd.alloc(sizeof(double*) * 8) != hipSuccess ||
+        h->peer_tab_pb.alloc(sizeof(double*) * 8) != hipSuccess ||
+        hipMemcpy(h->peer_tab_pcd.p, t1.data(), sizeof(double*) * (size_t)n_ranks,
+                  hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->peer_tab_pb.p, t2.data(), sizeof(double*) * (size_t)n_ranks,
+                  hipMemcpyHostToDevice) != hipSuccess) {
+        h->err = "peer table upload failed";
+        return SPFM_ERR_RUNTIME;
+    }
+    h->peer_ready = true;
+    h->have_schedule = false;  // the step cap depends on the engine: set the schedule again
+    h->prb_ready = false;
+    h->pb_stream_ready = false;
     h->clear_graphs();
     return SPFM_OK;
 }

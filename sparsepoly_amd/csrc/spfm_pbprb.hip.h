@@ -551,7 +551,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 if (a.n_ranks > 1) {
                     const size_t off = ((size_t)par * 64 + q) * a.n_ranks * L;
                     for (int rr = 0; rr < a.n_ranks; ++rr)
-                        prb_store_granule(a.slabC[rr] + off + (size_t)a.rank * L + lane, 0.0, tag);
+                        prb_store_granule_sys(a.slabC[rr] + off + (size_t)a.rank * L + lane, 0.0, tag);
                 }
             }
             if (own && grp == 0) {
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                     // the n_ranks vectors of the own slabC summed in rank order
                     const size_t off = ((size_t)par * 64 + q) * a.n_ranks * L;
                     for (int rr = 0; rr < a.n_ranks; ++rr)
-                        prb_store_granule(a.slabC[rr] + off + (size_t)a.rank * L + lane, tot, tag);
+                        prb_store_granule_sys(a.slabC[rr] + off + (size_t)a.rank * L + lane, tot, tag);
                     double gt = 0.0;
                     bool ok = true;
                     const double* mine = a.slabC[a.rank];
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                         unsigned long long t;
                         unsigned spins = 0;
                         for (;;) {
-                            t = prb_load_granule(mine + off + (size_t)rr * L + lane);
+                            t = prb_load_granule_sys(mine + off + (size_t)rr * L + lane);
                             if ((t & 3ull) == tag) break;
                             if (pbprb_poll_fail(a, spins)) {
                                 ok = false;

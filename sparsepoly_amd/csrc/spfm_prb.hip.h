@@ -45,7 +45,14 @@ struct PrbArgs {
     unsigned* abort_flag;  // [1]
     long long* stamps;     // diagnostic: [G][16] accumulated cycles per phase (8 control-wave,
                            // 8 worker-wave values), or nullptr
+    // multi-GPU (n_ranks > 1): after the local sweep every workgroup holds this GPU's per-slot
+    // totals; workgroup 0 writes them into EVERY GPU's exchange slab (peer-mapped stores over
+    // xGMI, system scope), every workgroup then adds the n_ranks vectors found in its own GPU's
+    // slab in rank order -- one more hop, no collective, bit-identical totals on every GPU
+    int n_ranks, rank;
+    double* const* xslab;  // [n_ranks] peer pointers; xslab[r] = GPU r's [2][n_ranks][64][2]
 };
+
 
 __device__ __forceinline__ void st_agent(double* p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p),
@@ -79,6 +86,64 @@ __device__ __forceinline__ void prb_store_granule(double* p, double v, unsigned 
 __device__ __forceinline__ unsigned long long prb_load_granule(const double* p) {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// system-scope forms of the tagged granule (cross-GPU exchange)
+__device__ __forceinline__ void prb_store_granule_sys(double* p, double v, unsigned long long tag) {
+    const unsigned long long u =
+        ((unsigned long long)__double_as_longlong(v) & ~3ull) | tag;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), u, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long prb_load_granule_sys(const double* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Cross-GPU stage of the exchange, run by a control wave (lane = slot): tot[0..NV) are this
+// GPU's totals (identical in every workgroup); on return they are the sums over all GPUs.
+template <int NV>
+__device__ __forceinline__ bool prb_cross_gpu(const PrbArgs& a, int g, int b, int lane,
+                                              double* tot) {
+    const unsigned long long tag = prb_tag(b);
+    const size_t par_off = (size_t)(b & 1) * a.n_ranks * 64 * 2;
+    if (g == 0) {
+        for (int rr = 0; rr < a.n_ranks; ++rr) {
+            double* dst = a.xslab[rr] + par_off + ((size_t)a.rank * 64 + lane) * 2;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) prb_store_granule_sys(dst + v, tot[v], tag);
+        }
+    }
+    const double* mine = a.xslab[a.rank] + par_off + (size_t)lane * 2;
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    for (int rr = 0; rr < a.n_ranks; ++rr) {
+        unsigned long long t[NV];
+        unsigned spins = 0;
+        for (;;) {
+            bool all = true;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                t[v] = prb_load_granule_sys(mine + (size_t)rr * 64 * 2 + v);
+                all = all && ((t[v] & 3ull) == tag);
+            }
+            if (all) break;
+            if ((++spins & 63u) == 0) {
+                if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                    spins > (1u << 21)) {
+                    __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] += __longlong_as_double((long long)(t[v] & ~3ull));
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) tot[v] = acc[v];
+    return true;
 }
 
 // Sweeping wave `w` (0..nparts-1) sums the granules of workgroups [w*G/nparts,
@@ -548,6 +613,9 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
 #pragma unroll
                 for (int w = 1; w < kPrbParts; ++w) tot[v] += sh_quart[(w * 64 + lane) * 2 + v];
             }
+            if (a.n_ranks > 1) {
+                if (!prb_cross_gpu<2>(a, g, b, lane, tot)) *sh_ok = 0;
+            }
             const bool valid = lane < ncols;
             const double res = pcd_chain_lanes<M>(REGC >= 0 ? REGC : reg, lane, ncols - 1, valid, pl,
                                                   tot[0], tot[1],
@@ -850,6 +918,9 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
             double tot = sh_quart[lane * 2];
 #pragma unroll
             for (int w = 1; w < kPrbParts; ++w) tot += sh_quart[(w * 64 + lane) * 2];
+            if (a.n_ranks > 1) {
+                if (!prb_cross_gpu<1>(a, g, b, lane, &tot)) *sh_ok = 0;
+            }
             const bool valid = lane < ncols;
             double upd = tot;           // cd_linear.py:19-24
             upd += alpha * wl;

@@ -69,3 +69,23 @@ def init_engine_comm(engine):
     uid = broadcast_bytes(uid, src=0)
     engine.comm_init(uid, world, rank)
     return rank, world
+
+
+def connect_peers(engine):
+    """Enable the in-kernel cross-GPU exchange of the persistent passes: all-gather the ranks'
+    exchange-slab IPC handles over the (control) process group and map them.  Call after
+    ``init_engine_comm``; ``SPFM_PEER=0`` keeps the per-step collective instead."""
+    import os
+
+    if os.environ.get("SPFM_PEER", "1") == "0":
+        return False
+    d = _dist()
+    rank, world = rank_world()
+    if world < 2 or world > 8:
+        return False
+    mine = engine.peer_alloc()
+    box = [None] * world
+    d.all_gather_object(box, mine)
+    engine.peer_connect(world, rank, box)
+    d.barrier()
+    return True

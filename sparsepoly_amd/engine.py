@@ -261,6 +261,20 @@ class HipEngine(object):
         """Host shared-memory communicator for ranks sharing one GPU (test / bring-up)."""
         self._check(self._lib.spfm_comm_init_shm(self._h, name.encode(), int(n_ranks), int(rank)))
 
+    def peer_alloc(self):
+        """This rank's exchange slab for the in-kernel cross-GPU exchange: its 64-byte IPC
+        handle (ship it to every rank, then call ``peer_connect``)."""
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.spfm_peer_alloc(self._h, buf))
+        return buf.raw
+
+    def peer_connect(self, n_ranks, rank, handles):
+        """Map the peers' exchange slabs (``handles``: list of n_ranks 64-byte handles in rank
+        order).  The persistent passes then run with several ranks; set the schedule after."""
+        blob = b"".join(handles)
+        assert len(blob) == 64 * n_ranks
+        self._check(self._lib.spfm_peer_connect(self._h, int(n_ranks), int(rank), blob))
+
     # -------------------------------------------------------- instrumentation
     def profile_enable(self, on=True):
         self._check(self._lib.spfm_profile_enable(self._h, int(bool(on))))

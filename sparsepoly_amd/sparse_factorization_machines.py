@@ -398,6 +398,7 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 conflict_csc = Xc
                 Xl = canonical_csc(Xc.tocsr()[lo:hi])
                 _dist.init_engine_comm(engine)
+                _dist.connect_peers(engine)  # in-kernel exchange for the persistent passes
                 engine.set_data(Xl, y[lo:hi])
             else:
                 engine.set_data(Xc, y)

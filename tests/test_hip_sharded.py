@@ -1,7 +1,10 @@
-"""The multi-GPU protocol (contiguous row shards, per-step all-reduce of
-the column partial sums, replicated chain) executed by the real engine: two processes share
-the one GPU of the test box and exchange through the host shared-memory communicator
-(`spfm_comm_init_shm`; RCCL refuses two ranks on one device).  The sharded result must equal
+"""The multi-GPU protocol (contiguous row shards, per-step exchange of the
+column partial sums, replicated chain) executed by the real engine: two processes share the one
+GPU of the test box.  Two exchange paths: the multi-kernel engine with a per-step all-reduce
+through the host shared-memory communicator (`spfm_comm_init_shm`; RCCL refuses two ranks on one
+device), and the persistent passes with the in-kernel exchange through IPC-mapped slabs
+(`spfm_peer_alloc` / `spfm_peer_connect`) -- two persistent kernels co-resident on the GPU,
+each writing its per-step totals into the other's slab.  The sharded result must equal
 the single-process multi-kernel engine and the oracle, and be bit-identical on both ranks.
 Needs a real MI355X: ``pytest -m gpu``."""
 import multiprocessing as mp
@@ -33,8 +36,11 @@ def _problem(loss):
     return sp.csr_matrix(X), y
 
 
-def _run(case, world, rank, shm_name, precision):
-    """One rank of the sharded run (world == 1: the whole problem, no communicator)."""
+def _run(case, world, rank, shm_name, precision, engine="multi_kernel", hq=None):
+    """One rank of the sharded run (world == 1: the whole problem, no communicator).
+    engine = 'multi_kernel': per-step all-reduce through the host communicator;
+    'persistent_peer': the persistent passes with the in-kernel exchange through IPC-mapped
+    slabs (hq = per-rank queues that carry the 64-byte handles between the two processes)."""
     sys.path.insert(0, ROOT)
     from sparsepoly_amd.engine import HipEngine, canonical_csc
 
@@ -44,9 +50,22 @@ def _run(case, world, rank, shm_name, precision):
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world
     Xg = canonical_csc(X)
     eng = HipEngine(0, precision)
-    eng.set_option("persistent", 0)       # the multi-kernel engine in both runs
+    if engine == "multi_kernel":
+        eng.set_option("persistent", 0)   # the multi-kernel engine in both runs
+    else:
+        eng.set_option("pbprb_groups", 64)  # two co-resident persistent kernels: 2 x 64 CUs
     if world > 1:
         eng.comm_init_shm(shm_name, world, rank)
+        if engine == "persistent_peer":
+            mine = eng.peer_alloc()
+            for r in range(world):
+                if r != rank:
+                    hq[r].put((rank, mine))
+            handles = {rank: mine}
+            while len(handles) < world:
+                r, h = hq[rank].get(timeout=120)
+                handles[r] = h
+            eng.peer_connect(world, rank, [handles[r] for r in range(world)])
     eng.set_data(canonical_csc(X[lo:hi]), y[lo:hi])
     P0 = 0.01 * np.random.RandomState(0).randn(degree - 1, k, d)
     eng.set_params(P0, np.zeros(d), np.ones(k))
@@ -65,25 +84,29 @@ def _run(case, world, rank, shm_name, precision):
         losses.append(eng.loss_sum())       # all-reduced over the shards
     P, w = eng.get_params()
     yp = eng.get_y_pred()
+    active = (eng.get_option("persistent_active"), eng.get_option("pbprb_active"))
     eng.close()
     return dict(P=P, w=w, viol=np.array(viol), loss=np.array(losses), y_pred=yp, order=order,
-                rows=(lo, hi))
+                rows=(lo, hi), active=active)
 
 
-def _worker(case, world, rank, shm_name, precision, q):
+def _worker(case, world, rank, shm_name, precision, q, engine, hq):
     try:
-        q.put((rank, _run(case, world, rank, shm_name, precision)))
+        q.put((rank, _run(case, world, rank, shm_name, precision, engine, hq)))
     except Exception as e:  # surface the failure in the parent
         q.put((rank, repr(e)))
 
 
+@pytest.mark.parametrize("engine", ["multi_kernel", "persistent_peer"])
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_two_row_shards_on_one_gpu(oracle, case):
+def test_two_row_shards_on_one_gpu(oracle, case, engine):
     solver, reg, degree, k, loss, beta, gamma = CASES[case]
-    shm_name = "/spfm_test_%d_%s" % (os.getpid(), case)
+    shm_name = "/spfm_test_%d_%s_%s" % (os.getpid(), case, engine)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(case, 2, r, shm_name, "f64", q)) for r in (0, 1)]
+    hq = [ctx.Queue(), ctx.Queue()]
+    procs = [ctx.Process(target=_worker, args=(case, 2, r, shm_name, "f64", q, engine, hq))
+             for r in (0, 1)]
     for p in procs:
         p.start()
     got = {}
@@ -108,7 +131,9 @@ def test_two_row_shards_on_one_gpu(oracle, case):
     assert np.array_equal(a["viol"], b["viol"]) and np.array_equal(a["loss"], b["loss"])
     assert np.array_equal(a["order"], b["order"])
     # equals the unsharded engine (summation order of the partial sums differs: 1e-10)
-    one = _run(case, 1, 0, None, "f64")
+    one = _run(case, 1, 0, None, "f64", engine)
+    if engine == "persistent_peer":  # the persistent passes really ran, with two ranks
+        assert a["active"] == ((1, 0) if solver == "pcd" else (1, 1)), a["active"]
     assert np.array_equal(one["order"], a["order"])
     np.testing.assert_allclose(a["P"], one["P"], rtol=0, atol=1e-10)
     np.testing.assert_allclose(a["w"], one["w"], rtol=0, atol=1e-10)

@@ -358,8 +358,13 @@ struct spfm_engine {
     }
 
     int allreduce_shm(double* buf, size_t count) {
-        if (count > ShmComm::kMaxDoubles)
-            FAIL(SPFM_ERR_UNSUPPORTED, "shm communicator: message too large");
+        for (size_t off = 0; off < count; off += ShmComm::kMaxDoubles) {  // long vectors in pieces
+            int rc = allreduce_shm_piece(buf + off, std::min(ShmComm::kMaxDoubles, count - off));
+            if (rc) return rc;
+        }
+        return SPFM_OK;
+    }
+    int allreduce_shm_piece(double* buf, size_t count) {
         shm_host.resize(count);
         HIPC(hipMemcpyAsync(shm_host.data(), buf, sizeof(double) * count, hipMemcpyDeviceToHost,
                             stream));

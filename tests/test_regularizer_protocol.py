@@ -1,0 +1,130 @@
+"""The host-callable regularizer plug-in objects (sparsepoly_amd.regularizer) against per-call
+traces recorded from the reference (tests/golden/g5_reg_traces.npz: every prox_cd / prox_bcd
+input and output, and the cache state after every update, including the sweeps whose state was
+pushed into the reference's "numerical error" branches).  CPU only."""
+import numpy as np
+import pytest
+from conftest import load_golden
+
+from sparsepoly_amd.regularizer import REGULARIZATION
+
+D, K = 12, 5
+PCD = [("l1", 2), ("squaredl12", 2), ("omegati", 2), ("omegati", 3), ("omegati", 4)]
+PBCD = [("l1", 2, "plain"), ("l21", 2, "plain"), ("squaredl21", 2, "plain"),
+        ("omegacs", 2, "plain"), ("omegacs", 3, "plain"), ("omegacs", 4, "plain"),
+        ("omegacs", 3, "poison"), ("squaredl21", 2, "poison")]
+
+
+@pytest.mark.parametrize("regname,degree", PCD)
+def test_pcd_protocol_replays_reference_trace(regname, degree):
+    z = load_golden("g5_reg_traces.npz")
+    tag = "pcd|%s|deg%d" % (regname, degree)
+    reg = REGULARIZATION[regname]()
+    reg.init_cache_pcd(degree, D, K)
+    P = z["P0|" + tag].copy()
+    t = 0
+    for s in range(K):
+        reg.compute_cache_pcd(P, degree, s)
+        for j in range(D):
+            new = reg.prox_cd(float(z["p_in|" + tag][t]), float(z["strength|" + tag][t]), degree, j)
+            np.testing.assert_allclose(new, z["p_out|" + tag][t], rtol=0, atol=1e-13)
+            P[s, j] = new
+            reg.update_cache_pcd(P, degree, s, j)
+            if regname != "l1":
+                c = np.zeros(degree + 1)
+                c[: len(reg._cache)] = reg._cache
+                np.testing.assert_allclose(c, z["cache|" + tag][t], rtol=1e-12, atol=1e-13)
+                if regname == "omegati":
+                    np.testing.assert_allclose(reg._dcache, z["dcache|" + tag][t], rtol=1e-12,
+                                               atol=1e-13)
+            t += 1
+    np.testing.assert_allclose(P, z["P_end|" + tag], rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("regname,degree,mode", PBCD)
+def test_pbcd_protocol_replays_reference_trace(regname, degree, mode):
+    z = load_golden("g5_reg_traces.npz")
+    tag = "pbcd|%s|deg%d|%s" % (regname, degree, mode)
+    reg = REGULARIZATION[regname]()
+    reg.init_cache_pbcd(degree, D, K)
+    P = z["P0|" + tag].copy()
+    reg.compute_cache_pbcd(P, degree)
+    t = 0
+    for sweep in range(2):
+        for j in range(D):
+            if mode == "poison" and sweep == 1 and j % 4 == 1:
+                # the same state pushes the fixture generator applied to the reference objects
+                if regname == "omegacs":
+                    if j % 8 == 1:
+                        reg._cache[degree - 1] = -abs(reg._cache[degree - 1]) - 1e-3
+                    reg._norms[j] = reg._norms[j] + 50.0
+                else:
+                    reg._cache = reg._norms[j] - 1e-3
+            pj = z["v_in|" + tag][t].copy()
+            reg.prox_bcd(pj, float(z["strength|" + tag][t]), degree, j)
+            np.testing.assert_allclose(pj, z["v_out|" + tag][t], rtol=0, atol=1e-12)
+            P[j] = pj
+            reg.update_cache_pbcd(P, degree, j)
+            if regname in ("squaredl21", "omegacs"):
+                c = np.zeros(degree + 1)
+                if regname == "squaredl21":
+                    c[0] = reg._cache
+                else:
+                    c[:] = reg._cache
+                    np.testing.assert_allclose(reg._dcache, z["dcache|" + tag][t], rtol=1e-11,
+                                               atol=1e-12)
+                np.testing.assert_allclose(c, z["cache|" + tag][t], rtol=1e-11, atol=1e-12)
+                np.testing.assert_allclose(reg._norms, z["norms|" + tag][t], rtol=1e-12, atol=1e-13)
+            t += 1
+    np.testing.assert_allclose(P, z["P_end|" + tag], rtol=0, atol=1e-12)
+
+
+def test_eval_and_full_prox_against_definitions():
+    rng = np.random.RandomState(0)
+    P = rng.randn(D, K) * (rng.rand(D, K) < 0.7)
+    R = REGULARIZATION
+    assert np.isclose(R["l1"]().eval(P), np.abs(P).sum())
+    assert np.isclose(R["l21"]().eval(P), np.linalg.norm(P, axis=1).sum())
+    assert np.isclose(R["squaredl21"]().eval(P), np.linalg.norm(P, axis=1).sum() ** 2)
+    assert np.isclose(R["squaredl12"]().eval(P.T), (np.abs(P.T).sum(axis=1) ** 2).sum())
+    # e_2 of the magnitudes = ((sum)^2 - sum of squares) / 2
+    a = np.abs(P[:, 0])
+    assert np.isclose(R["omegati"]().eval(P[:, 0], 2), (a.sum() ** 2 - (a * a).sum()) / 2)
+    nrm = np.linalg.norm(P, axis=1)
+    assert np.isclose(R["omegacs"]().eval(P, 2), (nrm.sum() ** 2 - (nrm * nrm).sum()) / 2)
+    # full-matrix prox: optimality of 0.5 ||U - V||^2 + c ||u||_1^2 per component (subgradient)
+    c = 0.3
+    V = P.copy()
+    U = V.copy()
+    R["squaredl12"]().prox(U, c, 2)
+    for s in range(K):
+        u, v = U[:, s], V[:, s]
+        nzs = u != 0
+        g = u - v + 2 * c * np.abs(u).sum() * np.sign(u)
+        assert np.allclose(g[nzs], 0.0, atol=1e-12)
+        assert np.all(np.abs((u - v)[~nzs]) <= 2 * c * np.abs(u).sum() + 1e-12)
+    U = V.copy()
+    R["l1"]().prox(U, c, 2)
+    assert np.allclose(U, np.sign(V) * np.maximum(np.abs(V) - c, 0))
+    U = V.copy()
+    R["l21"]().prox(U, c, 2)
+    nv = np.linalg.norm(V, axis=1)
+    big = nv > c
+    assert np.allclose(U[big], V[big] * (1 - c / nv[big])[:, None])
+    assert np.allclose(U[~big], V[~big])          # the reference leaves small rows unchanged
+    U = V.copy()
+    R["squaredl21"]().prox(U, c, 2)
+    nu = np.linalg.norm(U, axis=1)
+    nzs = nu > 0
+    assert np.allclose((nv - nu)[nzs], 2 * c * nu.sum(), atol=1e-12)
+
+
+def test_constraints_and_errors():
+    with pytest.raises(ValueError, match="SquaredL12 supports only degree=2."):
+        REGULARIZATION["squaredl12"]().init_cache_pcd(3, D, K)
+    with pytest.raises(ValueError, match="SquaredL21 supports only degree=2."):
+        REGULARIZATION["squaredl21"]().init_cache_pbcd(3, D, K)
+    with pytest.raises(ValueError):
+        REGULARIZATION["l21"]().init_cache_pcd(2, D, K)
+    with pytest.raises(ValueError):
+        REGULARIZATION["omegati"]().init_cache_pbcd(2, D, K)

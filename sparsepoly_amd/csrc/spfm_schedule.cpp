@@ -8,8 +8,11 @@
 // batch as one dependent step and the result equals the reference sweep over the
 // concatenated batch order (the reference accepts any order: pcd.py:86-87).
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace spfm {
@@ -50,9 +53,19 @@ void schedule_exact(int64_t n_rows, int32_t d, const int64_t* cptr, const int32_
 // rows' short lists (instead of one bitset of all colours per row) keeps the traffic
 // per column at ~(entries x colours-so-far-in-row) bytes.  out_order = colour classes
 // concatenated (columns keep their relative visiting order inside a class).
+void schedule_colored_parallel(int64_t, int32_t, const int64_t*, const int32_t*, const int32_t*, int,
+                               int, std::vector<int32_t>&, std::vector<int32_t>&);
+int schedule_threads();
+
 void schedule_colored(int64_t n_rows, int32_t d, const int64_t* cptr, const int32_t* cidx,
                       const int32_t* order, int max_batch, std::vector<int32_t>& out_order,
                       std::vector<int32_t>& batch_ptr) {
+    // large problems: the parallel form (same greedy rule, deterministic for any thread count)
+    if (d >= 4096 && cptr[d] >= (1 << 20)) {
+        schedule_colored_parallel(n_rows, d, cptr, cidx, order, max_batch, schedule_threads(),
+                                  out_order, batch_ptr);
+        return;
+    }
     // row capacities = entries per row
     std::vector<int64_t> rstart((size_t)n_rows + 1, 0);
     const int64_t nnz = cptr[d];
@@ -118,6 +131,224 @@ void schedule_colored(int64_t n_rows, int32_t d, const int64_t* cptr, const int3
         batch_ptr.push_back((int32_t)out_order.size());
     }
     if (batch_ptr.size() == 1) batch_ptr.push_back(0);
+}
+
+// ---- parallel form of the same greedy colouring (deterministic, speculative) ------------
+// Rounds of `kRound` columns taken in visiting order.  (1) In parallel, every column of the
+// round picks the lowest colour that is absent from all its rows AS OF THE START OF THE ROUND
+// (a snapshot: assignments of the same round are not seen, so the choice does not depend on
+// thread timing).  (2) One thread walks the round in order and accepts a column unless an
+// already accepted column of the round took the same colour and shares a row with it (merge of
+// the two sorted row lists), or the class is full; refused columns go to the front of the next
+// round.  (3) In parallel, the accepted columns append their colour to their rows' lists
+// (atomic slot counters: the order inside a row's list varies, the SET does not).  The result
+// is a valid greedy colouring, identical for any thread count; it differs from the sequential
+// first fit only where a refused column is coloured one round later (~1 % more colours).
+namespace {
+
+class SpinBarrier {
+   public:
+    explicit SpinBarrier(int n) : n_(n) {}
+    void wait() {
+        const int gen = gen_.load(std::memory_order_acquire);
+        if (count_.fetch_add(1, std::memory_order_acq_rel) == n_ - 1) {
+            count_.store(0, std::memory_order_relaxed);
+            gen_.fetch_add(1, std::memory_order_release);
+        } else {
+            while (gen_.load(std::memory_order_acquire) == gen) std::this_thread::yield();
+        }
+    }
+
+   private:
+    const int n_;
+    std::atomic<int> count_{0}, gen_{0};
+};
+
+bool columns_share_row(const int64_t* cptr, const int32_t* cidx, int32_t a, int32_t b) {
+    int64_t i = cptr[a], ie = cptr[a + 1], j = cptr[b], je = cptr[b + 1];
+    while (i < ie && j < je) {
+        const int32_t ra = cidx[i], rb = cidx[j];
+        if (ra == rb) return true;
+        if (ra < rb) ++i;
+        else ++j;
+    }
+    return false;
+}
+
+}  // namespace
+
+void schedule_colored_parallel(int64_t n_rows, int32_t d, const int64_t* cptr, const int32_t* cidx,
+                               const int32_t* order, int max_batch, int n_threads,
+                               std::vector<int32_t>& out_order, std::vector<int32_t>& batch_ptr) {
+    constexpr int kRound = 32;
+    const int64_t nnz = cptr[d];
+    std::vector<int64_t> rstart((size_t)n_rows + 1, 0);
+    for (int64_t ii = 0; ii < nnz; ++ii) rstart[(size_t)cidx[ii] + 1]++;
+    for (int64_t i = 0; i < n_rows; ++i) rstart[(size_t)i + 1] += rstart[(size_t)i];
+    std::vector<int32_t> rcol((size_t)nnz);
+    std::vector<std::atomic<int32_t>> rcnt((size_t)n_rows);
+    for (auto& c : rcnt) c.store(0, std::memory_order_relaxed);
+    std::vector<std::vector<int32_t>> classes;
+    std::vector<uint64_t> full;  // bit c: class c holds max_batch columns
+    // round state
+    std::vector<int32_t> todo(order, order + d);  // remaining columns, visiting order
+    size_t head = 0;
+    std::vector<int32_t> round_cols, refused, tentative((size_t)kRound), accepted;
+    round_cols.reserve(kRound);
+    size_t n_classes = 0, words = 1;
+    bool done = false;
+    SpinBarrier bar(n_threads);
+    std::vector<std::vector<uint64_t>> used((size_t)n_threads);
+
+    auto worker = [&](int tid) {
+        for (;;) {
+            bar.wait();  // round prepared by thread 0
+            if (done) return;
+            // (1) tentative colours from the snapshot
+            std::vector<uint64_t>& u = used[(size_t)tid];
+            for (size_t q = (size_t)tid; q < round_cols.size(); q += (size_t)n_threads) {
+                const int32_t j = round_cols[q];
+                u.assign(words, 0);
+                for (size_t w = 0; w < full.size() && w < words; ++w) u[w] = full[w];
+                for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                    if (ii + 16 < cptr[j + 1]) {
+                        const int32_t i2 = cidx[ii + 16];
+                        __builtin_prefetch(&rcol[(size_t)rstart[(size_t)i2]]);
+                    }
+                    const int32_t i = cidx[ii];
+                    const int32_t* rc = &rcol[(size_t)rstart[(size_t)i]];
+                    const int32_t cnt = rcnt[(size_t)i].load(std::memory_order_relaxed);
+                    for (int32_t t = 0; t < cnt; ++t) u[(size_t)rc[t] >> 6] |= 1ull << (rc[t] & 63);
+                }
+                int32_t c = (int32_t)n_classes;
+                for (size_t w = 0; w < words; ++w)
+                    if (~u[w]) {
+                        const size_t cand = w * 64 + (size_t)__builtin_ctzll(~u[w]);
+                        if (cand < n_classes) c = (int32_t)cand;
+                        break;
+                    }
+                tentative[q] = c;
+            }
+            bar.wait();  // thread 0 resolves the round
+            bar.wait();
+            // (3) commit: colours of the accepted columns into their rows' lists
+            for (size_t q = (size_t)tid; q < accepted.size(); q += (size_t)n_threads) {
+                const int32_t j = round_cols[(size_t)accepted[q]];
+                const int32_t c = tentative[(size_t)accepted[q]];
+                for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                    const int32_t i = cidx[ii];
+                    const int32_t slot = rcnt[(size_t)i].fetch_add(1, std::memory_order_relaxed);
+                    rcol[(size_t)rstart[(size_t)i] + slot] = c;
+                }
+            }
+            bar.wait();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker, t);
+    // thread 0: drives the rounds and takes part in the parallel phases
+    std::vector<uint64_t>& u0 = used[0];
+    for (;;) {
+        // prepare: refused columns of the last round first, then fresh ones
+        round_cols.assign(refused.begin(), refused.end());
+        refused.clear();
+        while ((int)round_cols.size() < kRound && head < todo.size()) round_cols.push_back(todo[head++]);
+        n_classes = classes.size();
+        words = n_classes / 64 + 1;
+        if (round_cols.empty()) {
+            done = true;
+            bar.wait();
+            break;
+        }
+        bar.wait();
+        // thread 0's share of phase (1)
+        for (size_t q = 0; q < round_cols.size(); q += (size_t)n_threads) {
+            const int32_t j = round_cols[q];
+            u0.assign(words, 0);
+            for (size_t w = 0; w < full.size() && w < words; ++w) u0[w] = full[w];
+            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                const int32_t i = cidx[ii];
+                const int32_t* rc = &rcol[(size_t)rstart[(size_t)i]];
+                const int32_t cnt = rcnt[(size_t)i].load(std::memory_order_relaxed);
+                for (int32_t t = 0; t < cnt; ++t) u0[(size_t)rc[t] >> 6] |= 1ull << (rc[t] & 63);
+            }
+            int32_t c = (int32_t)n_classes;
+            for (size_t w = 0; w < words; ++w)
+                if (~u0[w]) {
+                    const size_t cand = w * 64 + (size_t)__builtin_ctzll(~u0[w]);
+                    if (cand < n_classes) c = (int32_t)cand;
+                    break;
+                }
+            tentative[q] = c;
+        }
+        bar.wait();
+        // (2) resolve in visiting order
+        accepted.clear();
+        for (size_t q = 0; q < round_cols.size(); ++q) {
+            int32_t c = tentative[q];
+            if (c >= (int32_t)classes.size()) {
+                // a new class: the first such column opens it, later ones of the round may join
+                // it unless they conflict (handled like any other colour below)
+                c = (int32_t)n_classes;
+                tentative[q] = c;
+            }
+            bool ok = true;
+            size_t same = 0;
+            for (int32_t a : accepted) {
+                if (tentative[(size_t)a] != c) continue;
+                ++same;
+                if (columns_share_row(cptr, cidx, round_cols[(size_t)a], round_cols[q])) {
+                    ok = false;
+                    break;
+                }
+            }
+            const size_t have = (c < (int32_t)classes.size()) ? classes[(size_t)c].size() : 0;
+            if (ok && (int)(have + same) >= max_batch) ok = false;
+            if (ok) accepted.push_back((int32_t)q);
+            else refused.push_back(round_cols[q]);
+        }
+        for (int32_t a : accepted) {
+            const int32_t c = tentative[(size_t)a];
+            if (c >= (int32_t)classes.size()) classes.resize((size_t)c + 1);
+            classes[(size_t)c].push_back(round_cols[(size_t)a]);
+            if ((int)classes[(size_t)c].size() >= max_batch) {
+                if (full.size() <= ((size_t)c >> 6)) full.resize(((size_t)c >> 6) + 1, 0);
+                full[(size_t)c >> 6] |= 1ull << (c & 63);
+            }
+        }
+        bar.wait();
+        for (size_t q = 0; q < accepted.size(); q += (size_t)n_threads) {
+            const int32_t j = round_cols[(size_t)accepted[q]];
+            const int32_t c = tentative[(size_t)accepted[q]];
+            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                const int32_t i = cidx[ii];
+                const int32_t slot = rcnt[(size_t)i].fetch_add(1, std::memory_order_relaxed);
+                rcol[(size_t)rstart[(size_t)i] + slot] = c;
+            }
+        }
+        bar.wait();
+    }
+    for (auto& t : pool) t.join();
+    out_order.clear();
+    out_order.reserve((size_t)d);
+    batch_ptr.clear();
+    batch_ptr.push_back(0);
+    for (auto& cl : classes) {
+        if (cl.empty()) continue;
+        out_order.insert(out_order.end(), cl.begin(), cl.end());
+        batch_ptr.push_back((int32_t)out_order.size());
+    }
+    if (batch_ptr.size() == 1) batch_ptr.push_back(0);
+}
+
+// threads for the parallel colouring: SPFM_THREADS, else min(hardware, 16); 1 = sequential
+int schedule_threads() {
+    if (const char* e = std::getenv("SPFM_THREADS")) {
+        const int v = std::atoi(e);
+        if (v >= 1) return std::min(v, 64);
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hw, 16u));
 }
 
 // CSC -> CSR (counting sort; keeps ascending column order inside each row)

@@ -33,7 +33,7 @@ def test_config5_full_size_single_gpu(oracle):
     if n == 10_000_000 and d == 1_000_000:
         assert 2000 < r["info"]["steps_per_sweep"] < 3500, r["info"]  # colours, not colours x 6
     scale = max(1.0, float(np.abs(r["y_recomputed"]).max()))
-    np.testing.assert_allclose(r["y_pred"], r["y_recomputed"], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(r["y_incremental"], r["y_recomputed"], rtol=0, atol=2e-4 * scale)
     ref = bench_c5.run_oracle(Xc, y, P0, r["y0"], r["order"], 2)
     np.testing.assert_allclose(r["v_lin"], ref["v_lin"], rtol=1e-5)
     np.testing.assert_allclose(r["v"], ref["v"], rtol=1e-5)

@@ -54,6 +54,7 @@ def run_engine(Xc, y, P0, passes, options, reps=1):
         t0 = time.perf_counter()
         eng.pcd_epoch(0, 2, BETA, GAMMA, 1.0, ic)
         t_pass = (time.perf_counter() - t0) / passes
+    y_inc = eng.get_y_pred()       # incrementally maintained through all the epochs above
     eng.init_pred(2, True, False)  # recomputed from the trained parameters
     y_new = eng.get_y_pred()
     info = dict(steps_per_sweep=eng.n_batches, persistent=eng.get_option("persistent_active"),
@@ -65,8 +66,8 @@ def run_engine(Xc, y, P0, passes, options, reps=1):
                     us_per_dependent_step=round(1e6 * t_pass / eng.n_batches, 2),
                     est_ms_per_iteration=round(1e3 * (t_lin + K * t_pass), 0))
     eng.close()
-    return dict(v_lin=v_lin, v=v, P=P, w=w, y_pred=yp, y_recomputed=y_new, y0=y0, order=order,
-                info=info)
+    return dict(v_lin=v_lin, v=v, P=P, w=w, y_pred=yp, y_incremental=y_inc, y_recomputed=y_new,
+                y0=y0, order=order, info=info)
 
 
 def run_oracle(Xc, y, P0, y0, order, passes):
@@ -112,7 +113,7 @@ def main():
         r = run_engine(Xc, y, P0, args.passes, opts[name])
         out = dict(config="BASELINE configs[4] on one GPU", engine=name, n=args.n, d=args.d,
                    nnz=int(Xc.nnz), passes=args.passes, **r["info"])
-        out["incremental_vs_recomputed_max_abs"] = float(np.abs(r["y_pred"] - r["y_recomputed"]).max())
+        out["incremental_vs_recomputed_max_abs"] = float(np.abs(r["y_incremental"] - r["y_recomputed"]).max())
         out["viol"] = [float(r["v_lin"]), float(r["v"])]
         if args.oracle and ref is None:
             ref = run_oracle(Xc, y, P0, r["y0"], r["order"], args.passes)

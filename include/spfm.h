@@ -81,6 +81,13 @@ int spfm_device_name(spfm_handle h, char* out, int cap);
 int spfm_set_data_csc(spfm_handle h, int64_t n, int32_t d, const int64_t* indptr,
                       const int32_t* indices, const double* data, const double* y);
 
+/* The same from a CSR matrix (what scipy hands the estimators most of the time): indptr[n+1]
+ * (int64), indices[nnz] (int32 column ids, sorted and duplicate-free inside each row), data,
+ * y[n].  Replaces X.tocsc() of get_dataset as well: the CSC image is built inside, by host
+ * threads (SPFM_THREADS, default min(cores, 16)). */
+int spfm_set_data_csr(spfm_handle h, int64_t n, int32_t d, const int64_t* indptr,
+                      const int32_t* indices, const double* data, const double* y);
+
 /* -- parameters -------------------------------------------------------------
  * P is (n_orders, k, d) row-major as self.P_ (sparse_factorization_machines.py
  * :383-389), w (d), lams (k, each +-1: :403-404).  d must equal the data's

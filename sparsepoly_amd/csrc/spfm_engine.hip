@@ -14,6 +14,7 @@
 #include <map>
 #include <string>
 #include <type_traits>
+#include <thread>
 #include <vector>
 
 #include "../../include/spfm.h"
@@ -24,6 +25,9 @@ void schedule_exact(int64_t, int32_t, const int64_t*, const int32_t*, const int3
                     std::vector<int32_t>&);
 void schedule_colored(int64_t, int32_t, const int64_t*, const int32_t*, const int32_t*, int,
                       std::vector<int32_t>&, std::vector<int32_t>&);
+bool csr_to_csc(int64_t, int32_t, const int64_t*, const int32_t*, std::vector<int64_t>&,
+                std::vector<int32_t>&, std::vector<int64_t>&);
+int schedule_threads();
 void csc_to_csr(int64_t, int32_t, const int64_t*, const int32_t*, std::vector<int64_t>&,
                 std::vector<int32_t>&, std::vector<int64_t>&);
 void build_pb_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
@@ -466,15 +470,32 @@ struct spfm_engine {
     }
 
     // =================================================================== data
+    // uploads both images; values in CSC order (`data_csc`) or in CSR order (`data_csr`) --
+    // the other order goes through `perm` (position in the wanted order -> position in the
+    // given one); conversions to the storage type run on host threads
     template <typename T>
-    int set_data_t(const int64_t* indptr, const int32_t* indices, const double* data,
-                   const double* y) {
-        std::vector<int64_t> h_rptr, perm;
-        std::vector<int32_t> h_ridx;
-        csc_to_csr(n, d, indptr, indices, h_rptr, h_ridx, perm);
+    int upload_images(const int64_t* h_cp, const int32_t* h_ci, const int64_t* h_rp,
+                      const int32_t* h_ri, const double* data_csc, const double* data_csr,
+                      const int64_t* perm, const double* y) {
         std::vector<T> cv((size_t)nnz), rv((size_t)nnz);
-        for (int64_t ii = 0; ii < nnz; ++ii) cv[(size_t)ii] = (T)data[ii];
-        for (int64_t ii = 0; ii < nnz; ++ii) rv[(size_t)ii] = cv[(size_t)perm[(size_t)ii]];
+        const int T_ = (nnz >= (1 << 20)) ? schedule_threads() : 1;
+        {
+            std::vector<std::thread> pool;
+            auto work = [&](int tid) {
+                const int64_t per = (nnz + T_ - 1) / T_;
+                const int64_t lo = per * tid, hi = std::min<int64_t>(nnz, lo + per);
+                if (data_csc) {
+                    for (int64_t ii = lo; ii < hi; ++ii) cv[(size_t)ii] = (T)data_csc[ii];
+                    for (int64_t ii = lo; ii < hi; ++ii) rv[(size_t)ii] = (T)data_csc[perm[ii]];
+                } else {
+                    for (int64_t ii = lo; ii < hi; ++ii) rv[(size_t)ii] = (T)data_csr[ii];
+                    for (int64_t ii = lo; ii < hi; ++ii) cv[(size_t)ii] = (T)data_csr[perm[ii]];
+                }
+            };
+            for (int t = 1; t < T_; ++t) pool.emplace_back(work, t);
+            work(0);
+            for (auto& th : pool) th.join();
+        }
         std::vector<T> hy((size_t)n * 2);
         for (int64_t i = 0; i < n; ++i) {
             hy[(size_t)2 * i] = (T)0;
@@ -488,16 +509,16 @@ struct spfm_engine {
         HIPC(rval.alloc(sizeof(T) * (size_t)nnz));
         HIPC(yy.alloc(sizeof(T) * 2 * (size_t)n));
         HIPC(col_norm.alloc(sizeof(double) * (size_t)d));
-        HIPC(hipMemcpyAsync(cptr.p, indptr, sizeof(int64_t) * ((size_t)d + 1),
-                            hipMemcpyHostToDevice, stream));
-        HIPC(hipMemcpyAsync(cidx.p, indices, sizeof(int32_t) * (size_t)nnz,
-                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(cptr.p, h_cp, sizeof(int64_t) * ((size_t)d + 1), hipMemcpyHostToDevice,
+                            stream));
+        HIPC(hipMemcpyAsync(cidx.p, h_ci, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice,
+                            stream));
         HIPC(hipMemcpyAsync(cval.p, cv.data(), sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice,
                             stream));
-        HIPC(hipMemcpyAsync(rptr.p, h_rptr.data(), sizeof(int64_t) * ((size_t)n + 1),
-                            hipMemcpyHostToDevice, stream));
-        HIPC(hipMemcpyAsync(ridx.p, h_ridx.data(), sizeof(int32_t) * (size_t)nnz,
-                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(rptr.p, h_rp, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice,
+                            stream));
+        HIPC(hipMemcpyAsync(ridx.p, h_ri, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice,
+                            stream));
         HIPC(hipMemcpyAsync(rval.p, rv.data(), sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice,
                             stream));
         HIPC(hipMemcpyAsync(yy.p, hy.data(), sizeof(T) * 2 * (size_t)n, hipMemcpyHostToDevice,
@@ -508,6 +529,64 @@ struct spfm_engine {
         HIPC(hipGetLastError());
         HIPC(hipStreamSynchronize(stream));  // host staging vectors die here
         return SPFM_OK;
+    }
+
+    template <typename T>
+    int set_data_t(const int64_t* indptr, const int32_t* indices, const double* data,
+                   const double* y) {
+        std::vector<int64_t> h_rptr, perm;
+        std::vector<int32_t> h_ridx;
+        csc_to_csr(n, d, indptr, indices, h_rptr, h_ridx, perm);
+        return upload_images<T>(indptr, indices, h_rptr.data(), h_ridx.data(), data, nullptr,
+                                perm.data(), y);
+    }
+
+    // after the images are on the device: state shared by both ingest forms
+    int data_installed(const double* y) {
+        y_pm1 = true;
+        for (int64_t i = 0; i < n; ++i)
+            if (std::fabs(y[i]) != 1.0) {
+                y_pm1 = false;
+                break;
+            }
+        have_data = true;
+        have_schedule = false;
+        configured = false;
+        col_norm_reduced = false;
+        clear_graphs();
+        HIPC(viol_col.alloc(sizeof(double) * (size_t)d));
+        HIPC(pred_tmp.alloc(sizeof(double) * (size_t)(n > 0 ? n : 1)));
+        HIPC(partial.alloc(sizeof(double) * 1024));
+        return SPFM_OK;
+    }
+
+    // CSR ingest (replaces get_dataset's X.tocsc(), dataset.py:119-123, too): the CSC image
+    // is built by host threads, the CSR image is the input itself
+    int set_data_csr(int64_t n_, int32_t d_, const int64_t* indptr, const int32_t* indices,
+                     const double* data, const double* y) {
+        if (n_ < 0 || d_ <= 0 || !indptr || !y) FAIL(SPFM_ERR_INVALID, "set_data: bad arguments");
+        if (n_ >= (int64_t)1 << 31) FAIL(SPFM_ERR_UNSUPPORTED, "n_samples must be < 2^31");
+        if (indptr[0] != 0) FAIL(SPFM_ERR_INVALID, "set_data: indptr[0] != 0");
+        for (int64_t i = 0; i < n_; ++i)
+            if (indptr[i + 1] < indptr[i]) FAIL(SPFM_ERR_INVALID, "set_data: indptr not monotone");
+        std::vector<int64_t> cp, perm;
+        std::vector<int32_t> ci;
+        if (!csr_to_csc(n_, d_, indptr, indices, cp, ci, perm))
+            FAIL(SPFM_ERR_INVALID,
+                 "set_data: CSR must have sorted, duplicate-free column indices in [0, d)");
+        if (have_params && d_ != d) have_params = false;
+        n = n_;
+        d = d_;
+        nnz = indptr[n_];
+        h_cptr.swap(cp);
+        h_cidx.swap(ci);
+        int rc = (dtype == SPFM_F32)
+                     ? upload_images<float>(h_cptr.data(), h_cidx.data(), indptr, indices, nullptr,
+                                            data, perm.data(), y)
+                     : upload_images<double>(h_cptr.data(), h_cidx.data(), indptr, indices, nullptr,
+                                             data, perm.data(), y);
+        if (rc) return rc;
+        return data_installed(y);
     }
 
     int set_data(int64_t n_, int32_t d_, const int64_t* indptr, const int32_t* indices,
@@ -531,26 +610,12 @@ struct spfm_engine {
         n = n_;
         d = d_;
         nnz = nz;
-        y_pm1 = true;
-        for (int64_t i = 0; i < n; ++i)
-            if (std::fabs(y[i]) != 1.0) {
-                y_pm1 = false;
-                break;
-            }
         h_cptr.assign(indptr, indptr + d + 1);
         h_cidx.assign(indices, indices + nnz);
-        have_data = true;
-        have_schedule = false;
-        configured = false;
-        col_norm_reduced = false;
-        clear_graphs();
         int rc = (dtype == SPFM_F32) ? set_data_t<float>(indptr, indices, data, y)
                                      : set_data_t<double>(indptr, indices, data, y);
         if (rc) return rc;
-        HIPC(viol_col.alloc(sizeof(double) * (size_t)d));
-        HIPC(pred_tmp.alloc(sizeof(double) * (size_t)(n > 0 ? n : 1)));
-        HIPC(partial.alloc(sizeof(double) * 1024));
-        return SPFM_OK;
+        return data_installed(y);
     }
 
     // ================================================================= params
@@ -2075,6 +2140,12 @@ int spfm_set_data_csc(spfm_handle h, int64_t n, int32_t d, const int64_t* indptr
                       const int32_t* indices, const double* data, const double* y) {
     GUARD(h);
     return h->set_data(n, d, indptr, indices, data, y);
+}
+
+int spfm_set_data_csr(spfm_handle h, int64_t n, int32_t d, const int64_t* indptr,
+                      const int32_t* indices, const double* data, const double* y) {
+    GUARD(h);
+    return h->set_data_csr(n, d, indptr, indices, data, y);
 }
 
 int spfm_set_params(spfm_handle h, int n_orders, int k, int32_t d, const double* P,

@@ -502,6 +502,27 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         }
         PB_STAMP(1)
 
+        // ---- prefetch: entries of step b+2, rows of step b+1 that this step does not touch,
+        // column ids / P rows / old norms of the coming steps.  Issued right behind the publish,
+        // in front of both polls: vmcnt retires in order, so the first tag check waits for these
+        // loads too -- but an owner waits about that long for the slowest workgroup's partial
+        // sums, and everybody else for the owners
+        int b3e0, b3e1;
+        bounds(b + 3, b3e0, b3e1);
+        load_entries(nn, b2e0, b2e1);
+        fetch_rows(nxt, par ^ 1, 0);
+        int j2[QM];
+#pragma unroll
+        for (int t = 0; t < QM; ++t) {
+            j2[t] = col_id(c2, c3 - c2, grp + t * NG);
+            pon[t] = (j1[t] >= 0 && kl) ? P[(size_t)j1[t] * k + lane] : 0.0;
+        }
+        const int oj2 = col_id(c2, c3 - c2, oq);
+        opon = (oj1 >= 0 && grp == 0 && kl) ? P[(size_t)oj1 * k + lane] : 0.0;
+        const int cj2 = (wave == 0) ? col_id(c2, c3 - c2, wlane) : -1;
+        cn1 = (cj1 >= 0 && chained) ? rs.norms[cj1] : 0.0;
+        PB_STAMP(4)
+
         // ---- phase 2: owners reduce their slot over the workgroups and take the step
         const int n_rounds = fixed_owner ? 1 : (nw + a.G - 1) / a.G;
         for (int r = 0; r < n_rounds; ++r) {
@@ -614,25 +635,6 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         }
         PB_STAMP(3)
 
-        // ---- prefetch: entries of step b+2, rows of step b+1 that this step does not touch,
-        // column ids / P rows / old norms of the coming steps.  Issued before the collect poll:
-        // vmcnt retires in order, so the first tag check waits for these loads too -- but the
-        // owners need about that long to reduce and publish anyway
-        int b3e0, b3e1;
-        bounds(b + 3, b3e0, b3e1);
-        load_entries(nn, b2e0, b2e1);
-        fetch_rows(nxt, par ^ 1, 0);
-        int j2[QM];
-#pragma unroll
-        for (int t = 0; t < QM; ++t) {
-            j2[t] = col_id(c2, c3 - c2, grp + t * NG);
-            pon[t] = (j1[t] >= 0 && kl) ? P[(size_t)j1[t] * k + lane] : 0.0;
-        }
-        const int oj2 = col_id(c2, c3 - c2, oq);
-        opon = (oj1 >= 0 && grp == 0 && kl) ? P[(size_t)oj1 * k + lane] : 0.0;
-        const int cj2 = (wave == 0) ? col_id(c2, c3 - c2, wlane) : -1;
-        cn1 = (cj1 >= 0 && chained) ? rs.norms[cj1] : 0.0;
-        PB_STAMP(4)
         // ---- phase 3: every workgroup collects the published vectors of all slots
         {
             const int total = ncols * L;

@@ -134,7 +134,7 @@ void schedule_colored(int64_t n_rows, int32_t d, const int64_t* cptr, const int3
 }
 
 // ---- parallel form of the same greedy colouring (deterministic, speculative) ------------
-// Rounds of `kRound` columns taken in visiting order.  (1) In parallel, every column of the
+// Rounds of 32 columns taken in visiting order.  (1) In parallel, every column of the
 // round picks the lowest colour that is absent from all its rows AS OF THE START OF THE ROUND
 // (a snapshot: assignments of the same round are not seen, so the choice does not depend on
 // thread timing).  (2) One thread walks the round in order and accepts a column unless an
@@ -180,7 +180,10 @@ bool columns_share_row(const int64_t* cptr, const int32_t* cidx, int32_t a, int3
 void schedule_colored_parallel(int64_t n_rows, int32_t d, const int64_t* cptr, const int32_t* cidx,
                                const int32_t* order, int max_batch, int n_threads,
                                std::vector<int32_t>& out_order, std::vector<int32_t>& batch_ptr) {
-    constexpr int kRound = 32;
+    // 32 columns per round: with more, the columns of a round pick the same few colours and
+    // refuse each other (64: 2.5x slower, 256: 5x); a constant, so the result is the same for
+    // any thread count
+    constexpr int kRoundMax = 32;
     const int64_t nnz = cptr[d];
     std::vector<int64_t> rstart((size_t)n_rows + 1, 0);
     for (int64_t ii = 0; ii < nnz; ++ii) rstart[(size_t)cidx[ii] + 1]++;
@@ -193,8 +196,8 @@ void schedule_colored_parallel(int64_t n_rows, int32_t d, const int64_t* cptr, c
     // round state
     std::vector<int32_t> todo(order, order + d);  // remaining columns, visiting order
     size_t head = 0;
-    std::vector<int32_t> round_cols, refused, tentative((size_t)kRound), accepted;
-    round_cols.reserve(kRound);
+    std::vector<int32_t> round_cols, refused, tentative((size_t)kRoundMax), accepted;
+    round_cols.reserve(kRoundMax);
     size_t n_classes = 0, words = 1;
     bool done = false;
     SpinBarrier bar(n_threads);
@@ -252,7 +255,8 @@ void schedule_colored_parallel(int64_t n_rows, int32_t d, const int64_t* cptr, c
         // prepare: refused columns of the last round first, then fresh ones
         round_cols.assign(refused.begin(), refused.end());
         refused.clear();
-        while ((int)round_cols.size() < kRound && head < todo.size()) round_cols.push_back(todo[head++]);
+        while ((int)round_cols.size() < kRoundMax && head < todo.size())
+            round_cols.push_back(todo[head++]);
         n_classes = classes.size();
         words = n_classes / 64 + 1;
         if (round_cols.empty()) {
@@ -282,16 +286,11 @@ void schedule_colored_parallel(int64_t n_rows, int32_t d, const int64_t* cptr, c
             tentative[q] = c;
         }
         bar.wait();
-        // (2) resolve in visiting order
+        // (2) resolve in visiting order (a column that found no free class has tentative colour
+        // n_classes: the first such column opens the class, later ones may join it)
         accepted.clear();
         for (size_t q = 0; q < round_cols.size(); ++q) {
-            int32_t c = tentative[q];
-            if (c >= (int32_t)classes.size()) {
-                // a new class: the first such column opens it, later ones of the round may join
-                // it unless they conflict (handled like any other colour below)
-                c = (int32_t)n_classes;
-                tentative[q] = c;
-            }
+            const int32_t c = tentative[q];
             bool ok = true;
             size_t same = 0;
             for (int32_t a : accepted) {
@@ -351,23 +350,96 @@ int schedule_threads() {
     return (int)std::max(1u, std::min(hw, 16u));
 }
 
-// CSC -> CSR (counting sort; keeps ascending column order inside each row)
+// run fn(tid) on `n_threads` host threads (thread 0 = the caller)
+template <typename F>
+static void run_threads(int n_threads, F&& fn) {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back([&fn, t]() { fn(t); });
+    fn(0);
+    for (auto& th : pool) th.join();
+}
+
+// Transposition of a compressed sparse structure by host threads, the pattern of every ingest
+// step below: the OUTPUT index space (rows of the CSR image, columns of the CSC image, row
+// blocks of an entry stream) is cut into one contiguous range per thread; every thread scans
+// ALL entries in input order (sequential reads: cheap) and handles those that fall into its
+// range, so there are no write conflicts and the order inside an output segment is the input
+// order (ascending) -- the result is identical for any thread count.
+
+// CSC -> CSR (keeps ascending column order inside each row)
 void csc_to_csr(int64_t n, int32_t d, const int64_t* cptr, const int32_t* cidx,
                 std::vector<int64_t>& rptr, std::vector<int32_t>& ridx,
                 std::vector<int64_t>& perm /* csr position -> csc position */) {
     const int64_t nnz = cptr[d];
     rptr.assign((size_t)n + 1, 0);
-    for (int64_t ii = 0; ii < nnz; ++ii) rptr[(size_t)cidx[ii] + 1]++;
-    for (int64_t i = 0; i < n; ++i) rptr[(size_t)i + 1] += rptr[(size_t)i];
     ridx.resize((size_t)nnz);
     perm.resize((size_t)nnz);
-    std::vector<int64_t> fill(rptr.begin(), rptr.end() - 1);
-    for (int32_t j = 0; j < d; ++j)
-        for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
-            const int64_t dst = fill[(size_t)cidx[ii]]++;
-            ridx[(size_t)dst] = j;
-            perm[(size_t)dst] = ii;
+    const int T = (nnz >= (1 << 20)) ? schedule_threads() : 1;
+    const int64_t per = (n + T - 1) / T;
+    run_threads(T, [&](int tid) {  // counts of the thread's rows
+        const int64_t lo = per * tid, hi = std::min<int64_t>(n, lo + per);
+        for (int64_t ii = 0; ii < nnz; ++ii) {
+            const int64_t i = cidx[ii];
+            if (i >= lo && i < hi) rptr[(size_t)i + 1]++;
         }
+    });
+    for (int64_t i = 0; i < n; ++i) rptr[(size_t)i + 1] += rptr[(size_t)i];
+    std::vector<int64_t> fill(rptr.begin(), rptr.end() - 1);
+    run_threads(T, [&](int tid) {
+        const int64_t lo = per * tid, hi = std::min<int64_t>(n, lo + per);
+        for (int32_t j = 0; j < d; ++j)
+            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                const int64_t i = cidx[ii];
+                if (i < lo || i >= hi) continue;
+                const int64_t dst = fill[(size_t)i]++;
+                ridx[(size_t)dst] = j;
+                perm[(size_t)dst] = ii;
+            }
+    });
+}
+
+// CSR -> CSC (dataset.py:119-123's X.tocsc(), on host threads): rows ascending inside each
+// column; perm = csc position -> csr position.  Returns false if a row's column indices are
+// not strictly ascending (not canonical) or out of range.
+bool csr_to_csc(int64_t n, int32_t d, const int64_t* rptr, const int32_t* ridx,
+                std::vector<int64_t>& cptr, std::vector<int32_t>& cidx,
+                std::vector<int64_t>& perm) {
+    const int64_t nnz = rptr[n];
+    cptr.assign((size_t)d + 1, 0);
+    cidx.resize((size_t)nnz);
+    perm.resize((size_t)nnz);
+    const int T = (nnz >= (1 << 20)) ? schedule_threads() : 1;
+    const int32_t per = (int32_t)((d + T - 1) / T);
+    std::vector<char> bad((size_t)T, 0);
+    run_threads(T, [&](int tid) {
+        const int32_t lo = per * tid, hi = std::min<int32_t>(d, lo + per);
+        if (tid == 0)
+            for (int64_t i = 0; i < n && !bad[0]; ++i)
+                for (int64_t ii = rptr[i]; ii < rptr[i + 1]; ++ii)
+                    if (ridx[ii] < 0 || ridx[ii] >= d || (ii > rptr[i] && ridx[ii] <= ridx[ii - 1])) {
+                        bad[0] = 1;
+                        break;
+                    }
+        for (int64_t ii = 0; ii < nnz; ++ii) {
+            const int32_t j = ridx[ii];
+            if (j >= lo && j < hi) cptr[(size_t)j + 1]++;
+        }
+    });
+    if (bad[0]) return false;
+    for (int32_t j = 0; j < d; ++j) cptr[(size_t)j + 1] += cptr[(size_t)j];
+    std::vector<int64_t> fill(cptr.begin(), cptr.end() - 1);
+    run_threads(T, [&](int tid) {
+        const int32_t lo = per * tid, hi = std::min<int32_t>(d, lo + per);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t ii = rptr[i]; ii < rptr[i + 1]; ++ii) {
+                const int32_t j = ridx[ii];
+                if (j < lo || j >= hi) continue;
+                const int64_t dst = fill[(size_t)j]++;
+                cidx[(size_t)dst] = (int32_t)i;
+                perm[(size_t)dst] = ii;
+            }
+    });
+    return true;
 }
 
 // Entry stream of the persistent row-block pass: entries sorted by (row block g,
@@ -384,15 +456,23 @@ void build_rowblock_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
     const int nb = (int)batch_ptr.size() - 1;
     const int64_t rows_per = (n + G - 1) / G > 0 ? (n + G - 1) / G : 1;
     sp.assign((size_t)G * nb * 65 + 1, 0);
-    // pass 1: counts
-    for (int b = 0; b < nb; ++b)
-        for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
-            const int32_t j = order[(size_t)batch_ptr[b] + q];
-            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
-                const int g = (int)(cidx[ii] / rows_per);
-                sp[((size_t)g * nb + b) * 65 + q]++;
+    const int64_t nnz = cptr[order.size()];
+    const int T = std::min(G, (nnz >= (1 << 20)) ? schedule_threads() : 1);
+    const int gper = (G + T - 1) / T;  // row blocks per thread
+    // pass 1: counts (a thread owns the row blocks [g0, g1), hence its slice of sp)
+    run_threads(T, [&](int tid) {
+        const int g0 = gper * tid, g1 = std::min(G, g0 + gper);
+        const int64_t rlo = (int64_t)g0 * rows_per, rhi = (int64_t)g1 * rows_per;
+        for (int b = 0; b < nb; ++b)
+            for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
+                const int32_t j = order[(size_t)batch_ptr[b] + q];
+                for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                    const int64_t i = cidx[ii];
+                    if (i < rlo || i >= rhi) continue;
+                    sp[((size_t)(i / rows_per) * nb + b) * 65 + q]++;
+                }
             }
-        }
+    });
     // exclusive prefix sum in (g, b, q) order; slots >= ncols of a batch hold 0 entries, so
     // sp[..+q] for q in [ncols, 64] all equal the end of the (g, b) segment
     int64_t run = 0;
@@ -411,14 +491,19 @@ void build_rowblock_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
         }
     src.resize((size_t)run);
     std::vector<int32_t> fill(sp.begin(), sp.end());
-    for (int b = 0; b < nb; ++b)
-        for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
-            const int32_t j = order[(size_t)batch_ptr[b] + q];
-            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
-                const int g = (int)(cidx[ii] / rows_per);
-                src[(size_t)fill[((size_t)g * nb + b) * 65 + q]++] = (int32_t)ii;
+    run_threads(T, [&](int tid) {
+        const int g0 = gper * tid, g1 = std::min(G, g0 + gper);
+        const int64_t rlo = (int64_t)g0 * rows_per, rhi = (int64_t)g1 * rows_per;
+        for (int b = 0; b < nb; ++b)
+            for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
+                const int32_t j = order[(size_t)batch_ptr[b] + q];
+                for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                    const int64_t i = cidx[ii];
+                    if (i < rlo || i >= rhi) continue;
+                    src[(size_t)fill[((size_t)(i / rows_per) * nb + b) * 65 + q]++] = (int32_t)ii;
+                }
             }
-        }
+    });
 }
 
 // Entry stream of the persistent pbcd pass: entries sorted by (row block g, batch b, slot
@@ -435,14 +520,22 @@ void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
     const int64_t rows_per = (n + G - 1) / G > 0 ? (n + G - 1) / G : 1;
     const size_t stride = (size_t)NG + 1;
     gsp.assign((size_t)G * nb * stride + 1, 0);
-    for (int b = 0; b < nb; ++b)
-        for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
-            const int32_t j = order[(size_t)batch_ptr[b] + q];
-            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
-                const int g = (int)(cidx[ii] / rows_per);
-                gsp[((size_t)g * nb + b) * stride + (size_t)(q % NG)]++;
+    const int64_t nnz = cptr[order.size()];
+    const int T = std::min(G, (nnz >= (1 << 20)) ? schedule_threads() : 1);
+    const int gper = (G + T - 1) / T;
+    run_threads(T, [&](int tid) {
+        const int g0 = gper * tid, g1 = std::min(G, g0 + gper);
+        const int64_t rlo = (int64_t)g0 * rows_per, rhi = (int64_t)g1 * rows_per;
+        for (int b = 0; b < nb; ++b)
+            for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
+                const int32_t j = order[(size_t)batch_ptr[b] + q];
+                for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                    const int64_t i = cidx[ii];
+                    if (i < rlo || i >= rhi) continue;
+                    gsp[((size_t)(i / rows_per) * nb + b) * stride + (size_t)(q % NG)]++;
+                }
             }
-        }
+    });
     int64_t run = 0;
     for (size_t t = 0; t < gsp.size(); ++t) {  // exclusive prefix sum; the pad word of each
         const int64_t c = gsp[t];              // (g, b) holds 0 entries = end of the last group
@@ -452,26 +545,28 @@ void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
     src.resize((size_t)run);
     meta.resize((size_t)run);
     std::vector<int32_t> fill(gsp.begin(), gsp.end());
-    std::vector<int32_t> last((size_t)n, -2);  // last step that touched the row
-    // slots of one group in ascending order: q = grp, grp + NG, ... -> walk q ascending and the
+    std::vector<int32_t> last((size_t)n, -2);  // last step that touched the row (own rows only)
+    // slots of one group in ascending order: q = grp, grp + NG, ... -> walking q ascending, the
     // per-group fill pointers keep (slot, row) order inside each group
-    for (int b = 0; b < nb; ++b) {
-        for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
-            const int32_t j = order[(size_t)batch_ptr[b] + q];
-            const uint8_t qi = (uint8_t)(q / NG);
-            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
-                const int32_t i = cidx[ii];
-                const int g = (int)(i / rows_per);
-                const size_t e = (size_t)fill[((size_t)g * nb + b) * stride + (size_t)(q % NG)]++;
-                src[e] = (int32_t)ii;
-                meta[e] = (uint8_t)(qi | (last[(size_t)i] == b - 1 ? 0x80 : 0));
+    run_threads(T, [&](int tid) {
+        const int g0 = gper * tid, g1 = std::min(G, g0 + gper);
+        const int64_t rlo = (int64_t)g0 * rows_per, rhi = (int64_t)g1 * rows_per;
+        for (int b = 0; b < nb; ++b) {
+            for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
+                const int32_t j = order[(size_t)batch_ptr[b] + q];
+                const uint8_t qi = (uint8_t)(q / NG);
+                for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                    const int64_t i = cidx[ii];
+                    if (i < rlo || i >= rhi) continue;
+                    const size_t e = (size_t)fill[((size_t)(i / rows_per) * nb + b) * stride +
+                                                  (size_t)(q % NG)]++;
+                    src[e] = (int32_t)ii;
+                    meta[e] = (uint8_t)(qi | (last[(size_t)i] == b - 1 ? 0x80 : 0));
+                    last[(size_t)i] = b;  // columns of one step share no row: no read-after-write
+                }
             }
         }
-        for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
-            const int32_t j = order[(size_t)batch_ptr[b] + q];
-            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) last[(size_t)cidx[ii]] = b;
-        }
-    }
+    });
 }
 
 }  // namespace spfm

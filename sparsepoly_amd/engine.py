@@ -83,6 +83,16 @@ class HipEngine(object):
 
     # ------------------------------------------------------------------ data
     def set_data(self, X, y):
+        if sp.isspmatrix_csr(X) and X.has_canonical_format:
+            # CSR input: no scipy tocsc(); the library transposes on host threads
+            n, d = X.shape
+            keep = [_capi.i64(X.indptr), _capi.i32(X.indices), _capi.f64(X.data), _capi.f64(y)]
+            if keep[3][0].shape[0] != n:
+                raise ValueError("y has %d entries, X has %d rows" % (keep[3][0].shape[0], n))
+            self._check(self._lib.spfm_set_data_csr(self._h, n, d, keep[0][1], keep[1][1],
+                                                    keep[2][1], keep[3][1]))
+            self.n, self.d = n, d
+            return
         Xc = X if (sp.isspmatrix_csc(X) and X.has_canonical_format) else canonical_csc(X)
         n, d = Xc.shape
         self._keep = [_capi.i64(Xc.indptr), _capi.i32(Xc.indices), _capi.f64(Xc.data),

@@ -368,7 +368,11 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         if isinstance(self.schedule, Schedule) and self.shuffle:
             raise ValueError("a fixed Schedule cannot be combined with shuffle=True.")
 
-        Xc = canonical_csc(X)
+        # canonical CSR goes to the library as it is (threaded transposition inside); everything
+        # else -- and the paths that need the CSC on the host -- through scipy
+        csr_direct = (sp.isspmatrix_csr(X) and X.has_canonical_format and not self.distributed
+                      and not self.warm_start)
+        Xc = None if csr_direct else canonical_csc(X)
         conflict_csc = None
         # warm_start keeps the device session: same data => no re-upload,
         # no re-colouring, no new row-block stream
@@ -401,7 +405,7 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 _dist.connect_peers(engine)  # in-kernel exchange for the persistent passes
                 engine.set_data(Xl, y[lo:hi])
             else:
-                engine.set_data(Xc, y)
+                engine.set_data(X if csr_direct else Xc, y)
             self.P_ = np.ascontiguousarray(self.P_, dtype=np.double)
             self.w_ = np.ascontiguousarray(self.w_, dtype=np.double)
             engine.set_params(self.P_, self.w_, self.lams_)

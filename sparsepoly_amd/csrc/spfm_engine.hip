@@ -1087,20 +1087,31 @@ struct spfm_engine {
         }
         prof_begin(4, nnz);
         bool launched = false;
+        auto launch = [&](auto lr_tag, auto mg_tag, size_t lds) -> int {
+            constexpr int LRc = decltype(lr_tag)::value;
+            constexpr bool MGc = decltype(mg_tag)::value;
+            HIPC(hipFuncSetAttribute((const void*)lin_prb_kernel<T, LOSS, LRc, MGc>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((lin_prb_kernel<T, LOSS, LRc, MGc>), dim3(prb_G), dim3(kPrbThreads),
+                               lds, stream, pa, prb_eval.as<T>(), yy.as<T>(),
+                               prow_old.as<double>(), prb_cn.as<double>(), w.as<double>(), alpha,
+                               mu, prb_viol.as<double>());
+            return SPFM_OK;
+        };
+        int lrc = SPFM_OK;
         if constexpr (can_lr) {
             if (use_lr) {
-                hipLaunchKernelGGL((lin_prb_kernel<T, LOSS, LRV>), dim3(prb_G), dim3(kPrbThreads),
-                                   lds_bytes, stream, pa, prb_eval.as<T>(), yy.as<T>(),
-                                   prow_old.as<double>(), prb_cn.as<double>(), w.as<double>(),
-                                   alpha, mu, prb_viol.as<double>());
+                lrc = pa.n_ranks > 1
+                          ? launch(std::integral_constant<int, LRV>{}, std::true_type{}, lds_bytes)
+                          : launch(std::integral_constant<int, LRV>{}, std::false_type{}, lds_bytes);
                 launched = true;
             }
         }
         if (!launched)
-            hipLaunchKernelGGL((lin_prb_kernel<T, LOSS, 0>), dim3(prb_G), dim3(kPrbThreads),
-                               kPrbLds, stream, pa, prb_eval.as<T>(), yy.as<T>(),
-                               prow_old.as<double>(), prb_cn.as<double>(), w.as<double>(), alpha,
-                               mu, prb_viol.as<double>());
+            lrc = pa.n_ranks > 1
+                      ? launch(std::integral_constant<int, 0>{}, std::true_type{}, kPrbLds)
+                      : launch(std::integral_constant<int, 0>{}, std::false_type{}, kPrbLds);
+        if (lrc) return lrc;
         prof_end(4);
         hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
                            d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());
@@ -1323,13 +1334,20 @@ struct spfm_engine {
             constexpr bool STc = decltype(stamp_tag)::value;
             constexpr int RGc = decltype(reg_tag)::value;
             const size_t lds = LRc != 0 ? lds_bytes : kPrbLds;
-            HIPC(hipFuncSetAttribute((const void*)pcd_prb_kernel<T, M, LOSS, LRc, STc, RGc>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, LRc, STc, RGc>), dim3(prb_G),
-                               dim3(kPrbThreads), lds, stream, c, pa, prb_eval.as<T>(), A.as<T>(),
-                               (size_t)n * Kind<M>::AS, yy.as<T>(), prow_old.as<double>(), Po, d,
-                               reg, cb, mu, beta, gamma, eta, prb_viol.as<double>());
-            return SPFM_OK;
+            auto launch = [&](auto mg_tag) -> int {
+                constexpr bool MGc = decltype(mg_tag)::value;
+                HIPC(hipFuncSetAttribute(
+                    (const void*)pcd_prb_kernel<T, M, LOSS, LRc, STc, RGc, MGc>,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, LRc, STc, RGc, MGc>), dim3(prb_G),
+                                   dim3(kPrbThreads), lds, stream, c, pa, prb_eval.as<T>(),
+                                   A.as<T>(), (size_t)n * Kind<M>::AS, yy.as<T>(),
+                                   prow_old.as<double>(), Po, d, reg, cb, mu, beta, gamma, eta,
+                                   prb_viol.as<double>());
+                return SPFM_OK;
+            };
+            if constexpr (STc) return launch(std::false_type{});  // timers: single GPU only
+            else return pa.n_ranks > 1 ? launch(std::true_type{}) : launch(std::false_type{});
         };
         using std::integral_constant;
         int lrc = SPFM_OK;

@@ -328,7 +328,9 @@ constexpr int kPrbLdsFixed = 2560;  // doubles of fixed LDS (control data, part 
 // configuration); as a runtime switch they cost 5 % of every step.
 // REGC >= 0: the regularizer as a compile-time constant (the chain then carries only that
 // regularizer's code: -3.6 % per step on config 2); REGC = -1: taken from the argument.
-template <typename T, int M, int LOSS, int LR, bool STAMP = false, int REGC = -1>
+// MG = true: several GPUs share the sweep (cross-GPU stage behind the local sweep); a separate
+// instantiation, because even a never-taken branch in the control wave cost 2 % per step.
+template <typename T, int M, int LOSS, int LR, bool STAMP = false, int REGC = -1, bool MG = false>
 __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     const Ctl* __restrict__ ctl, PrbArgs a, const T* __restrict__ eval, T* __restrict__ A_all,
     size_t a_stride, T* __restrict__ yy, const double* __restrict__ pold_sched,
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
 #pragma unroll
                 for (int w = 1; w < kPrbParts; ++w) tot[v] += sh_quart[(w * 64 + lane) * 2 + v];
             }
-            if (a.n_ranks > 1) {
+            if constexpr (MG) {
                 if (!prb_cross_gpu<2>(a, g, b, lane, tot)) *sh_ok = 0;
             }
             const bool valid = lane < ncols;
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
 // epoch start: workgroup 0 writes the new w[j] while others may still read the old one).
 // LR as in pcd_prb_kernel: 1 = residual word per row in LDS (squared loss), 2 = prediction
 // word + label sign (+-1 targets); float storage.  4-5 bytes per row: it always fits.
-template <typename T, int LOSS, int LR>
+template <typename T, int LOSS, int LR, bool MG = false>
 __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
     PrbArgs a, const T* __restrict__ eval, T* __restrict__ yy,
     const double* __restrict__ w_sched, const double* __restrict__ cn_sched,
@@ -918,7 +920,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
             double tot = sh_quart[lane * 2];
 #pragma unroll
             for (int w = 1; w < kPrbParts; ++w) tot += sh_quart[(w * 64 + lane) * 2];
-            if (a.n_ranks > 1) {
+            if constexpr (MG) {
                 if (!prb_cross_gpu<1>(a, g, b, lane, &tot)) *sh_ok = 0;
             }
             const bool valid = lane < ncols;

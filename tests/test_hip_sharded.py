@@ -23,13 +23,18 @@ CASES = {
     "pcd_sql12": ("pcd", "squaredl12", 2, 6, "squared", 10.0, 1e-3),
     "pcd_ti3": ("pcd", "omegati", 3, 4, "logistic", 10.0, 1e-4),
     "pbcd_cs": ("pbcd", "omegacs", 2, 6, "squared", 1.0, 1e-2),
+    # sparse and wide: colour classes of hundreds of columns -> the wide persistent passes
+    "pcd_wide": ("pcd", "squaredl12", 2, 4, "squared", 10.0, 1e-3),
 }
 
 
-def _problem(loss):
+def _problem(loss, case=None):
     sys.path.insert(0, ROOT)
     from sparsepoly_amd.synth import make_problem
 
+    if case == "pcd_wide":
+        X, y = make_problem(6000, 4000, 4, seed=3)
+        return sp.csr_matrix(X), y
     X, y = make_problem(6000, 500, 20, seed=3)
     if loss != "squared":
         y = np.where(y > np.median(y), 1.0, -1.0)
@@ -45,7 +50,7 @@ def _run(case, world, rank, shm_name, precision, engine="multi_kernel", hq=None)
     from sparsepoly_amd.engine import HipEngine, canonical_csc
 
     solver, reg, degree, k, loss, beta, gamma = CASES[case]
-    X, y = _problem(loss)
+    X, y = _problem(loss, case)
     n, d = X.shape
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world
     Xg = canonical_csc(X)
@@ -54,6 +59,7 @@ def _run(case, world, rank, shm_name, precision, engine="multi_kernel", hq=None)
         eng.set_option("persistent", 0)   # the multi-kernel engine in both runs
     else:
         eng.set_option("pbprb_groups", 64)  # two co-resident persistent kernels: 2 x 64 CUs
+        eng.set_option("pcdw_groups", 64)
     if world > 1:
         eng.comm_init_shm(shm_name, world, rank)
         if engine == "persistent_peer":
@@ -143,7 +149,7 @@ def test_two_row_shards_on_one_gpu(oracle, case, engine):
     np.testing.assert_allclose(yp, one["y_pred"], rtol=0, atol=1e-9)
     assert a["rows"] == (0, 3000) and b["rows"] == (3000, 6000)
     # ... and the oracle replaying the coloured order
-    X, y = _problem(loss)
+    X, y = _problem(loss, case)
     fm = oracle.OracleFM(degree=degree, loss=loss, n_components=k, solver=solver, regularizer=reg,
                          alpha=0.1, beta=beta, gamma=gamma, tol=0, max_iter=2,
                          feature_order=a["order"])

@@ -45,7 +45,7 @@ NNZ_PER_ROW = 50
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # bumped whenever a hot kernel changes; profiles/<round>_traffic.json records the tag it was
 # collected with, and `traffic` is only reported when the two agree
-ENGINE_TAG = "r02-e3"
+ENGINE_TAG = "r02-e4"
 
 # hyper-parameters: well conditioned and such that P does NOT collapse to
 # zero (with gamma = 1 every coordinate is thresholded away in the first epoch and the scatter
@@ -214,7 +214,9 @@ def main():
         if persistent:
             # one launch = one component pass; per column entry: row 4 + value T + (yhat, y)
             # read 2T + yhat write T + A[i,1..m-1] read and write 2T(m-1)
-            kname, bytes_per_nnz = "pcd_prb_kernel", 4 + 4 * tsz + 2 * tsz * (DEGREE - 1)
+            # (the wide pass -- steps of more than 64 columns, DESIGN 3d -- moves the same bytes)
+            kname = "pcdw_kernel" if eng.get_option("wide_active") else "pcd_prb_kernel"
+            bytes_per_nnz = 4 + 4 * tsz + 2 * tsz * (DEGREE - 1)
         else:
             kname, bytes_per_nnz = "pcd_grad_kernel", 4 + 3 * tsz + tsz * (DEGREE - 1)
     else:

@@ -225,6 +225,7 @@ struct spfm_engine {
     // stream when that differs from the pcd / cd_linear pass's
     bool pb_persistent = true;
     int pbprb_G = 256;
+    int probe_xcd = 0, probe_lds = 60 * 1024;  // diagnostics (spfm_debug_exchange_cost)
     bool pb_stream_ready = false;
     int pb_stream_G = 0, pb_stream_NG = 0;
     DevBuf pb_sp, pb_erow, pb_eval, pb_meta, pb_slabA, pb_slabB, pb_slabC, pb_stamps;
@@ -1292,21 +1293,24 @@ struct spfm_engine {
         double* Po = P.as<double>() + (size_t)order_idx * k * d;
         Ctl* c = ctl.as<Ctl>();
         double* cb = cache.as<double>();
-        // row block resident in LDS (8 bytes per row) when the variant exists and fits
-        // (squared loss: A + residual, 8 bytes per row; +-1 targets: A + yhat + sign, 9 bytes)
-        constexpr bool can_lr = std::is_same<T, float>::value && Kind<M>::AS == 1;
+        // row block resident in LDS when the variant exists and fits (squared loss: A[i,1..AS] +
+        // residual, 8 / 12 bytes per row; +-1 targets: A + yhat + sign, 9 / 13 bytes)
+        constexpr bool can_lr = std::is_same<T, float>::value && Kind<M>::AS <= 2;
         constexpr int LRV = (LOSS == LOSS_SQUARED) ? 1 : 2;
         // the in-kernel phase timers exist as a separate instantiation of ONE configuration
         // (float, degree 2, squared loss, rows in LDS): tools/prb_stamp_probe.py
         constexpr bool can_stamp = std::is_same<T, float>::value && M == 2 && LOSS == LOSS_SQUARED;
-        if (prb_stamp_on && !(can_stamp && prb_lds))
+        // ... and of (float, degree 3, squared loss, rows in global memory)
+        constexpr bool can_stamp3 = std::is_same<T, float>::value && M == 3 && LOSS == LOSS_SQUARED;
+        if (prb_stamp_on && !((can_stamp && prb_lds) || (can_stamp3 && !prb_lds)))
             FAIL(SPFM_ERR_UNSUPPORTED,
-                 "prb_stamps: built for float storage, degree 2, squared loss, prb_lds=1 only");
+                 "prb_stamps: built for float storage, squared loss and degree 2 with prb_lds=1 "
+                 "or degree 3 with prb_lds=0 only");
         const PrbArgs pa = prb_args();
         int lds_max = 0;
         HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
         const size_t lds_lr = sizeof(double) * kPrbLdsFixed +
-                              (size_t)pa.rows_per * (LRV == 1 ? 8 : 9) + 16;
+                              (size_t)pa.rows_per * (4 * Kind<M>::AS + (LRV == 1 ? 4 : 5)) + 16;
         const bool use_lr = can_lr && prb_lds && lds_lr <= (size_t)lds_max &&
                             (LRV == 1 || y_pm1);
         const size_t lds_bytes = use_lr ? std::max(lds_lr, kPrbLds) : kPrbLds;
@@ -1374,6 +1378,12 @@ struct spfm_engine {
                         lrc = go(integral_constant<int, LRV>{}, std::false_type{},
                                  integral_constant<int, -1>{});
                 }
+            }
+        }
+        if constexpr (can_stamp3) {
+            if (!launched && prb_stamp_on) {
+                launched = true;
+                lrc = go(integral_constant<int, 0>{}, std::true_type{}, integral_constant<int, -1>{});
             }
         }
         if (!launched)
@@ -2737,6 +2747,10 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->wide_ready = false;
     } else if (k == "pbcd_persistent") {
         h->pb_persistent = value != 0;
+    } else if (k == "probe_xcd") {
+        h->probe_xcd = (int)value;
+    } else if (k == "probe_lds") {
+        h->probe_lds = (int)value;
     } else if (k == "pbprb_dbg") {
         h->pb_dbg = value;
     } else if (k == "pbprb_stamps") {
@@ -2894,8 +2908,11 @@ int spfm_debug_exchange_cost(spfm_handle h, int groups, int ncols, int readers_m
         (void)hipMemsetAsync(slab.p, 0, bytes, h->stream);
         (void)hipMemsetAsync(abortw.p, 0, 16, h->stream);
         (void)hipEventRecord(e0, h->stream);
-        hipLaunchKernelGGL(exchange_probe_kernel, dim3(groups), dim3(readers_mod == -12 ? 768 : 512),
-                           h->kPrbLds, h->stream, a, rounds, ncols, readers_mod);
+        // probe_xcd = x+1: single-XCD variant on XCD x (8x oversized grid, see the kernel)
+        hipLaunchKernelGGL(exchange_probe_kernel, dim3(h->probe_xcd ? 8 * groups + 64 : groups),
+                           dim3(readers_mod == -12 ? 768 : 512),
+                           h->probe_xcd ? (size_t)h->probe_lds : (size_t)h->kPrbLds, h->stream, a,
+                           rounds, ncols, readers_mod, h->probe_xcd);
         (void)hipEventRecord(e1, h->stream);
         if (hipStreamSynchronize(h->stream) != hipSuccess) {
             h->err = "exchange_probe_kernel failed";

@@ -338,7 +338,8 @@ template <int M>
 __device__ __forceinline__ double pcd_chain_lanes(int reg, int lane, int last, bool valid,
                                                   double p_old, double g, double h, double lam,
                                                   double mu, double beta, double gamma,
-                                                  double eta, double (&cache)[M + 1]) {
+                                                  double eta, double (&cache)[M + 1],
+                                                  double* sc /* LDS [68][4]; used for M > 2 */) {
     double pin = 0.0, st = 0.0;
     if (valid) {
         double inv = h * mu;
@@ -441,23 +442,93 @@ __device__ __forceinline__ double pcd_chain_lanes(int reg, int lane, int last, b
             cache[1] = readlane_d(al, last) * c0 + readlane_d(be, last);
             return sg * r;
         }
-        if constexpr (M > 2)
-        for (int i = 0; i <= last; ++i) {
-            const double ai = readlane_d(ab, i), si = readlane_d(st, i), pi = readlane_d(apin, i);
-            double dc[M + 2];
-            dc[1] = 1.0;
-#pragma unroll
-            for (int deg = 2; deg <= M; ++deg) {
-                double v = cache[deg - 1];
-                v -= dc[deg - 1] * ai;
-                if (v < 0) count_branch(BR_OMEGATI_CLIP, lane);
-                dc[deg] = (v < 0) ? 0.0 : v;
+        if constexpr (M > 2) {
+            // Serial over the columns (the map of a nonzero column is not affine in the cache).
+            // A lone wave issues one instruction every four cycles (eight for an f64 operation),
+            // so this loop -- the critical path of every step of a degree >= 3 pass, 3.6 us of a
+            // 7.6 us step at 37 columns when written with v_readlane broadcasts, a clip and a
+            // conditional move per column -- is bound by its instruction COUNT.  Hence:
+            //  * the per-column operands (|p_old|, strength, |p_in|) go to LDS once and come back
+            //    as broadcast reads (2 LDS instructions instead of 6 v_readlane);
+            //  * the loop runs in lane 0 alone, which makes "store this column's result" one LDS
+            //    write instead of a compare and two conditional moves;
+            //  * the clips of omegati.py:97-98 only ever fire through rounding (the cache values
+            //    are elementary symmetric sums of |p| with one term removed: >= 0 in exact
+            //    arithmetic), so the first attempt leaves them out -- v used as it is, the sign
+            //    bits OR-ed into one word -- and a step that saw a negative v (or a -0.0) is redone
+            //    with the clips in place.  Where no clip fires both forms compute the same bits.
+            //  * columns go in blocks of four, the next block's operands fetched while the current
+            //    one is computed; lanes behind `last` hold (0, 0, 0), for which a column is an
+            //    exact no-op, so there is no tail loop (sc has one block of slack: [68][4]).
+            {
+                const bool in = lane <= last;
+                double* my = sc + lane * 4;
+                my[0] = in ? ab : 0.0;
+                my[1] = in ? st : 0.0;
+                my[2] = in ? apin : 0.0;
             }
-            const double m = pi - si * dc[M];
-            const double r = (m > 0) ? m : 0.0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: its LDS ops are in order
+            double c[M + 1];
 #pragma unroll
-            for (int deg = 1; deg < M; ++deg) cache[deg] = dc[deg + 1] + dc[deg] * r;
-            if (lane == i) mine = r;
+            for (int t = 0; t <= M; ++t) c[t] = cache[t];
+            unsigned neg = 0u;
+            const int nblk = (last + 4) >> 2;
+            auto sweep = [&](auto clip_tag) __attribute__((always_inline)) {
+                constexpr bool CLIP = decltype(clip_tag)::value;
+                double na[4], ns[4], np[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    na[u] = sc[u * 4];
+                    ns[u] = sc[u * 4 + 1];
+                    np[u] = sc[u * 4 + 2];
+                }
+                for (int blk = 0; blk < nblk; ++blk) {
+                    double ca[4], cs[4], cp[4];
+                    double* nx = sc + (blk + 1) * 16;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        ca[u] = na[u];
+                        cs[u] = ns[u];
+                        cp[u] = np[u];
+                        na[u] = nx[u * 4];
+                        ns[u] = nx[u * 4 + 1];
+                        np[u] = nx[u * 4 + 2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double ai = ca[u], si = cs[u], pi = cp[u];
+                        double dc[M + 2];
+                        dc[1] = 1.0;
+#pragma unroll
+                        for (int deg = 2; deg <= M; ++deg) {
+                            double v = c[deg - 1];
+                            v -= dc[deg - 1] * ai;
+                            if constexpr (CLIP) {
+                                dc[deg] = (v < 0) ? 0.0 : v;
+                            } else {
+                                neg |= (unsigned)__double2hiint(v);
+                                dc[deg] = v;
+                            }
+                        }
+                        const double m = pi - si * dc[M];
+                        const double r = (m > 0) ? m : 0.0;
+#pragma unroll
+                        for (int deg = 1; deg < M; ++deg) c[deg] = dc[deg + 1] + dc[deg] * r;
+                        sc[(blk * 4 + u) * 4 + 3] = r;
+                    }
+                }
+            };
+            if (lane == 0) sweep(std::false_type{});
+            if (__builtin_amdgcn_readfirstlane((int)neg) < 0) {
+                count_branch(BR_OMEGATI_CLIP, lane);
+#pragma unroll
+                for (int t = 0; t <= M; ++t) c[t] = cache[t];
+                if (lane == 0) sweep(std::true_type{});
+            }
+#pragma unroll
+            for (int t = 1; t < M; ++t) cache[t] = readlane_d(c[t], 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mine = (lane <= last) ? sc[lane * 4 + 3] : 0.0;
         }
         return sg * mine;
     }
@@ -473,6 +544,7 @@ __global__ __launch_bounds__(kWave) void pcd_chain_kernel(
     const double* __restrict__ pold, int reg, const double* __restrict__ cache_in,
     double* __restrict__ cache_out, double mu, double beta, double gamma, double eta,
     double* __restrict__ delta, double* __restrict__ viol_col) {
+    __shared__ double sh_chain[(kWave + 4) * 4];
     const int lane = threadIdx.x;
     const double lam = ctl->lam;
     double* ps = P + (size_t)ctl->s * d;
@@ -493,7 +565,7 @@ __global__ __launch_bounds__(kWave) void pcd_chain_kernel(
         }
         const double res =
             pcd_chain_lanes<M>(reg, lane, cnt - 1, valid, p_old, g, h, lam, mu, beta, gamma, eta,
-                               cache);
+                               cache, sh_chain);
         if (valid) {
             const double dl = p_old - res;
             ps[j] = res;
@@ -540,14 +612,14 @@ __device__ __forceinline__ void pcd_sync_entry(size_t i, double x, double p_old,
     yy[2 * i] = (T)(yh - lam * upd * dprev);
 }
 
-// the same update on a row block held in LDS as (A[i], r_i = yhat_i - y_i); one cache
-// value per row (M == 2 or all-subsets)
+// the same update on a row block held in LDS as (A[i, 1..AS], r_i = yhat_i - y_i)
 template <typename T, int M>
 __device__ __forceinline__ void pcd_sync_entry_lds(int il, double x, double p_old, double upd,
                                                    double lam, T* lds_a, T* lds_r) {
-    const double a0 = (double)lds_a[il];
+    constexpr int AS = Kind<M>::AS;
     double yh = (double)lds_r[il];
     if constexpr (M == 0) {
+        const double a0 = (double)lds_a[il];
         yh -= lam * a0;
         double a1 = a0 / (1.0 + x * p_old);
         a1 *= 1.0 + x * (p_old - upd);
@@ -555,8 +627,15 @@ __device__ __forceinline__ void pcd_sync_entry_lds(int il, double x, double p_ol
         lds_a[il] = (T)a1;
         lds_r[il] = (T)yh;
     } else {
-        lds_a[il] = (T)(a0 - upd * x);
-        lds_r[il] = (T)(yh - lam * upd * (x * (a0 - p_old * x)));
+        double dprev = x;
+#pragma unroll
+        for (int t = 0; t < AS; ++t) {
+            const double a = (double)lds_a[il * AS + t];
+            const double dcur = x * (a - p_old * dprev);
+            lds_a[il * AS + t] = (T)(a - upd * dprev);
+            dprev = dcur;
+        }
+        lds_r[il] = (T)(yh - lam * upd * dprev);
     }
 }
 
@@ -592,6 +671,7 @@ __global__ __launch_bounds__(kBlock) void pcd_chain_sync_kernel(
     const int32_t* __restrict__ cidx, const T* __restrict__ cval, T* __restrict__ A_all,
     size_t a_stride, T* __restrict__ yy, double* __restrict__ viol_col) {
     __shared__ double sh[2];
+    __shared__ double sh_chain[(kWave + 4) * 4];
     T* __restrict__ A = A_all + (size_t)ctl->s * a_stride;
     constexpr int PF = 2;  // entries per thread fetched before the chain result is known
     const int q = blockIdx.x;
@@ -620,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void pcd_chain_sync_kernel(
 #pragma unroll
         for (int t = 0; t <= M; ++t) cache[t] = cache_in[t];
         const double res = pcd_chain_lanes<M>(reg, lane, q, valid, p_old, g, h, lam, mu, beta,
-                                              gamma, eta, cache);
+                                              gamma, eta, cache, sh_chain);
         if (lane == q) {
             const double dl = p_old - res;
             P[(size_t)ctl->s * d + cd.j] = res;

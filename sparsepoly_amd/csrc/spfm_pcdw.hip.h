@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
                     const double t1 = valid ? sh_tot[(size_t)qq * 2 + 1] : 0.0;
                     const double res = pcd_chain_lanes<2>(pp.reg, wlane, last, valid, pl, t0, t1,
                                                           lam, pp.mu, pp.beta, pp.gamma, pp.eta,
-                                                          cache);
+                                                          cache, nullptr);
                     if (valid) sh_delta[qq] = pl - res;
                 }
             }

@@ -88,6 +88,13 @@ __device__ __forceinline__ unsigned long long prb_load_granule(const double* p) 
                              __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// plain store: the line stays in the storing XCD's L2 (same-XCD readers hit it there)
+__device__ __forceinline__ void prb_store_granule_l2(double* p, double v, unsigned long long tag) {
+    const unsigned long long u =
+        ((unsigned long long)__double_as_longlong(v) & ~3ull) | tag;
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(u) : "memory");
+}
+
 // system-scope forms of the tagged granule (cross-GPU exchange)
 __device__ __forceinline__ void prb_store_granule_sys(double* p, double v, unsigned long long tag) {
     const unsigned long long u =
@@ -314,9 +321,10 @@ constexpr int kPrbThreads = 512;
 constexpr int kPrbParts = 8;  // waves that sweep = parts of the workgroup range
 constexpr int kPrbLdsFixed = 2560;  // doubles of fixed LDS (control data, part sums, long slots)
 
-// LR != 0: row state resident in LDS (float storage, one cache value per row: M == 2 or
-// the all-subsets model).  The workgroup keeps A[i] and a 4-byte prediction word of its
-// rows in LDS for the whole pass (8-9 bytes per row; 125 KB at 15 625 rows), so the
+// LR != 0: row state resident in LDS (float storage; one cache value per row: M == 2 or
+// the all-subsets model, or two: M == 3).  The workgroup keeps A[i, 1..AS] and a 4-byte
+// prediction word of its rows in LDS for the whole pass (8-9 bytes per row, 125 KB at
+// 15 625 rows; 12-13 bytes for M == 3, which needs more, smaller row blocks), so the
 // per-step gather and scatter are LDS accesses instead of L2 round trips and the
 // end-of-step barrier no longer waits for store acknowledgements.
 //   LR == 1 (squared loss): the word is the residual r_i = yhat_i - y_i; dloss is the
@@ -340,6 +348,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // sized to pin 1 WG / CU
     double* sh_delta = dyn_lds + 128;  // [64]
     double* sh_pold = dyn_lds + 192;   // [64]
+    double* sh_chain = dyn_lds + 256;  // [68][4] operands / results of the serial prox loop
     double* sh_quart = dyn_lds + 1536;  // [8][64][2] part sums over workgroups
     int* sh_ok = reinterpret_cast<int*>(dyn_lds + 768);
     int* sh_go = reinterpret_cast<int*>(dyn_lds + 770);  // last step this workgroup published
@@ -359,18 +368,20 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     for (int t = 0; t <= M; ++t) cache[t] = cache_in[t];
 
     double* sh_long = dyn_lds + 1024;  // [64][4][2] wave partials of long slots
-    static_assert(LR == 0 || (Kind<M>::AS == 1 && sizeof(T) == 4 &&
+    static_assert(LR == 0 || (Kind<M>::AS <= 2 && sizeof(T) == 4 &&
                               (LR == 2 || LOSS == LOSS_SQUARED)),
-                  "LDS-resident rows: float storage, one cache value per row");
+                  "LDS-resident rows: float storage, one or two cache values per row");
+    constexpr int AS = Kind<M>::AS;
     const int row0 = LR ? g * a.rows_per : 0;
-    T* lds_a = reinterpret_cast<T*>(dyn_lds + kPrbLdsFixed);  // [rows_per] A[i]
-    T* lds_r = lds_a + a.rows_per;                             // [rows_per] residual or yhat
+    T* lds_a = reinterpret_cast<T*>(dyn_lds + kPrbLdsFixed);  // [rows_per][AS] A[i, 1..AS]
+    T* lds_r = lds_a + (size_t)a.rows_per * AS;                // [rows_per] residual or yhat
     unsigned char* lds_s = reinterpret_cast<unsigned char*>(lds_r + a.rows_per);  // y > 0
     if constexpr (LR != 0) {
         const int nr = min(a.rows_per, a.n_rows - row0);
         for (int il = tid; il < nr; il += kPrbThreads) {
             const typename Vec2<T>::type yv = yy2[(size_t)(row0 + il)];
-            lds_a[il] = A[(size_t)(row0 + il)];
+#pragma unroll
+            for (int t = 0; t < AS; ++t) lds_a[il * AS + t] = A[(size_t)(row0 + il) * AS + t];
             if constexpr (LR == 1) {
                 lds_r[il] = (T)((double)yv.x - (double)yv.y);
             } else {
@@ -429,7 +440,6 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         __builtin_amdgcn_s_waitcnt(0x0F70);
         // ---- phase 1 (workers): gather the rows of the prefetched entries, partial sums
         // (pcd.py:52-59); A / yhat values stay in registers for phase 3
-        constexpr int AS = Kind<M>::AS;
         double av[PRB_PF][AS];
         double yh[PRB_PF], yt[PRB_PF], dlast[PRB_PF];
         double pl = 0.0;
@@ -446,7 +456,8 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                     const int il = cur.row[u] - row0;
                     yh[u] = (double)lds_r[il];
                     yt[u] = (LR == 1) ? 0.0 : (lds_s[il] ? 1.0 : -1.0);
-                    av[u][0] = (double)lds_a[il];
+#pragma unroll
+                    for (int t = 0; t < AS; ++t) av[u][t] = (double)lds_a[il * AS + t];
                 } else {
                     const size_t i = (size_t)cur.row[u];
                     const typename Vec2<T>::type yv = yy2[i];
@@ -473,7 +484,8 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 if constexpr (LR != 0) {
                     y0 = (double)lds_r[i - row0];
                     y1 = (LR == 1) ? 0.0 : (lds_s[i - row0] ? 1.0 : -1.0);
-                    a1[0] = (double)lds_a[i - row0];
+#pragma unroll
+                    for (int t = 0; t < AS; ++t) a1[t] = (double)lds_a[(i - row0) * AS + t];
                 } else {
                     const typename Vec2<T>::type yv = yy2[i];
                     y0 = (double)yv.x;
@@ -522,7 +534,9 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                         if constexpr (LR != 0) {
                             y0 = (double)lds_r[i - row0];
                             y1 = (LR == 1) ? 0.0 : (lds_s[i - row0] ? 1.0 : -1.0);
-                            a1[0] = (double)lds_a[i - row0];
+#pragma unroll
+                            for (int t = 0; t < Kind<M>::AS; ++t)
+                                a1[t] = (double)lds_a[(i - row0) * Kind<M>::AS + t];
                         } else {
                             const typename Vec2<T>::type yv = yy2[i];
                             y0 = (double)yv.x;
@@ -621,7 +635,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             const bool valid = lane < ncols;
             const double res = pcd_chain_lanes<M>(REGC >= 0 ? REGC : reg, lane, ncols - 1, valid, pl,
                                                   tot[0], tot[1],
-                                                  lam, mu, beta, gamma, eta, cache);
+                                                  lam, mu, beta, gamma, eta, cache, sh_chain);
             const double dl = valid ? (pl - res) : 0.0;
             sh_delta[lane] = dl;
             sh_pold[lane] = pl;
@@ -656,9 +670,17 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                                 A[i] = (T)an;
                                 yy[2 * i] = (T)yn;
                             }
-                        } else if constexpr (LR != 0) {  // M == 2
-                            lds_a[i - row0] = (T)(av[u][0] - upd * x);
-                            lds_r[i - row0] = (T)(yh[u] - lam * upd * dlast[u]);
+                        } else if constexpr (LR != 0) {
+                            const int il = (int)i - row0;
+                            double dprev = x;
+#pragma unroll
+                            for (int t = 0; t < AS; ++t) {
+                                const double a1 = av[u][t];
+                                const double dcur = x * (a1 - p_old * dprev);
+                                lds_a[il * AS + t] = (T)(a1 - upd * dprev);
+                                dprev = dcur;
+                            }
+                            lds_r[il] = (T)(yh[u] - lam * upd * dlast[u]);
                         } else {
                             double dprev = x;
 #pragma unroll
@@ -728,7 +750,8 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         const int nr = min(a.rows_per, a.n_rows - row0);
         for (int il = tid; il < nr; il += kPrbThreads) {
             const size_t i = (size_t)(row0 + il);
-            A[i] = lds_a[il];
+#pragma unroll
+            for (int t = 0; t < AS; ++t) A[i * AS + t] = lds_a[il * AS + t];
             if constexpr (LR == 1)
                 yy[2 * i] = (T)((double)lds_r[il] + (double)yy[2 * i + 1]);
             else
@@ -1063,12 +1086,30 @@ __device__ __forceinline__ bool prb_poll(const PrbArgs& a, const double* p,
 // readers_mod = -8: eight waves sweep an eighth each, control wave and helpers gated on the
 // publish flag (the engine since v6); readers_mod = -12: twelve waves, the eight sweepers
 // all store-free.
+// xcd_mode = 1: the grid is 8x oversized, only workgroups that landed on XCD `xcd_pick` stay and
+// number themselves through a counter (abort_flag[1]); their publishes are PLAIN stores (the
+// line stays in that XCD's L2, MI355X_MICROARCH.md store table) and the sc1 loads of the
+// sweep are served by that L2.
 __global__ __launch_bounds__(768) void exchange_probe_kernel(PrbArgs a, int rounds,
-                                                                     int ncols, int readers_mod) {
+                                                                     int ncols, int readers_mod,
+                                                                     int xcd_mode) {
     __shared__ double quart[8 * 64 * 2];
     __shared__ int ok_flag;
     __shared__ int go_flag;
-    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int my_rank;
+    int g = blockIdx.x;
+    if (xcd_mode) {
+        if (threadIdx.x == 0) {
+            const int xcc = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+            int r = -1;
+            if (xcc == xcd_mode - 1) r = (int)atomicAdd(a.abort_flag + 1, 1u);
+            my_rank = (r >= 0 && r < a.G) ? r : -1;
+        }
+        __syncthreads();
+        g = my_rank;
+        if (g < 0) return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool control = wave == 0;
     const int wt = tid - 64, slot = (wave >= 1 && wave <= 4) ? (wt >> 2) : 64, sub = wt & 3;
     const bool eight = readers_mod < 0;  // 8 sweeping waves, one round each
@@ -1087,8 +1128,13 @@ __global__ __launch_bounds__(768) void exchange_probe_kernel(PrbArgs a, int roun
                 if (sub == 0) {
                     double* sl =
                         a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + slot) * 2;
-                    prb_store_granule(sl, 1.0 + b, tag);
-                    prb_store_granule(sl + 1, 2.0 + g, tag);
+                    if (xcd_mode) {
+                        prb_store_granule_l2(sl, 1.0 + b, tag);
+                        prb_store_granule_l2(sl + 1, 2.0 + g, tag);
+                    } else {
+                        prb_store_granule(sl, 1.0 + b, tag);
+                        prb_store_granule(sl + 1, 2.0 + g, tag);
+                    }
                 }
                 if (tid == 64 + 255)
                     __hip_atomic_store(&go_flag, b + 1, __ATOMIC_RELAXED,

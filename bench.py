@@ -92,6 +92,11 @@ def main():
                          "that ends in BASELINE configs[4] = 10M x 1M on 8 GPUs); strong = the "
                          "same 1M x 100k matrix sharded over the ranks")
     args = ap.parse_args()
+    # stdout carries ONE JSON line and nothing else: libraries that write to file descriptor 1
+    # (gloo announces its connections there) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     cfg = CONFIGS[args.config]
     K, DEGREE = cfg["k"], cfg["degree"]
 
@@ -181,8 +186,46 @@ def main():
             torch.cuda.synchronize()
 
     viols = []
-    for _ in range(args.warmup):
-        viols.append(iteration(eng))
+
+    def warm_up(eng):
+        """The untimed steps; with several ranks all of them learn whether any rank failed."""
+        ok, why = 1, ""
+        try:
+            for _ in range(args.warmup):
+                viols.append(iteration(eng))
+            torch.cuda.synchronize()
+        except RuntimeError as exc:
+            if dist is None:
+                raise
+            ok, why = 0, str(exc)
+        if dist is not None:
+            t = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0 and ok == 1:
+                why = "another rank failed"
+            ok = int(t.item())
+        return ok, why
+
+    ok, why = warm_up(eng)
+    if not ok:
+        # the in-kernel peer exchange did not come up on this node (the warm-up aborted on some
+        # rank): every rank rebuilds its engine with the per-step collective instead and the
+        # line says so
+        if os.environ.get("SPFM_PEER", "1") == "0":
+            raise RuntimeError("warm-up failed: " + why)
+        log("rank %d: warm-up failed with the in-kernel peer exchange (%s); falling back to the "
+            "per-step collective" % (rank, why))
+        try:
+            eng.close()
+        except Exception:
+            pass
+        os.environ["SPFM_PEER"] = "0"
+        del viols[:]
+        eng, order, t_sched = make_engine(args.precision, args.schedule)
+        n_batches = eng.n_batches
+        ok, why = warm_up(eng)
+        if not ok:
+            raise RuntimeError("warm-up failed: " + why)
     fence()
     t_start = time.perf_counter()
     for _ in range(args.steps):
@@ -374,7 +417,7 @@ def main():
             "engine_tag": ENGINE_TAG,
         }
         out.update(extras)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -2747,6 +2747,18 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->wide_ready = false;
     } else if (k == "pbcd_persistent") {
         h->pb_persistent = value != 0;
+    } else if (k == "peer_exchange") {
+        // 0: give the in-kernel cross-GPU exchange up (a rank could not map its peers): the
+        // passes fall back to the per-step collective.  (1 is set by spfm_peer_connect only.)
+        if (value != 0) {
+            h->err = "peer_exchange: only 0 can be set; connect with spfm_peer_connect";
+            return SPFM_ERR_INVALID;
+        }
+        h->peer_ready = false;
+        h->have_schedule = false;
+        h->prb_ready = false;
+        h->pb_stream_ready = false;
+        h->wide_ready = false;
     } else if (k == "probe_xcd") {
         h->probe_xcd = (int)value;
     } else if (k == "probe_lds") {

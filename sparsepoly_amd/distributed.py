@@ -83,9 +83,24 @@ def connect_peers(engine):
     rank, world = rank_world()
     if world < 2 or world > 8:
         return False
-    mine = engine.peer_alloc()
+    try:
+        mine = engine.peer_alloc()
+    except RuntimeError:
+        mine = None
     box = [None] * world
     d.all_gather_object(box, mine)
-    engine.peer_connect(world, rank, box)
-    d.barrier()
+    ok = all(h is not None for h in box)
+    if ok:
+        try:
+            engine.peer_connect(world, rank, box)
+        except RuntimeError:
+            ok = False
+    # all ranks use the peer exchange or none does (a rank that cannot map its peers' slabs --
+    # no IPC / no peer access between two devices -- takes everybody to the collective)
+    flags = [None] * world
+    d.all_gather_object(flags, bool(ok))
+    if not all(flags):
+        if ok:
+            engine.set_option("peer_exchange", 0)
+        return False
     return True

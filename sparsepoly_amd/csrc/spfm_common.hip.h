@@ -55,6 +55,19 @@ __device__ __forceinline__ void count_branch(int which, int lane) {
 
 // ------------------------------------------------------------------ helpers
 
+// 1/d to about one ulp: v_rcp_f64 and two Newton steps -- the core of the compiler's IEEE
+// division without its operand scaling and final fix-up (11-13 instructions per quotient).
+// Used where a lone wave's instruction count is the critical path of a dependent step and two
+// quotients share a denominator (the step-size block of the chains): n * recip_nr(d) differs
+// from n / d by at most ~1.5 ulp; d must be a normal number of moderate exponent (here
+// mu*h + beta and 1 + 2*strength).
+__device__ __forceinline__ double recip_nr(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
+}
+
 // loss.py:23-24, :44-51, :67-71
 __device__ __forceinline__ double dloss_dev(int loss, double p, double y) {
     if (loss == LOSS_SQUARED) return p - y;

@@ -346,9 +346,10 @@ __device__ __forceinline__ double pcd_chain_lanes(int reg, int lane, int last, b
         inv += beta;
         double upd = g * lam;
         upd += beta * p_old;
-        upd /= inv;
+        const double rinv = recip_nr(inv);  // one reciprocal for both quotients (see recip_nr)
+        upd *= rinv;
         pin = p_old - eta * upd;
-        st = eta * gamma / inv;
+        st = (eta * gamma) * rinv;
     }
     if (reg == REG_L1) {
         const double sg = (pin > 0) ? 1.0 : ((pin < 0) ? -1.0 : 0.0);
@@ -359,9 +360,10 @@ __device__ __forceinline__ double pcd_chain_lanes(int reg, int lane, int last, b
     double mine = 0.0;
     if (reg == REG_SQL12) {
         const double den = 1 + 2 * st;
-        const double pp = pin / den;
+        const double rden = recip_nr(den);
+        const double pp = pin * rden;
         const double app = fabs(pp);
-        const double tt = 2 * st / den;
+        const double tt = (2 * st) * rden;
         const double sg = (pp > 0) ? 1.0 : -1.0;
         const double c0 = cache[0];
         const bool act = valid && lane <= last;

@@ -473,9 +473,10 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 const double dprev = grad_factor<M>(av[u], (double)cur.x[u], p_slot);
                 dlast[u] = dprev;
                 const double dl = dloss_dev(LOSS, yh[u], yt[u]);
-                const bool v = cur.e0 + sub + 4 * u < cur.e1;
-                ag += v ? dl * dprev : 0.0;
-                ah += v ? dprev * dprev : 0.0;
+                // no validity mask: a padding entry has x = 0 (prb_load_entries), so its dprev
+                // and both products are exact zeros
+                ag += dl * dprev;
+                ah += dprev * dprev;
             }
             for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {  // rare: long slot
                 const int i = a.erow[e];
@@ -497,10 +498,13 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 ag += dloss_dev(LOSS, y0, y1) * dprev;
                 ah += dprev * dprev;
             }
-            ag += __shfl_xor(ag, 1, kWave);
-            ah += __shfl_xor(ah, 1, kWave);
-            ag += __shfl_xor(ag, 2, kWave);
-            ah += __shfl_xor(ah, 2, kWave);
+            // the slot's 4 lanes are one DPP quad: quad_perm moves (a VALU operand modifier)
+            // instead of ds_bpermute shuffles (two LDS-crossbar round trips on the step's
+            // critical path); same pairing, same sums
+            ag += dpp_move_d<0xB1, 0xf>(0.0, ag);  // quad_perm:[1,0,3,2]
+            ah += dpp_move_d<0xB1, 0xf>(0.0, ah);
+            ag += dpp_move_d<0x4E, 0xf>(0.0, ag);  // quad_perm:[2,3,0,1]
+            ah += dpp_move_d<0x4E, 0xf>(0.0, ah);
             PRB_WSTAMP(0)  // gather + partial sums
             // publish this row block's partial sums of the slot (tagged granules).  Slots
             // beyond the batch are published too (as zeros): every word of a slab is then
@@ -889,16 +893,15 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
             double ag = 0.0;
 #pragma unroll
             for (int u = 0; u < PRB_PF; ++u) {
-                const bool v = cur.e0 + sub + 4 * u < cur.e1;
-                ag += v ? dloss_dev(LOSS, yh[u], yt[u]) * (double)cur.x[u] : 0.0;
+                ag += dloss_dev(LOSS, yh[u], yt[u]) * (double)cur.x[u];  // padding: x = 0
             }
             for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {
                 double y0, y1;
                 row_state(a.erow[e], y0, y1);
                 ag += dloss_dev(LOSS, y0, y1) * (double)eval[e];
             }
-            ag += __shfl_xor(ag, 1, kWave);
-            ag += __shfl_xor(ag, 2, kWave);
+            ag += dpp_move_d<0xB1, 0xf>(0.0, ag);  // quad_perm:[1,0,3,2] (see pcd_prb_kernel)
+            ag += dpp_move_d<0x4E, 0xf>(0.0, ag);  // quad_perm:[2,3,0,1]
             if (sub == 0 && !((lm0 >> slot) & 1ull)) {
                 double* sl = a.slab + (size_t)(b & 1) * a.G * 64 * 2 + ((size_t)g * 64 + slot) * 2;
                 prb_store_granule(sl, ag, prb_tag(b));

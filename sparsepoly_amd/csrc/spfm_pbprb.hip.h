@@ -111,8 +111,19 @@ __device__ __forceinline__ double pb_swz_xor(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// v(lane) + v(lane ^ 16) in every lane: gfx950's v_permlane16_swap exchanges the odd rows (of
+// 16 lanes) of one register with the even rows of another -- fed two copies of v it leaves
+// (row0,row0,row2,row2) and (row1,row1,row3,row3), whose sum is the pair sum in all four rows.
+// Two VALU instructions per dword instead of a ds_swizzle trip through the LDS pipe.
+__device__ __forceinline__ double pb_pairsum16(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+}
+
 // Sum over the L lanes of a group, result in every lane: quad_perm / row_ror moves inside the
-// rows of 16 lanes (DPP: one issue slot each, no LDS crossbar round trip), one swizzle across
+// rows of 16 lanes (DPP: one issue slot each, no LDS crossbar round trip), a row swap across
 // the two rows of a 32-lane half, one cross-half shuffle for L = 64.  Fixed order.
 template <int L>
 __device__ __forceinline__ double pb_group_allsum(double v) {
@@ -120,7 +131,7 @@ __device__ __forceinline__ double pb_group_allsum(double v) {
     v += dpp_move_d<0x4E, 0xf>(0.0, v);   // quad_perm [2,3,0,1]
     v += dpp_move_d<0x124, 0xf>(0.0, v);  // row_ror:4
     v += dpp_move_d<0x128, 0xf>(0.0, v);  // row_ror:8
-    v += pb_swz_xor<16>(v);
+    v = pb_pairsum16(v);
     if constexpr (L == 64) v += __shfl_xor(v, 32, kWave);
     return v;
 }
@@ -148,7 +159,12 @@ __device__ __forceinline__ void pb_mr_stage(double* v, int lane) {
         for (int i = 0; i < N / 2; ++i) {
             const double keep = hi ? v[2 * i + 1] : v[2 * i];
             const double send = hi ? v[2 * i] : v[2 * i + 1];
-            v[i] = keep + pb_swz_xor<MASK>(send);
+            if constexpr (MASK == 1)
+                v[i] = keep + dpp_move_d<0xB1, 0xf>(0.0, send);  // quad_perm [1,0,3,2]
+            else if constexpr (MASK == 2)
+                v[i] = keep + dpp_move_d<0x4E, 0xf>(0.0, send);  // quad_perm [2,3,0,1]
+            else
+                v[i] = keep + pb_swz_xor<MASK>(send);
         }
         pb_mr_stage<N / 2, MASK * 2>(v, lane);
     }
@@ -158,11 +174,11 @@ __device__ __forceinline__ double pb_multi_reduce(double* v, int lane) {
     static_assert(N <= 16 && N >= 1 && (N & (N - 1)) == 0, "N: power of two <= 16");
     pb_mr_stage<N, 1>(v, lane);
     double r = v[0];
-    if constexpr (N <= 1) r += pb_swz_xor<1>(r);
-    if constexpr (N <= 2) r += pb_swz_xor<2>(r);
-    if constexpr (N <= 4) r += pb_swz_xor<4>(r);
-    if constexpr (N <= 8) r += pb_swz_xor<8>(r);
-    r += pb_swz_xor<16>(r);
+    if constexpr (N <= 1) r += dpp_move_d<0xB1, 0xf>(0.0, r);   // lane ^ 1
+    if constexpr (N <= 2) r += dpp_move_d<0x4E, 0xf>(0.0, r);   // lane ^ 2
+    if constexpr (N <= 4) r += dpp_move_d<0x124, 0xf>(0.0, r);  // row_ror:4 (the 4-orbit ...
+    if constexpr (N <= 8) r += dpp_move_d<0x128, 0xf>(0.0, r);  // row_ror:8  ... of lane & 3)
+    r = pb_pairsum16(r);
     if constexpr (L == 64) r += __shfl_xor(r, 32, kWave);
     return r;
 }
@@ -601,7 +617,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                     const int j = a.jsched[c0 + q];
                     pold = kl ? P[(size_t)j * k + lane] : 0.0;
                 }
-                const double hsum = __shfl(tot, L - 2, L);
+                const double hsum = pb_bcast<L>(tot, L - 2, grp);  // grp == 0 here
                 double inv = hsum * mu;
                 inv += beta;
                 const double st0 = eta * gamma / inv;

@@ -473,10 +473,11 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 const double dprev = grad_factor<M>(av[u], (double)cur.x[u], p_slot);
                 dlast[u] = dprev;
                 const double dl = dloss_dev(LOSS, yh[u], yt[u]);
-                // no validity mask: a padding entry has x = 0 (prb_load_entries), so its dprev
-                // and both products are exact zeros
-                ag += dl * dprev;
-                ah += dprev * dprev;
+                // (the mask is needed although a padding entry has x = 0: its row state may be
+                // uninitialised LDS of a workgroup without rows, and NaN * 0 is NaN)
+                const bool v = cur.e0 + sub + 4 * u < cur.e1;
+                ag += v ? dl * dprev : 0.0;
+                ah += v ? dprev * dprev : 0.0;
             }
             for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {  // rare: long slot
                 const int i = a.erow[e];
@@ -893,7 +894,8 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
             double ag = 0.0;
 #pragma unroll
             for (int u = 0; u < PRB_PF; ++u) {
-                ag += dloss_dev(LOSS, yh[u], yt[u]) * (double)cur.x[u];  // padding: x = 0
+                const bool v = cur.e0 + sub + 4 * u < cur.e1;
+                ag += v ? dloss_dev(LOSS, yh[u], yt[u]) * (double)cur.x[u] : 0.0;
             }
             for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {
                 double y0, y1;

@@ -419,6 +419,14 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             tprev = tn;                     \
         }                                   \
     }
+#define PRB_HSTAMP(k)                       \
+    if constexpr (STAMP) {                  \
+        if (tid == 320) {                   \
+            const long long tn = clock64(); \
+            acc[k] += tn - tprev;           \
+            tprev = tn;                     \
+        }                                   \
+    }
 #define PRB_WSTAMP(k)                       \
     if constexpr (STAMP) {                  \
         if (tid == 64) {                    \
@@ -585,6 +593,8 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         if (b + 2 < a.nb) prb_load_sp(a, g, b + 2, slot, c3 - c2, n2e0, n2e1, lm2);
         if (worker) {
             PRB_WSTAMP(1)  // publish issue
+            // (measured: raising the flag earlier -- right behind the granule stores, ~150 cycles
+            // sooner -- costs 3 %: 271 -> 279 ms per epoch on config 2)
             if (tid == 64 + 255)  // last worker wave: this workgroup's partials are on their way
                 __hip_atomic_store(sh_go, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (LR != 0 && b + 1 < a.nb) {
@@ -615,8 +625,10 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                        b + 1 &&
                    ++spins < (1u << 24))
                 __builtin_amdgcn_s_sleep(1);
+            PRB_HSTAMP(1)  // helper wave 5: from the end of the previous step to "go"
             const bool ok = prb_collect_quarter<2>(a, b, part, lane, ncols, sh_quart, kPrbParts);
             if (!ok) *sh_ok = 0;
+            PRB_HSTAMP(2)  // its part of the sweep
         }
         // B3: part sums in LDS.  Raw barrier: only LDS traffic must have landed; the
         // prefetch loads just issued stay in flight across it (a __syncthreads() would
@@ -625,6 +637,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (!*sh_ok) break;
         PRB_STAMP(3)
+        PRB_HSTAMP(7)  // helper: B3
         PRB_WSTAMP(4)  // B3
         if (control) {
             double tot[2];
@@ -746,9 +759,13 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         else
             __syncthreads();
         PRB_STAMP(6)
+        if constexpr (STAMP) {
+            if (tid == 320) tprev = clock64();  // helper: the rest of the step is not its time
+        }
         PRB_WSTAMP(7)  // B5 (stores acknowledged)
     }
 #undef PRB_STAMP
+#undef PRB_HSTAMP
 #undef PRB_WSTAMP
     if constexpr (LR != 0) {  // write the row block back (LR == 1: yhat = r + y)
         __syncthreads();
@@ -765,7 +782,14 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     }
     if (STAMP && a.stamps != nullptr && (tid == 0 || tid == 64)) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a.stamps[(size_t)g * 16 + (tid == 64 ? 8 : 0) + q] = acc[q];
+        for (int q = 0; q < 8; ++q)
+            if (tid == 64 || (q != 1 && q != 2 && q != 7))
+                a.stamps[(size_t)g * 16 + (tid == 64 ? 8 : 0) + q] = acc[q];
+    }
+    if (STAMP && a.stamps != nullptr && tid == 320) {  // helper wave 5 in the control block's gaps
+        a.stamps[(size_t)g * 16 + 1] = acc[1];
+        a.stamps[(size_t)g * 16 + 2] = acc[2];
+        a.stamps[(size_t)g * 16 + 7] = acc[7];
     }
 }
 

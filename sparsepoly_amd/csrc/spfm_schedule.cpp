@@ -133,17 +133,18 @@ void schedule_colored(int64_t n_rows, int32_t d, const int64_t* cptr, const int3
     if (batch_ptr.size() == 1) batch_ptr.push_back(0);
 }
 
-// ---- parallel form of the same greedy colouring (deterministic, speculative) ------------
-// Rounds of 32 columns taken in visiting order.  (1) In parallel, every column of the
-// round picks the lowest colour that is absent from all its rows AS OF THE START OF THE ROUND
-// (a snapshot: assignments of the same round are not seen, so the choice does not depend on
-// thread timing).  (2) One thread walks the round in order and accepts a column unless an
-// already accepted column of the round took the same colour and shares a row with it (merge of
-// the two sorted row lists), or the class is full; refused columns go to the front of the next
-// round.  (3) In parallel, the accepted columns append their colour to their rows' lists
-// (atomic slot counters: the order inside a row's list varies, the SET does not).  The result
-// is a valid greedy colouring, identical for any thread count; it differs from the sequential
-// first fit only where a refused column is coloured one round later (~1 % more colours).
+// ---- parallel form of the same greedy colouring (deterministic: the sequential result) ----
+// Rounds of kRoundMax columns taken in visiting order.  (1) In parallel, every column of the
+// round collects the set of colours present in its rows AS OF THE START OF THE ROUND (a
+// snapshot: assignments of the same round are not seen, so nothing depends on thread timing).
+// (2) One thread walks the round in order and gives each column the lowest colour that is
+// neither in its snapshot set, nor full, nor taken in this round by a column that shares a row
+// with it (merge of the two sorted row lists) -- exactly what the sequential first fit would
+// have chosen.  (3) In parallel, the columns append their colour to their rows' lists (atomic
+// slot counters: the order inside a row's list varies, the SET does not).  Every column is
+// scanned once; the result is identical to schedule_colored's sequential loop for any thread
+// count.  (The first version let a column pick ONE tentative colour in (1) and refused it in
+// (2) when an earlier column of the round had taken it: 2.2 scans per column on config 2.)
 namespace {
 
 class SpinBarrier {
@@ -180,81 +181,103 @@ bool columns_share_row(const int64_t* cptr, const int32_t* cidx, int32_t a, int3
 void schedule_colored_parallel(int64_t n_rows, int32_t d, const int64_t* cptr, const int32_t* cidx,
                                const int32_t* order, int max_batch, int n_threads,
                                std::vector<int32_t>& out_order, std::vector<int32_t>& batch_ptr) {
-    // 32 columns per round: with more, the columns of a round pick the same few colours and
-    // refuse each other (64: 2.5x slower, 256: 5x); a constant, so the result is the same for
-    // any thread count
-    constexpr int kRoundMax = 32;
+    // columns per round: more columns mean fewer barriers but more in-round checks by the one
+    // resolving thread (measured on 400k x 40k, 7 scanning threads: 32 -> 0.63 s, 64 -> 0.73 s,
+    // 128 -> 1.0 s, 21 -> 0.55 s: three columns per scanning thread).  The result does not depend
+    // on it.
+    int kRoundMax = std::max(8, std::min(64, 3 * std::max(1, n_threads - 1)));
+    if (const char* e = std::getenv("SPFM_SCHED_ROUND")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 1024) kRoundMax = v;
+    }
     const int64_t nnz = cptr[d];
-    std::vector<int64_t> rstart((size_t)n_rows + 1, 0);
-    for (int64_t ii = 0; ii < nnz; ++ii) rstart[(size_t)cidx[ii] + 1]++;
-    for (int64_t i = 0; i < n_rows; ++i) rstart[(size_t)i + 1] += rstart[(size_t)i];
+    // one 16-byte descriptor per row (start of its colour list, entries so far): one cache miss
+    // per visited row instead of two
+    struct RowList {
+        int64_t start;
+        std::atomic<int32_t> cnt;
+        int32_t pad;
+    };
+    std::vector<RowList> rows((size_t)n_rows + 1);
+    {
+        std::vector<int64_t> rstart((size_t)n_rows + 1, 0);
+        for (int64_t ii = 0; ii < nnz; ++ii) rstart[(size_t)cidx[ii] + 1]++;
+        for (int64_t i = 0; i < n_rows; ++i) rstart[(size_t)i + 1] += rstart[(size_t)i];
+        for (int64_t i = 0; i <= n_rows; ++i) {
+            rows[(size_t)i].start = rstart[(size_t)i];
+            rows[(size_t)i].cnt.store(0, std::memory_order_relaxed);
+            rows[(size_t)i].pad = 0;
+        }
+    }
     std::vector<int32_t> rcol((size_t)nnz);
-    std::vector<std::atomic<int32_t>> rcnt((size_t)n_rows);
-    for (auto& c : rcnt) c.store(0, std::memory_order_relaxed);
     std::vector<std::vector<int32_t>> classes;
     std::vector<uint64_t> full;  // bit c: class c holds max_batch columns
     // round state
-    std::vector<int32_t> todo(order, order + d);  // remaining columns, visiting order
+    std::vector<int32_t> todo(order, order + d);  // columns in visiting order
     size_t head = 0;
-    std::vector<int32_t> round_cols, refused, tentative((size_t)kRoundMax), accepted;
+    std::vector<int32_t> round_cols, colour((size_t)kRoundMax);
     round_cols.reserve(kRoundMax);
     size_t n_classes = 0, words = 1;
     bool done = false;
     SpinBarrier bar(n_threads);
-    std::vector<std::vector<uint64_t>> used((size_t)n_threads);
+    std::vector<std::vector<uint64_t>> used((size_t)kRoundMax);  // snapshot colour sets
+    // the columns of a round are shared among the threads 1..T-1 (thread 0 prepares and resolves
+    // the rounds; it only takes columns when it is alone)
+    const int n_work = n_threads > 1 ? n_threads - 1 : 1;
+
+    // (1) the colours present in the rows of column j as of the start of the round (plus the
+    // full classes).  The rows of a column are scattered over the whole matrix: descriptor and
+    // colour list are requested ahead (two-stage software prefetch), else every row costs two
+    // dependent misses
+    auto snapshot_set = [&](int32_t j, std::vector<uint64_t>& u) {
+        u.assign(words, 0);
+        for (size_t w = 0; w < full.size() && w < words; ++w) u[w] = full[w];
+        const int64_t cb = cptr[j], ce = cptr[j + 1];
+        constexpr int64_t PD = 12;
+        for (int64_t ii = cb; ii < ce; ++ii) {
+            if (ii + 2 * PD < ce) __builtin_prefetch(&rows[(size_t)cidx[ii + 2 * PD]]);
+            if (ii + PD < ce) __builtin_prefetch(&rcol[(size_t)rows[(size_t)cidx[ii + PD]].start]);
+            const RowList& r = rows[(size_t)cidx[ii]];
+            const int32_t* rc = &rcol[(size_t)r.start];
+            const int32_t cnt = r.cnt.load(std::memory_order_relaxed);
+            for (int32_t t = 0; t < cnt; ++t) u[(size_t)rc[t] >> 6] |= 1ull << (rc[t] & 63);
+        }
+    };
+    // (3) colour of an accepted column into its rows' lists
+    auto commit = [&](int32_t j, int32_t c) {
+        const int64_t cb = cptr[j], ce = cptr[j + 1];
+        for (int64_t ii = cb; ii < ce; ++ii) {
+            if (ii + 12 < ce) __builtin_prefetch(&rows[(size_t)cidx[ii + 12]], 1);
+            RowList& r = rows[(size_t)cidx[ii]];
+            const int32_t slot = r.cnt.fetch_add(1, std::memory_order_relaxed);
+            rcol[(size_t)r.start + slot] = c;
+        }
+    };
+    auto phase1 = [&](int wid) {
+        for (size_t q = (size_t)wid; q < round_cols.size(); q += (size_t)n_work)
+            snapshot_set(round_cols[q], used[q]);
+    };
+    auto phase3 = [&](int wid) {
+        for (size_t q = (size_t)wid; q < round_cols.size(); q += (size_t)n_work)
+            commit(round_cols[q], colour[q]);
+    };
 
     auto worker = [&](int tid) {
         for (;;) {
             bar.wait();  // round prepared by thread 0
             if (done) return;
-            // (1) tentative colours from the snapshot
-            std::vector<uint64_t>& u = used[(size_t)tid];
-            for (size_t q = (size_t)tid; q < round_cols.size(); q += (size_t)n_threads) {
-                const int32_t j = round_cols[q];
-                u.assign(words, 0);
-                for (size_t w = 0; w < full.size() && w < words; ++w) u[w] = full[w];
-                for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
-                    if (ii + 16 < cptr[j + 1]) {
-                        const int32_t i2 = cidx[ii + 16];
-                        __builtin_prefetch(&rcol[(size_t)rstart[(size_t)i2]]);
-                    }
-                    const int32_t i = cidx[ii];
-                    const int32_t* rc = &rcol[(size_t)rstart[(size_t)i]];
-                    const int32_t cnt = rcnt[(size_t)i].load(std::memory_order_relaxed);
-                    for (int32_t t = 0; t < cnt; ++t) u[(size_t)rc[t] >> 6] |= 1ull << (rc[t] & 63);
-                }
-                int32_t c = (int32_t)n_classes;
-                for (size_t w = 0; w < words; ++w)
-                    if (~u[w]) {
-                        const size_t cand = w * 64 + (size_t)__builtin_ctzll(~u[w]);
-                        if (cand < n_classes) c = (int32_t)cand;
-                        break;
-                    }
-                tentative[q] = c;
-            }
+            phase1(tid - 1);
             bar.wait();  // thread 0 resolves the round
             bar.wait();
-            // (3) commit: colours of the accepted columns into their rows' lists
-            for (size_t q = (size_t)tid; q < accepted.size(); q += (size_t)n_threads) {
-                const int32_t j = round_cols[(size_t)accepted[q]];
-                const int32_t c = tentative[(size_t)accepted[q]];
-                for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
-                    const int32_t i = cidx[ii];
-                    const int32_t slot = rcnt[(size_t)i].fetch_add(1, std::memory_order_relaxed);
-                    rcol[(size_t)rstart[(size_t)i] + slot] = c;
-                }
-            }
+            phase3(tid - 1);
             bar.wait();
         }
     };
     std::vector<std::thread> pool;
     for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker, t);
-    // thread 0: drives the rounds and takes part in the parallel phases
-    std::vector<uint64_t>& u0 = used[0];
+    // thread 0: drives the rounds
     for (;;) {
-        // prepare: refused columns of the last round first, then fresh ones
-        round_cols.assign(refused.begin(), refused.end());
-        refused.clear();
+        round_cols.clear();
         while ((int)round_cols.size() < kRoundMax && head < todo.size())
             round_cols.push_back(todo[head++]);
         n_classes = classes.size();
@@ -265,66 +288,45 @@ void schedule_colored_parallel(int64_t n_rows, int32_t d, const int64_t* cptr, c
             break;
         }
         bar.wait();
-        // thread 0's share of phase (1)
-        for (size_t q = 0; q < round_cols.size(); q += (size_t)n_threads) {
-            const int32_t j = round_cols[q];
-            u0.assign(words, 0);
-            for (size_t w = 0; w < full.size() && w < words; ++w) u0[w] = full[w];
-            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
-                const int32_t i = cidx[ii];
-                const int32_t* rc = &rcol[(size_t)rstart[(size_t)i]];
-                const int32_t cnt = rcnt[(size_t)i].load(std::memory_order_relaxed);
-                for (int32_t t = 0; t < cnt; ++t) u0[(size_t)rc[t] >> 6] |= 1ull << (rc[t] & 63);
-            }
-            int32_t c = (int32_t)n_classes;
-            for (size_t w = 0; w < words; ++w)
-                if (~u0[w]) {
-                    const size_t cand = w * 64 + (size_t)__builtin_ctzll(~u0[w]);
-                    if (cand < n_classes) c = (int32_t)cand;
-                    break;
-                }
-            tentative[q] = c;
-        }
+        if (n_threads == 1) phase1(0);
         bar.wait();
-        // (2) resolve in visiting order (a column that found no free class has tentative colour
-        // n_classes: the first such column opens the class, later ones may join it)
-        accepted.clear();
+        // (2) first fit in visiting order: snapshot set, classes filled meanwhile, columns of
+        // this round that hold the candidate colour
         for (size_t q = 0; q < round_cols.size(); ++q) {
-            const int32_t c = tentative[q];
-            bool ok = true;
-            size_t same = 0;
-            for (int32_t a : accepted) {
-                if (tentative[(size_t)a] != c) continue;
-                ++same;
-                if (columns_share_row(cptr, cidx, round_cols[(size_t)a], round_cols[q])) {
-                    ok = false;
-                    break;
+            const std::vector<uint64_t>& u = used[q];
+            int32_t c = 0;
+            for (;; ++c) {
+                if ((size_t)c >= classes.size()) break;  // nothing fits: a new class
+                if ((size_t)c < n_classes && ((u[(size_t)c >> 6] >> (c & 63)) & 1ull)) {
+                    // jump to the next colour outside the snapshot set
+                    size_t w = (size_t)c >> 6;
+                    uint64_t free_bits = ~u[w] & (~0ull << (c & 63));
+                    while (free_bits == 0 && ++w < words) free_bits = ~u[w];
+                    c = (free_bits == 0) ? (int32_t)(words * 64)
+                                         : (int32_t)(w * 64 + (size_t)__builtin_ctzll(free_bits));
+                    if ((size_t)c >= classes.size()) break;
                 }
+                if ((int)classes[(size_t)c].size() >= max_batch) continue;
+                bool clash = false;
+                for (size_t a = 0; a < q && !clash; ++a)
+                    if (colour[a] == c &&
+                        columns_share_row(cptr, cidx, round_cols[a], round_cols[q]))
+                        clash = true;
+                if (!clash) break;
             }
-            const size_t have = (c < (int32_t)classes.size()) ? classes[(size_t)c].size() : 0;
-            if (ok && (int)(have + same) >= max_batch) ok = false;
-            if (ok) accepted.push_back((int32_t)q);
-            else refused.push_back(round_cols[q]);
-        }
-        for (int32_t a : accepted) {
-            const int32_t c = tentative[(size_t)a];
-            if (c >= (int32_t)classes.size()) classes.resize((size_t)c + 1);
-            classes[(size_t)c].push_back(round_cols[(size_t)a]);
+            if ((size_t)c >= classes.size()) {
+                c = (int32_t)classes.size();
+                classes.emplace_back();
+            }
+            colour[q] = c;
+            classes[(size_t)c].push_back(round_cols[q]);
             if ((int)classes[(size_t)c].size() >= max_batch) {
                 if (full.size() <= ((size_t)c >> 6)) full.resize(((size_t)c >> 6) + 1, 0);
                 full[(size_t)c >> 6] |= 1ull << (c & 63);
             }
         }
         bar.wait();
-        for (size_t q = 0; q < accepted.size(); q += (size_t)n_threads) {
-            const int32_t j = round_cols[(size_t)accepted[q]];
-            const int32_t c = tentative[(size_t)accepted[q]];
-            for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
-                const int32_t i = cidx[ii];
-                const int32_t slot = rcnt[(size_t)i].fetch_add(1, std::memory_order_relaxed);
-                rcol[(size_t)rstart[(size_t)i] + slot] = c;
-            }
-        }
+        if (n_threads == 1) phase3(0);
         bar.wait();
     }
     for (auto& t : pool) t.join();

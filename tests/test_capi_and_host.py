@@ -97,6 +97,50 @@ def test_schedule_is_a_partition_into_row_disjoint_batches(mode, max_batch):
             assert np.intersect1d(prev, X.indices[X.indptr[j]:X.indptr[j + 1]]).size > 0
 
 
+@pytest.mark.parametrize("max_batch", [0, 3])
+def test_parallel_colouring_is_the_sequential_first_fit(max_batch, monkeypatch):
+    """Big inputs take the threaded colouring (csrc/spfm_schedule.cpp, schedule_colored_parallel:
+    d >= 4096 and nnz >= 2^20).  It must return exactly the first-fit colouring of the given
+    order -- restated here with Python sets -- for any number of threads."""
+    from sparsepoly_amd.schedule import build_schedule
+
+    rng = np.random.RandomState(5)
+    n, d, per_row = 66000, 4200, 16
+    cols = rng.randint(0, d, size=(n, per_row))
+    rows = np.repeat(np.arange(n), per_row)
+    X = sp.csc_matrix((np.ones(n * per_row), (rows, cols.ravel())), shape=(n, d))
+    X.sum_duplicates()
+    X.sort_indices()
+    assert X.nnz >= (1 << 20)
+    jf = rng.permutation(d).astype(np.int32)
+    got = {}
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("SPFM_THREADS", threads)
+        order, bp = build_schedule(X, "colored", jf, max_batch)
+        got[threads] = (order.copy(), bp.copy())
+    for threads in ("3", "8"):
+        np.testing.assert_array_equal(got[threads][0], got["1"][0])
+        np.testing.assert_array_equal(got[threads][1], got["1"][1])
+    # first fit in Python: colours present in each row, lowest colour absent from all rows of j
+    row_colours = [set() for _ in range(n)]
+    classes = []
+    for j in jf:
+        rj = X.indices[X.indptr[j]:X.indptr[j + 1]]
+        taken = set().union(*[row_colours[i] for i in rj]) if len(rj) else set()
+        c = 0
+        while c < len(classes) and (c in taken or (max_batch and len(classes[c]) >= max_batch)):
+            c += 1
+        if c == len(classes):
+            classes.append([])
+        classes[c].append(int(j))
+        for i in rj:
+            row_colours[i].add(c)
+    want_order = np.array([j for cl in classes for j in cl], dtype=np.int32)
+    want_bp = np.cumsum([0] + [len(cl) for cl in classes]).astype(np.int32)
+    np.testing.assert_array_equal(got["1"][0], want_order)
+    np.testing.assert_array_equal(got["1"][1], want_bp)
+
+
 def test_schedule_rejects_non_permutation():
     from sparsepoly_amd.schedule import build_schedule
 

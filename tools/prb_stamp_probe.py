@@ -13,7 +13,7 @@ for G in [int(g) for g in os.environ.get("GS", "16,32").split(",")]:
     eng.pcd_epoch(0, 2, 10.0, 1.0, 1.0, ic[:2])
     t=time.time(); eng.pcd_epoch(0, 2, 10.0, 1.0, 1.0, ic[:4]); dt=(time.time()-t)/4
     st = eng.debug_prb_stamps().astype(float)
-    names = ["c:pre", "c:-", "c:-", "c:waitB3", "c:sum+chain", "c:B4", "c:ph3+B5", "c:-",
+    names = ["c:pre", "h:to-go", "h:sweep", "c:waitB3", "c:sum+chain", "c:B4", "c:ph3+B5", "h:B3",
              "w:gather+sum", "w:publish", "w:sweep", "w:prefetch", "w:B3", "w:waitB4", "w:scatter",
              "w:B5"]
     print("G=%d pass %.2f ms, %.2f us/step; cycles/step (WG0 | min | mean over WGs | max):" % (G, dt*1e3, dt*1e6/nb))

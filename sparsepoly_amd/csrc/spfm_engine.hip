@@ -212,6 +212,8 @@ struct spfm_engine {
     DevBuf prb_sp, prb_erow, prb_eval, prb_slab, prb_abort, prow_old, d_bptr, prb_stamps,
         prb_viol, prb_cn, prb_lmask;
     bool prb_stamp_on = false;
+    bool wide_stamp_on = false;  // pcdw_stamps: phase timers of the wide pcd pass (float storage)
+    DevBuf wide_stamps;
     static constexpr size_t kPrbLds = 84 * 1024;  // > half of the CU's 160 KiB: 1 WG per CU
     // wide persistent passes (spfm_pcdw.hip.h): steps of up to 512 columns, degree-2 pcd and
     // cd_linear; chosen when the schedule has a step of more than 64 columns
@@ -1544,6 +1546,30 @@ struct spfm_engine {
             int prc = peer_clear(kPeerPbOff, kPeerDoubles - kPeerPbOff);
             if (prc) return prc;
         }
+        a.stamps = nullptr;
+        if constexpr (can_lr && KIND == 0) {
+            if (wide_stamp_on) {  // diagnostic instantiations (tools/pcdw_stamp_probe.py)
+                HIPC(wide_stamps.alloc(sizeof(long long) * 16 * (size_t)a.G));
+                HIPC(hipMemsetAsync(wide_stamps.p, 0, wide_stamps.bytes, stream));
+                a.stamps = wide_stamps.as<long long>();
+                const size_t lds = use_lr ? std::max(lds_lr, kPrbLds) : kPrbLds;
+                if (use_lr) {
+                    HIPC(hipFuncSetAttribute((const void*)pcdw_kernel<T, KIND, 1, true>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((pcdw_kernel<T, KIND, 1, true>), dim3(a.G),
+                                       dim3(kPcdwThreads), lds, stream, a, pp, w_eval.as<T>(), Aptr,
+                                       yy.as<T>());
+                } else {
+                    HIPC(hipFuncSetAttribute((const void*)pcdw_kernel<T, KIND, 0, true>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((pcdw_kernel<T, KIND, 0, true>), dim3(a.G),
+                                       dim3(kPcdwThreads), lds, stream, a, pp, w_eval.as<T>(), Aptr,
+                                       yy.as<T>());
+                }
+                HIPC(hipGetLastError());
+                return SPFM_OK;
+            }
+        }
         if constexpr (can_lr) {
             if (use_lr) {
                 const size_t lds = std::max(lds_lr, kPrbLds);
@@ -2765,6 +2791,8 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->probe_lds = (int)value;
     } else if (k == "pbprb_dbg") {
         h->pb_dbg = value;
+    } else if (k == "pcdw_stamps") {
+        h->wide_stamp_on = value != 0;
     } else if (k == "pbprb_stamps") {
         h->pb_stamp_on = value != 0;
     } else if (k == "pbprb_groups") {
@@ -2832,6 +2860,14 @@ int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap) {
         int i = 0;
         for (; i < 16 + 4096 && i < cap; ++i) out[i] = (long long)v[i];
         return i - (i % 16);
+    }
+    if (h->wide_stamp_on && h->wide_stamps.p && out) {  // wide pcd pass's timers
+        const int nv = (int)(h->wide_stamps.bytes / sizeof(long long));
+        if (cap < nv) return SPFM_ERR_INVALID;
+        if (hipMemcpy(out, h->wide_stamps.p, sizeof(long long) * (size_t)nv,
+                      hipMemcpyDeviceToHost) != hipSuccess)
+            return SPFM_ERR_RUNTIME;
+        return nv;
     }
     if (h->pb_stamp_on && h->pb_stream_ready && out) {  // persistent pbcd pass's timers
         const int nv = 16 * h->pb_stream_G;

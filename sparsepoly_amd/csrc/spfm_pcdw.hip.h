@@ -46,6 +46,7 @@ struct PcdwArgs {
     unsigned* abort_flag;
     int n_ranks, rank;
     double* const* slabC;   // [n_ranks] peer-mapped [2][32][n_ranks][32]
+    long long* stamps;      // diagnostic (STAMP instantiation): [G][16] cycles per phase, thread 0
 };
 
 struct PcdwParams {
@@ -62,7 +63,7 @@ struct PcdwParams {
 };
 
 constexpr int kPcdwThreads = 512;
-constexpr int kPcdwEPT = 3;  // entries of a slot kept in registers per thread
+constexpr int kPcdwEPT = 6;  // entries of a slot kept in registers per thread
 
 __device__ __forceinline__ bool pcdw_poll_fail(const PcdwArgs& a, unsigned& spins) {
     if ((++spins & 63u) == 0) {
@@ -94,7 +95,7 @@ struct PcdwSet {  // a thread's entries of one step: [e0, e0 + cnt), the first k
 
 // KIND 0: pcd component pass (degree 2), 1: cd_linear epoch.  LR 0: rows in global memory,
 // 1: (A[i], residual) in LDS (float storage, squared loss).
-template <typename T, int KIND, int LR>
+template <typename T, int KIND, int LR, bool STAMP = false>
 __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwParams pp,
                                                             const T* __restrict__ eval,
                                                             T* __restrict__ A_all,
@@ -124,6 +125,16 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
         for (int t = 0; t < 3; ++t) cache[t] = pp.cache_in[t];
     }
     if (tid == 0) *sh_ok = 1;
+    long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = STAMP ? clock64() : 0;
+#define PW_STAMP(kk)                        \
+    if constexpr (STAMP) {                  \
+        if (tid == 0) {                     \
+            const long long tn = clock64(); \
+            acc[kk] += tn - tprev;          \
+            tprev = tn;                     \
+        }                                   \
+    }
     if constexpr (LR != 0) {  // row block -> LDS (residual form: dloss = yhat - y)
         const int nr = min(a.rows_per, a.n_rows - row0);
         for (int il = tid; il < nr; il += kPcdwThreads) {
@@ -200,6 +211,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
 
         // ---- phase 0 (LR = 0): rows this step shares with the previous one
         if constexpr (LR == 0) load_rows(cur, av, yh, yt, 1);
+        PW_STAMP(0)  // hazard rows
         // ---- phase 1: the thread's column: partial sums over the block's rows (pcd.py:52-59,
         // cd_linear.py:15-18)
         double ag = 0.0, ah = 0.0;
@@ -260,6 +272,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
             prb_store_granule(dst + 16, ah, tag);
         }
         sh_pold[q] = s0;
+        PW_STAMP(1)  // sums + publish
 
         // ---- phase 2: owners reduce their vslot over the workgroups (+ over the GPUs)
         const int n_rounds = (a.G >= 32) ? 1 : (nwv + a.G - 1) / a.G;
@@ -301,6 +314,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
                 }
                 red[grp * L + lane] = tot;
             }
+            PW_STAMP(2)  // owner poll
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (v >= nv && v < nwv && v >= 0 && grp == 0) {  // keep the unused vslot's tags fresh
                 prb_store_granule(slabB + (size_t)v * L + lane, 0.0, tag);
@@ -341,6 +355,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
             }
         }
 
+        PW_STAMP(3)  // owner barrier + total + publish
         // ---- prefetch (in front of the collect poll, as in the pbcd pass): entries of step
         // b+2, row state of step b+1 that this step does not touch, slot data of step b+1
         int b3e0, b3e1;
@@ -352,6 +367,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
         int jmine = 0;  // workgroup 0 writes the parameters
         if (g == 0 && q < ncols) jmine = a.jsched[c0 + q];
 
+        PW_STAMP(4)  // prefetch issue
         // ---- phase 3: every workgroup collects the totals of all vslots
         {
             const int total = nv * L;
@@ -384,8 +400,10 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
                 }
             }
         }
+        PW_STAMP(5)  // collect poll
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // totals, p_old in LDS
         if (!*sh_ok) break;
+        PW_STAMP(6)  // barrier
 
         // ---- phase 4: the update.  pcd: the control wave runs the chain over the step's
         // columns, 64 per round (pcd.py:61-68 + the regularizer's cache recurrence), every
@@ -427,6 +445,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
             }
         }
 
+        PW_STAMP(7)  // chain rounds + barrier
         // ---- phase 5: scatter over the thread's entries (pcd.py:124-133, cd_linear.py:28-31)
         if (q < ncols && delta != 0.0) {
 #pragma unroll
@@ -482,6 +501,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
                 }
             }
         }
+        PW_STAMP(8)  // scatter
         // ---- rotate the pipeline
         cur = nxt;
         nxt = nn;
@@ -503,6 +523,12 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else
             __syncthreads();  // rows move between threads from step to step (stores drained)
+        PW_STAMP(9)  // rotate + end barrier
+    }
+#undef PW_STAMP
+    if (STAMP && a.stamps != nullptr && tid == 0) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t) a.stamps[(size_t)g * 16 + t] = acc[t];
     }
     if constexpr (LR != 0) {  // write the row block back (yhat = r + y)
         __syncthreads();

@@ -63,7 +63,12 @@ struct PcdwParams {
 };
 
 constexpr int kPcdwThreads = 512;
-constexpr int kPcdwEPT = 6;  // entries of a slot kept in registers per thread
+// entries of a slot kept in registers per thread.  A thread with more entries reads the rest
+// through two dependent global loads, in the gradient phase and again in the scatter -- and every
+// step waits for its slowest workgroup.  With ~2 entries per thread (Poisson) 3 registers left
+// 14 % of the threads on that path: 2M x 200k (rows in LDS) 7.88 us per step with 3, 7.16 with 6,
+// 7.02 with 8; 6M x 600k (rows in global memory) 15.6 / 13.8 / 13.45.
+constexpr int kPcdwEPT = 8;
 
 __device__ __forceinline__ bool pcdw_poll_fail(const PcdwArgs& a, unsigned& spins) {
     if ((++spins & 63u) == 0) {

@@ -212,6 +212,7 @@ struct spfm_engine {
     DevBuf prb_sp, prb_erow, prb_eval, prb_slab, prb_abort, prow_old, d_bptr, prb_stamps,
         prb_viol, prb_cn, prb_lmask;
     bool prb_stamp_on = false;
+    int wide_min_cols = 110;     // mean class width below which 64-column steps are used instead
     bool wide_stamp_on = false;  // pcdw_stamps: phase timers of the wide pcd pass (float storage)
     DevBuf wide_stamps;
     static constexpr size_t kPrbLds = 84 * 1024;  // > half of the CU's 160 KiB: 1 WG per CU
@@ -782,6 +783,18 @@ struct spfm_engine {
             schedule_exact(rows, d, cp, ci, indices_feature, max_batch, batch_ptr);
         } else if (mode == SPFM_SCHED_COLORED) {
             schedule_colored(rows, d, cp, ci, indices_feature, max_batch, order, batch_ptr);
+            if (pers && max_batch > 64 && batch_ptr.size() > 1) {
+                // A wide step costs about twice a 64-column step (two fabric hops, 7.0 vs 3.2 us
+                // on one GPU): classes of moderate width are cheaper as more, narrower steps.
+                // 110 columns per class is where d/64 steps of the 64-column pass equal the
+                // classes' count of wide steps; below it, colour again with 64.
+                int32_t widest = 0;
+                for (size_t b = 0; b + 1 < batch_ptr.size(); ++b)
+                    widest = std::max(widest, batch_ptr[b + 1] - batch_ptr[b]);
+                const double mean_cols = (double)d / (double)(batch_ptr.size() - 1);
+                if (widest > 64 && mean_cols < (double)wide_min_cols)
+                    schedule_colored(rows, d, cp, ci, indices_feature, 64, order, batch_ptr);
+            }
         } else {
             FAIL(SPFM_ERR_INVALID, "set_schedule: unknown mode");
         }
@@ -2791,6 +2804,8 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->probe_lds = (int)value;
     } else if (k == "pbprb_dbg") {
         h->pb_dbg = value;
+    } else if (k == "wide_min_cols") {
+        h->wide_min_cols = value;
     } else if (k == "pcdw_stamps") {
         h->wide_stamp_on = value != 0;
     } else if (k == "pbprb_stamps") {

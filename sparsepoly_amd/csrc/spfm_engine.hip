@@ -792,7 +792,18 @@ struct spfm_engine {
                 for (size_t b = 0; b + 1 < batch_ptr.size(); ++b)
                     widest = std::max(widest, batch_ptr[b + 1] - batch_ptr[b]);
                 const double mean_cols = (double)d / (double)(batch_ptr.size() - 1);
-                if (widest > 64 && mean_cols < (double)wide_min_cols)
+                // ... with the 64-column pass's rows in LDS; when the row blocks of 64 workgroups
+                // do not fit (float storage: > ~1.1 M rows per GPU; double storage: never) its
+                // step costs 5.7 us and the break-even is 80 columns
+                int lds_max = 0;
+                HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock,
+                                           device));
+                const bool rows_fit = dtype == SPFM_F32 && prb_lds &&
+                                      (loss == SPFM_LOSS_SQUARED || y_pm1) &&
+                                      sizeof(double) * kPrbLdsFixed + (size_t)((n + 63) / 64) * 9 + 16 <=
+                                          (size_t)lds_max;
+                const double limit = rows_fit ? (double)wide_min_cols : 0.72 * (double)wide_min_cols;
+                if (widest > 64 && mean_cols < limit)
                     schedule_colored(rows, d, cp, ci, indices_feature, 64, order, batch_ptr);
             }
         } else {

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
             double* red = sh_red + (size_t)(r & 1) * NG * L;
             if (own) {
                 double tot = 0.0;
-                constexpr int GU = 8;
+                constexpr int GU = sizeof(T) == 4 ? 16 : 8;  // sources polled together per lane (float: all 256 in one round; double storage is short of registers)
                 for (int src0 = grp; src0 < a.G; src0 += NG * GU) {
                     unsigned long long t[GU];
                     unsigned spins = 0;

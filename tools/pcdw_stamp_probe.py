@@ -18,6 +18,7 @@ Xc = X.tocsc(); Xc.sort_indices()
 for stamps in (0, 1):
     eng = HipEngine(0, "f32")
     eng.set_option("pcdw_groups", G); eng.set_option("pcdw_stamps", stamps)
+    eng.set_option("wide_min_cols", 0)  # the wide pass whatever the class width
     eng.set_data(Xc, y)
     eng.set_params(0.01 * np.random.RandomState(0).randn(1, 30, d), np.zeros(d), np.ones(30))
     eng.configure("pcd", "squared", "squaredl12", 2); eng.init_pred(2, True, False)

@@ -45,7 +45,7 @@ NNZ_PER_ROW = 50
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # bumped whenever a hot kernel changes; profiles/<round>_traffic.json records the tag it was
 # collected with, and `traffic` is only reported when the two agree
-ENGINE_TAG = "r02-e5"
+ENGINE_TAG = "r02-e6"
 
 # hyper-parameters: well conditioned and such that P does NOT collapse to
 # zero (with gamma = 1 every coordinate is thresholded away in the first epoch and the scatter

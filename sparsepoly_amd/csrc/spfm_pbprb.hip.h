@@ -539,7 +539,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             if (own) {
                 // group `grp` sums the source workgroups grp, grp + NG, ... in that order
                 double tot = 0.0;
-                constexpr int GU = 8;
+                constexpr int GU = (L == 32) ? 16 : 8;  // sources per lane and round (L = 32: all 256 in one round)
                 for (int s0 = grp; s0 < a.G; s0 += NG * GU) {
                     unsigned long long t[GU];
                     unsigned spins = 0;

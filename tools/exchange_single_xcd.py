@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Bare exchange cost: all XCDs (sc1 stores) vs one XCD (plain stores, L2-served sc1 loads)."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparsepoly_amd.engine import HipEngine
 eng = HipEngine(0, "f32")
 for xcd in (0, 1, 3):

@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Phase stamps of the degree-3 component pass of BASELINE config 3 (pcd_prb_kernel<float, 3>,
+rows in global memory; diagnostic instantiation, options prb_lds=0 + prb_stamps=1):
+profiles/r02_c3_step_stamps.txt."""
 import os, sys, time, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparsepoly_amd.engine import HipEngine
 from sparsepoly_amd.synth import make_problem
 n, d = 1000000, 100000

@@ -241,13 +241,22 @@ int spfm_set_use_graph(spfm_handle h, int on);
  * "psgd_eager" (1: launch every psgd minibatch eagerly instead of replaying runs of 32 from
  * a hipGraph), "psgd_graph_sweeps" (support-search sweeps recorded per minibatch for the
  * squared-norm prox, default 4; an epoch in which that was not enough is redone eagerly from
- * a snapshot -- spfm_get_option("psgd_redone") counts those).  They change how a sweep is
- * cut into launches and in which order partial sums are added, never the coordinate order. */
+ * a snapshot -- spfm_get_option("psgd_redone") counts those).  Round 2: "pbcd_persistent"
+ * (0/1: the persistent pbcd pass), "pbprb_groups" (its workgroups, default 256), "wide" (0/1:
+ * the wide passes for degree-2 pcd / cd_linear, steps of up to 512 columns), "pcdw_groups"
+ * (their workgroups, default 256), "wide_min_cols" (mean colour-class width below which the
+ * schedule is coloured again with 64 columns per class and the 64-column passes run, default
+ * 110; 0 = always wide), "peer_exchange" (only 0 can be set: give the in-kernel cross-GPU
+ * exchange up after spfm_peer_connect and use the per-step collective), diagnostics
+ * "pbprb_stamps", "pcdw_stamps", "probe_xcd" / "probe_lds" (spfm_debug_exchange_cost on one
+ * XCD).  They change how a sweep is cut into launches and in which order partial sums are
+ * added; "wide" / "wide_min_cols" / "max_batch" also the coloured schedule built next (never an
+ * order the caller passed as 'exact'). */
 int spfm_set_option(spfm_handle h, const char* key, int value);
 /* read back a tunable, or the derived "persistent_active" (1 if the next pcd epoch
  * will use the persistent pass: option on, single GPU, steps of <= 64 columns) and
  * "prb_lds_active" (what the last pcd pass used: 0 global rows, 1 LDS residual form,
- * 2 LDS prediction + label sign) */
+ * 2 LDS prediction + label sign), "pbprb_active", "wide_active", "wide_lds_active" */
 int spfm_get_option(spfm_handle h, const char* key, int* value);
 
 /* diagnostic ("prb_stamps" option): accumulated shader cycles per phase of the last

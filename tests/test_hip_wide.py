@@ -96,3 +96,26 @@ def test_wide_pass_f32_lds_rows_and_narrow_engine():
         np.testing.assert_allclose(a["P"], r["P"], rtol=0, atol=1e-4)
     n = _run(X, y, "squared", "squaredl12", "f64", {"wide": 0})
     assert n["wide"] == 0 and n["max_step"] <= 64 and n["steps"] > a["steps"]
+
+
+def test_moderately_wide_classes_run_as_64_column_steps(oracle):
+    """Mean class width below the threshold (`wide_min_cols` = 110 columns when the 64-column pass
+    keeps its rows in LDS, 0.72 x that otherwise -- double storage here): the engine colours again
+    with 64 columns per class and runs the 64-column passes (a wide step costs about twice a narrow
+    one); `wide_min_cols=0` keeps the wide pass.  Both equal the oracle in their
+    reported orders."""
+    X, y = _problem("squared", per_row=10)  # first fit: 51 classes, 59 columns on average, <= 96
+    k = 5
+    runs = {"policy": _run(X, y, "squared", "squaredl12", "f64", {}),
+            "wide": _run(X, y, "squared", "squaredl12", "f64", {"wide_min_cols": 0})}
+    assert runs["policy"]["wide"] == 0 and runs["policy"]["max_step"] <= 64
+    assert runs["wide"]["wide"] == 1 and runs["wide"]["max_step"] > 64
+    assert runs["policy"]["steps"] > runs["wide"]["steps"]
+    for r in runs.values():
+        fm = oracle.OracleFM(degree=2, loss="squared", n_components=k, solver="pcd",
+                             regularizer="squaredl12", alpha=0.5, beta=10.0, gamma=1e-3, tol=0,
+                             max_iter=2, fit_linear=True, feature_order=r["order"])
+        fm.fit(X, y, P_init=r["P0"], lams_init=np.where(np.arange(k) % 2 == 0, 1.0, -1.0))
+        np.testing.assert_allclose(r["viol"], [h[0] for h in fm.history], rtol=1e-9)
+        np.testing.assert_allclose(r["P"], fm.P_, rtol=0, atol=1e-8)
+

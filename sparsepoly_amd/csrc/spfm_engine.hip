@@ -215,6 +215,7 @@ struct spfm_engine {
     int wide_min_cols = 110;     // mean class width below which 64-column steps are used instead
     bool wide_stamp_on = false;  // pcdw_stamps: phase timers of the wide pcd pass (float storage)
     DevBuf wide_stamps;
+    DevBuf w_rec;  // packed row records of the wide pcd pass (rows in global memory)
     static constexpr size_t kPrbLds = 84 * 1024;  // > half of the CU's 160 KiB: 1 WG per CU
     // wide persistent passes (spfm_pcdw.hip.h): steps of up to 512 columns, degree-2 pcd and
     // cd_linear; chosen when the schedule has a step of more than 64 columns
@@ -1571,6 +1572,24 @@ struct spfm_engine {
             if (prc) return prc;
         }
         a.stamps = nullptr;
+        // pcd with the rows in global memory: packed row records (see PcdwRec)
+        PcdwRec<T>* rec = nullptr;
+        const bool packed = KIND == 0 && !use_lr;
+        if (packed) {
+            HIPC(w_rec.alloc(sizeof(PcdwRec<T>) * (size_t)n));
+            rec = w_rec.as<PcdwRec<T>>();
+            hipLaunchKernelGGL((pcdw_pack_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                               pp.ctl, n, pp.a_stride, yy.as<T>(), Aptr, rec);
+            HIPC(hipGetLastError());
+        }
+        auto unpack = [&]() -> int {
+            if (packed) {
+                hipLaunchKernelGGL((pcdw_unpack_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0,
+                                   stream, pp.ctl, n, pp.a_stride, rec, yy.as<T>(), Aptr);
+                HIPC(hipGetLastError());
+            }
+            return SPFM_OK;
+        };
         if constexpr (can_lr && KIND == 0) {
             if (wide_stamp_on) {  // diagnostic instantiations (tools/pcdw_stamp_probe.py)
                 HIPC(wide_stamps.alloc(sizeof(long long) * 16 * (size_t)a.G));
@@ -1582,16 +1601,16 @@ struct spfm_engine {
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     hipLaunchKernelGGL((pcdw_kernel<T, KIND, 1, true>), dim3(a.G),
                                        dim3(kPcdwThreads), lds, stream, a, pp, w_eval.as<T>(), Aptr,
-                                       yy.as<T>());
+                                       yy.as<T>(), rec);
                 } else {
                     HIPC(hipFuncSetAttribute((const void*)pcdw_kernel<T, KIND, 0, true>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     hipLaunchKernelGGL((pcdw_kernel<T, KIND, 0, true>), dim3(a.G),
                                        dim3(kPcdwThreads), lds, stream, a, pp, w_eval.as<T>(), Aptr,
-                                       yy.as<T>());
+                                       yy.as<T>(), rec);
                 }
                 HIPC(hipGetLastError());
-                return SPFM_OK;
+                return unpack();
             }
         }
         if constexpr (can_lr) {
@@ -1600,7 +1619,7 @@ struct spfm_engine {
                 HIPC(hipFuncSetAttribute((const void*)pcdw_kernel<T, KIND, 1>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((pcdw_kernel<T, KIND, 1>), dim3(a.G), dim3(kPcdwThreads), lds,
-                                   stream, a, pp, w_eval.as<T>(), Aptr, yy.as<T>());
+                                   stream, a, pp, w_eval.as<T>(), Aptr, yy.as<T>(), rec);
                 HIPC(hipGetLastError());
                 return SPFM_OK;
             }
@@ -1608,9 +1627,9 @@ struct spfm_engine {
         HIPC(hipFuncSetAttribute((const void*)pcdw_kernel<T, KIND, 0>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrbLds));
         hipLaunchKernelGGL((pcdw_kernel<T, KIND, 0>), dim3(a.G), dim3(kPcdwThreads), kPrbLds, stream,
-                           a, pp, w_eval.as<T>(), Aptr, yy.as<T>());
+                           a, pp, w_eval.as<T>(), Aptr, yy.as<T>(), rec);
         HIPC(hipGetLastError());
-        return SPFM_OK;
+        return unpack();
     }
 
     template <typename T>

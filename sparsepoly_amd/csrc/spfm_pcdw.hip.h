@@ -91,6 +91,45 @@ __device__ __forceinline__ int pcdw_owned_vslot(int G, int g, int r) {
     return v < 32 ? v : -1;
 }
 
+// Row record of the wide pcd pass with its rows in global memory: (yhat_i, y_i, A_s[i]) side by
+// side, so that an entry's row state is ONE line instead of one of `yy` and one of the
+// component's cache slice.  At 10M rows the pass is bound by the CU's outstanding misses (430
+// random rows per workgroup and step): half the lines, half the misses.  Packed from yy / A at
+// the start of a component pass and unpacked at its end (two streaming kernels, 0.1 ms).
+template <typename T>
+struct __attribute__((aligned(4 * sizeof(T)))) PcdwRec {
+    T yh, y, a, pad;
+};
+
+template <typename T>
+__global__ void pcdw_pack_kernel(const Ctl* __restrict__ ctl, int64_t n, size_t a_stride,
+                                 const T* __restrict__ yy, const T* __restrict__ A_all,
+                                 PcdwRec<T>* __restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const T* A = A_all + (size_t)ctl->s * a_stride;
+        PcdwRec<T> r;
+        r.yh = yy[2 * i];
+        r.y = yy[2 * i + 1];
+        r.a = A[i];
+        r.pad = (T)0;
+        rec[i] = r;
+    }
+}
+
+template <typename T>
+__global__ void pcdw_unpack_kernel(const Ctl* __restrict__ ctl, int64_t n, size_t a_stride,
+                                   const PcdwRec<T>* __restrict__ rec, T* __restrict__ yy,
+                                   T* __restrict__ A_all) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        T* A = A_all + (size_t)ctl->s * a_stride;
+        const PcdwRec<T> r = rec[i];
+        yy[2 * i] = r.yh;
+        A[i] = r.a;
+    }
+}
+
 template <typename T>
 struct PcdwSet {  // a thread's entries of one step: [e0, e0 + cnt), the first kPcdwEPT loaded
     int e0, cnt;
@@ -104,7 +143,10 @@ template <typename T, int KIND, int LR, bool STAMP = false>
 __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwParams pp,
                                                             const T* __restrict__ eval,
                                                             T* __restrict__ A_all,
-                                                            T* __restrict__ yy) {
+                                                            T* __restrict__ yy,
+                                                            PcdwRec<T>* __restrict__ rec) {
+    // KIND 0, LR 0: the rows live in `rec` (packed records); every other variant ignores it
+    constexpr bool PACKED = (KIND == 0 && LR == 0);
     static_assert(LR == 0 || sizeof(T) == 4, "LDS-resident rows: float storage");
     constexpr int NG = 16, L = 32, EPT = kPcdwEPT;
     using Set = PcdwSet<T>;
@@ -175,10 +217,17 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
         for (int u = 0; u < EPT; ++u) {
             if (u < s.cnt && (int)((unsigned)s.row[u] >> 31) == hz) {
                 const size_t i = (size_t)(s.row[u] & 0x7fffffff);
-                const typename Vec2<T>::type yv = yy2[i];
-                yh[u] = yv.x;
-                yt[u] = yv.y;
-                if constexpr (KIND == 0) av[u] = A[i];
+                if constexpr (PACKED) {
+                    const PcdwRec<T> r = rec[i];
+                    yh[u] = r.yh;
+                    yt[u] = r.y;
+                    av[u] = r.a;
+                } else {
+                    const typename Vec2<T>::type yv = yy2[i];
+                    yh[u] = yv.x;
+                    yt[u] = yv.y;
+                    if constexpr (KIND == 0) av[u] = A[i];
+                }
             }
         }
     };
@@ -214,6 +263,9 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
         double* slabA = a.slabA + (size_t)par * 32 * a.G * L;
         double* slabB = a.slabB + (size_t)par * 32 * L;
 
+        // Everything loaded in the previous step has landed by now; a real S_WAITCNT tells the
+        // compiler so (see pbcd_prb_kernel), else the prefetch block below stalls on its own loads
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         // ---- phase 0 (LR = 0): rows this step shares with the previous one
         if constexpr (LR == 0) load_rows(cur, av, yh, yt, 1);
         PW_STAMP(0)  // hazard rows
@@ -255,6 +307,11 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
                     y0 = (double)lds_r[i - row0];
                     y1 = 0.0;
                     if constexpr (KIND == 0) a1 = (double)lds_a[i - row0];
+                } else if constexpr (PACKED) {
+                    const PcdwRec<T> r = rec[i];
+                    y0 = (double)r.yh;
+                    y1 = (double)r.y;
+                    a1 = (double)r.a;
                 } else {
                     const typename Vec2<T>::type yv = yy2[i];
                     y0 = (double)yv.x;
@@ -363,14 +420,18 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
         PW_STAMP(3)  // owner barrier + total + publish
         // ---- prefetch (in front of the collect poll, as in the pbcd pass): entries of step
         // b+2, row state of step b+1 that this step does not touch, slot data of step b+1
-        int b3e0, b3e1;
-        bounds(b + 3, q, c4 - c3, b3e0, b3e1);
-        load_entries(nn, b2e0, b2e1);
+        // Order matters: the row gathers use the entries loaded a step ago, and the compiler --
+        // conservative about loads that are pending across the loop's back edge -- puts a full
+        // vmcnt(0) in front of that use; issued behind this step's (cold, streaming) entry loads
+        // it would wait for those too.  So: rows first, the entry stream last.
         if constexpr (LR == 0) load_rows(nxt, avn, yhn, ytn, 0);
         s0n = (q < c2 - c1) ? pp.sched0[c1 + q] : 0.0;
         if constexpr (KIND == 1) s1n = (q < c2 - c1) ? pp.sched1[c1 + q] : 0.0;
         int jmine = 0;  // workgroup 0 writes the parameters
         if (g == 0 && q < ncols) jmine = a.jsched[c0 + q];
+        int b3e0, b3e1;
+        bounds(b + 3, q, c4 - c3, b3e0, b3e1);
+        load_entries(nn, b2e0, b2e1);
 
         PW_STAMP(4)  // prefetch issue
         // ---- phase 3: every workgroup collects the totals of all vslots
@@ -469,7 +530,16 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
                             lds_r[il] = (T)((double)lds_r[il] - delta * x);
                         }
                     } else {
-                        if constexpr (KIND == 0) {
+                        if constexpr (PACKED) {
+                            const double a1 = (double)av[u];
+                            const double dprev = x * (a1 - s0 * x);
+                            PcdwRec<T> r;
+                            r.yh = (T)((double)yh[u] - lam * delta * dprev);
+                            r.y = yt[u];
+                            r.a = (T)(a1 - delta * x);
+                            r.pad = (T)0;
+                            rec[(size_t)i] = r;
+                        } else if constexpr (KIND == 0) {
                             const double a1 = (double)av[u];
                             const double dprev = x * (a1 - s0 * x);
                             A[(size_t)i] = (T)(a1 - delta * x);
@@ -493,6 +563,13 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
                     } else {
                         lds_r[il] = (T)((double)lds_r[il] - delta * x);
                     }
+                } else if constexpr (PACKED) {
+                    PcdwRec<T> r = rec[(size_t)i];
+                    const double a1 = (double)r.a;
+                    const double dprev = x * (a1 - s0 * x);
+                    r.a = (T)(a1 - delta * x);
+                    r.yh = (T)((double)r.yh - lam * delta * dprev);
+                    rec[(size_t)i] = r;
                 } else {
                     const double y0 = (double)yy[2 * (size_t)i];
                     if constexpr (KIND == 0) {

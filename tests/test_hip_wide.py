@@ -119,3 +119,40 @@ def test_moderately_wide_classes_run_as_64_column_steps(oracle):
         np.testing.assert_allclose(r["viol"], [h[0] for h in fm.history], rtol=1e-9)
         np.testing.assert_allclose(r["P"], fm.P_, rtol=0, atol=1e-8)
 
+
+
+@pytest.mark.parametrize("precision,groups", [("f64", 4), ("f32", 4), ("f32", 2), ("f64", 256)])
+def test_wide_pass_many_entries_per_thread_rows_in_global_memory(oracle, precision, groups):
+    """The memory path of the wide pass that BASELINE configs[4] takes at 10M rows, at a size the
+    oracle replays in a second: 240k x 16k with 60-entry columns and few row blocks, so a thread
+    (= one column slot of one row block) holds 15 (4 blocks) / 30 (2 blocks) entries per step --
+    more than the `kPcdwEPT` = 8 it keeps in registers, the rest goes through the two dependent
+    global loads in the gradient and again in the scatter -- and a workgroup gathers ~5 000 /
+    ~10 000 rows per step (config 5: 430).  The row blocks (60k rows and more) do not fit LDS:
+    packed 16-byte row records in global memory (float) / `yy` + `A` (double).  Classes hold up
+    to 477 columns.  256 blocks: the register path on the same matrix.  Against the oracle in the
+    reported order (pcd.py:97-135, cd_linear.py:8-33)."""
+    X, y = _problem("squared", n=240_000, d=16_000, per_row=4, seed=5)
+    k = 3
+    r = _run(X, y, "squared", "squaredl12", precision, {"pcdw_groups": groups}, k=k)
+    assert r["wide"] == 1 and r["lds"] == 0 and 256 < r["max_step"] <= 512, \
+        (r["wide"], r["lds"], r["max_step"])
+    col_len = np.diff(X.tocsc().indptr)
+    if groups <= 4:
+        assert col_len.mean() / groups > 12  # entries per thread and step, on average
+    fm = oracle.OracleFM(degree=2, loss="squared", n_components=k, solver="pcd",
+                         regularizer="squaredl12", alpha=0.5, beta=10.0, gamma=1e-3, tol=0,
+                         max_iter=2, fit_linear=True, feature_order=r["order"])
+    fm.fit(X, y, P_init=r["P0"], lams_init=np.where(np.arange(k) % 2 == 0, 1.0, -1.0))
+    ref_viol = [h[0] for h in fm.history]
+    if precision == "f64":
+        np.testing.assert_allclose(r["viol"], ref_viol, rtol=1e-9)
+        np.testing.assert_allclose(r["P"], fm.P_, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(r["w"], fm.w_, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(r["y_pred"], fm.y_pred_, rtol=0, atol=1e-7)
+    else:
+        np.testing.assert_allclose(r["viol"], ref_viol, rtol=2e-5)
+        np.testing.assert_allclose(r["P"], fm.P_, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(r["w"], fm.w_, rtol=0, atol=1e-4)
+        scale = max(1.0, float(np.abs(fm.y_pred_).max()))
+        np.testing.assert_allclose(r["y_pred"], fm.y_pred_, rtol=0, atol=2e-4 * scale)

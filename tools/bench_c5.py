@@ -58,6 +58,8 @@ def run_engine(Xc, y, P0, passes, options, reps=1):
     eng.init_pred(2, True, False)  # recomputed from the trained parameters
     y_new = eng.get_y_pred()
     info = dict(steps_per_sweep=eng.n_batches, persistent=eng.get_option("persistent_active"),
+                wide_active=eng.get_option("wide_active"),
+                wide_rows_in_lds=eng.get_option("wide_lds_active"),
                 set_data_s=round(t_data, 1), schedule_s=round(t_sched, 1),
                 first_calls_s=round(t_first, 1))
     if reps:

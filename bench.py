@@ -5,6 +5,12 @@ regularizer='squaredl12', solver='pcd', 1M x 100k synthetic CSR, ~50 nnz/row).
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4}]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+``--gpus N`` without a launcher (WORLD_SIZE unset) starts the N ranks itself: N child processes
+of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, started BEFORE anything in
+the parent touches the GPU; the parent relays rank 0's JSON line and exits with the children's
+status.  On a box with fewer than N devices the ranks share the devices (a rehearsal: host
+shared-memory communicator, exchange slabs mapped through IPC on one GPU) and the line says so.
+
 A "step" is one full training iteration of the reference's fit loop
 (sparse_factorization_machines.py:196-256 / :287-350): one cd_linear epoch, the lower-order
 epochs (fit_lower='explicit') and the top-order epoch, on data already resident in HBM.  The
@@ -25,11 +31,18 @@ Prints ONE JSON line (rank 0).  Extra objects:
 N > 1: rows are sharded over the ranks; the persistent passes exchange their per-step totals
 through peer-mapped slabs inside the kernels (no per-step collective).  Default is WEAK scaling:
 N times the rows and columns (the family that ends in BASELINE configs[4]: 10M x 1M on 8 GPUs),
-value = N x epochs/s; ``--scaling strong`` shards the 1M x 100k matrix itself.
+value = N x epochs/s; ``--scaling strong`` shards the 1M x 100k matrix itself.  Set-up is O(1/N)
+per rank: a rank draws only its own rows from the counter-based generator and hands them to the
+library as CSR; rank 0 alone draws the global STRUCTURE (no values), colours it and broadcasts
+order / batch boundaries, which the other ranks install with spfm_set_schedule_raw.  The line
+carries per-rank set-up seconds and peak host RSS.
 """
 import argparse
 import json
 import os
+import resource
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,9 +56,10 @@ N_SAMPLES = int(os.environ.get("SPFM_BENCH_N", 1_000_000))
 N_FEATURES = int(os.environ.get("SPFM_BENCH_D", 100_000))
 NNZ_PER_ROW = 50
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# bumped whenever a hot kernel changes; profiles/<round>_traffic.json records the tag it was
-# collected with, and `traffic` is only reported when the two agree
-ENGINE_TAG = "r02-e6"
+# profiles/<round>_traffic.json records the library's build tag (hash of its sources,
+# spfm_build_tag) it was collected with; `traffic` is only reported when that is the library
+# running now
+TRAFFIC_FILE = "r03_traffic.json"
 
 # hyper-parameters: well conditioned and such that P does NOT collapse to
 # zero (with gamma = 1 every coordinate is thresholded away in the first epoch and the scatter
@@ -75,6 +89,57 @@ def alg_bytes(cfg, n, nnz, tsz=4):
     return lin + 2 * 4 * nnz + tsz * (m - 1) * n * k + nnz * (4 + 4 * tsz + 2 * tsz * (m - 1) * k)
 
 
+def device_count():
+    """Devices of this box, asked of a short-lived child so that the launcher itself never
+    initialises the GPU (it must stay free to start the ranks)."""
+    try:
+        out = subprocess.run([sys.executable, "-c",
+                              "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=600)
+        return max(0, int(out.stdout.strip().splitlines()[-1]))
+    except Exception:
+        return 0
+
+
+def launch_ranks(n_ranks, argv):
+    """Start the N ranks as child processes, relay rank 0's JSON line, return the exit status."""
+    ndev = int(os.environ.get("SPFM_BENCH_DEVICES", 0)) or device_count()
+    if ndev < 1:
+        log("no GPU visible: cannot start %d ranks" % n_ranks)
+        return 1
+    with socket.socket() as sk:  # a free port for the control-plane rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    shared = ndev < n_ranks
+    if shared:
+        log("%d ranks on %d device(s): REHEARSAL -- ranks share a GPU (host-shm communicator, "
+            "exchange slabs IPC-mapped on one device)" % (n_ranks, ndev))
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r % ndev), WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SPFM_BENCH_LAUNCHER="self", SPFM_BENCH_NDEV=str(ndev))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if shared:
+            env["SPFM_DEVICE"] = str(r % ndev)
+            env.setdefault("SPFM_COMM", "shm")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    status = procs[0].returncode
+    for pr in procs[1:]:
+        try:
+            pr.wait(timeout=300)
+        except subprocess.TimeoutExpired:
+            pr.kill()  # exactly the child we started
+            pr.wait()
+        status = status or pr.returncode
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +157,10 @@ def main():
                          "that ends in BASELINE configs[4] = 10M x 1M on 8 GPUs); strong = the "
                          "same 1M x 100k matrix sharded over the ranks")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the ranks ourselves (children, never a re-exec; nothing in this
+        # process has touched the GPU)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     # stdout carries ONE JSON line and nothing else: libraries that write to file descriptor 1
     # (gloo announces its connections there) are sent to stderr for the whole run
     sys.stdout.flush()
@@ -117,47 +186,88 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world == 1 and args.gpus > 1:
-        log("--gpus %d requested but WORLD_SIZE=1: launch with torch.distributed.run" % args.gpus)
+    if args.gpus != world and rank == 0:
+        log("--gpus %d but WORLD_SIZE=%d: the line reports the %d rank(s) that really ran"
+            % (args.gpus, world, world))
 
+    from sparsepoly_amd import _capi
     from sparsepoly_amd import distributed as spdist
-    from sparsepoly_amd.engine import HipEngine, canonical_csc
+    from sparsepoly_amd.engine import HipEngine
     from sparsepoly_amd.synth import make_problem
+
+    ENGINE_TAG = _capi.build_tag()  # hash of the library's sources, written in at build time
 
     t0 = time.time()
     scale = world if (world > 1 and args.scaling == "weak") else 1
-    X, y = make_problem(N_SAMPLES * scale, N_FEATURES * scale, NNZ_PER_ROW, seed=0)
-    Xc = X.tocsc()
-    Xc.sort_indices()
-    n, d = Xc.shape
-    nnz = Xc.nnz
+    n, d = N_SAMPLES * scale, N_FEATURES * scale
+    setup = {}  # seconds of this rank's set-up phases
+    if world > 1:
+        # O(1/N) per rank: only the own rows, straight from the counter-based generator (CSR)
+        lo, hi = spdist.row_block(n, rank, world)
+        X, y = make_problem(n, d, NNZ_PER_ROW, seed=0, row_range=(lo, hi))
+        Xc = None
+        nnz_local = int(X.nnz)
+        t = torch.tensor([nnz_local], dtype=torch.int64)
+        dist.all_reduce(t)
+        nnz = int(t.item())
+    else:
+        X, y = make_problem(n, d, NNZ_PER_ROW, seed=0)
+        Xc = X.tocsc()
+        Xc.sort_indices()
+        nnz = Xc.nnz
+    setup["data_s"] = round(time.time() - t0, 2)
     if rank == 0:
-        log("data %dx%d nnz=%d generated in %.1fs" % (n, d, nnz, time.time() - t0))
+        log("data %dx%d nnz=%d: this rank's %d rows generated in %.1fs"
+            % (n, d, nnz, X.shape[0], time.time() - t0))
     n_orders = DEGREE - 1
     P0 = 0.01 * np.random.RandomState(0).randn(n_orders, K, d)
     lams = np.ones(K)
     ic = np.arange(K, dtype=np.int32)
     jf0 = np.arange(d, dtype=np.int32)
 
+    def global_structure():
+        """CSC structure (indices only) of the whole matrix: what a colouring needs.  Rank 0."""
+        from sparsepoly_amd.synth import make_csr
+
+        S = make_csr(n, d, NNZ_PER_ROW, seed=0, structure_only=True).tocsc()
+        S.sort_indices()
+        return S
+
     def make_engine(precision, schedule):
+        from sparsepoly_amd.schedule import Schedule
+
         eng = HipEngine(local_rank, precision)
         for kv in filter(None, os.environ.get("SPFM_OPTS", "").split(",")):  # e.g. prb_groups=32
             key, val = kv.split("=")
             eng.set_option(key, int(val))
-        conflict = None
+        t1 = time.time()
         if world > 1:
-            lo, hi = spdist.row_block(n, rank, world)
             spdist.init_engine_comm(eng)
             spdist.connect_peers(eng)  # persistent passes with the in-kernel xGMI exchange
-            eng.set_data(canonical_csc(X[lo:hi]), y[lo:hi])
-            conflict = Xc
-        else:
-            eng.set_data(Xc, y)
+        eng.set_data(X if world > 1 else Xc, y)  # CSR shard: transposed inside the library
         eng.set_params(P0, np.zeros(d), lams)
         eng.configure(cfg["solver"], "squared", cfg["reg"], DEGREE)
         eng.init_pred(DEGREE, True, DEGREE == 3)
+        setup["engine_s"] = round(time.time() - t1, 2)
         t1 = time.time()
-        order = eng.set_schedule(schedule, jf0, conflict)
+        if world > 1:
+            # rank 0 colours the global structure once (the library's own policy for the step
+            # width, decided from global inputs); everybody else installs the result
+            if rank == 0:
+                S = global_structure()
+                setup["structure_s"] = round(time.time() - t1, 2)
+                order = eng.set_schedule(schedule, jf0, S)
+                sch = eng.get_schedule(schedule)
+                payload = [sch.order, sch.batch_ptr]
+                del S
+            else:
+                payload = [None, None]
+            dist.broadcast_object_list(payload, src=0)
+            if rank != 0:
+                order = eng.install_schedule(Schedule(payload[0], payload[1], schedule, (n, d)))
+        else:
+            order = eng.set_schedule(schedule, jf0)
+        setup["schedule_s"] = round(time.time() - t1, 2)
         return eng, order, time.time() - t1
 
     def iteration(eng, comps=None):
@@ -278,16 +388,16 @@ def main():
         avg_us = 1e3 * g_ms / g_launch
         bytes_per_launch = bytes_per_nnz * g_nnz / g_launch
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
-        traffic, traffic_src = None, "not collected for this engine version (%s)" % ENGINE_TAG
+        traffic, traffic_src = None, "not collected for this build of the library (%s)" % ENGINE_TAG
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
             ent = tj.get("config%d" % args.config, {}).get(kname)
             if (ent and tj.get("engine_tag") == ENGINE_TAG and N_SAMPLES == 1_000_000
                     and N_FEATURES == 100_000 and world == 1 and args.precision == "f32"):
                 traffic = round(1024.0 * (ent["fetch_kb_per_launch"]
                                           + ent["write_kb_per_launch"]), 1)
-                traffic_src = "profiles/r02_traffic.json (rocprofv3 --pmc passes, engine %s)" \
-                    % ENGINE_TAG
+                traffic_src = "profiles/%s (rocprofv3 --pmc passes, library build %s)" \
+                    % (TRAFFIC_FILE, ENGINE_TAG)
         except Exception:
             pass
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
@@ -302,6 +412,17 @@ def main():
             if cfg["solver"] == "pcd":
                 # 0 = row state in global memory, 1 / 2 = row block resident in LDS
                 roof["row_block_in_lds"] = int(eng.get_option("prb_lds_active"))
+    # what really ran: the ranks of the engine's communicator, the exchange it used, whether a
+    # persistent pass had to be redone on the multi-kernel engine; per-rank set-up cost
+    ranks_seen = int(eng.get_option("n_ranks"))
+    peer_exchange = bool(eng.get_option("peer_ready"))
+    fallbacks = int(eng.get_option("persistent_fallbacks"))
+    setup["peak_rss_gb"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0, 2)
+    setup["rank"] = rank
+    setups = [setup]
+    if dist is not None:
+        setups = [None] * world
+        dist.all_gather_object(setups, setup)
     b_alg = alg_bytes(cfg, n, nnz)
     iter_gbs = b_alg / (ms_per_step * 1e-3) / 1e9
     steps_per_iter = (1 + (K * (DEGREE - 1) if cfg["solver"] == "pcd" else (DEGREE - 1))) * n_batches
@@ -380,7 +501,7 @@ def main():
             "metric": "pcd_epochs_per_sec" if cfg["solver"] == "pcd" else "pbcd_epochs_per_sec",
             "value": round(epochs_per_s, 4),
             "unit": "epochs/s",
-            "n_gpus": world,
+            "n_gpus": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
@@ -400,12 +521,19 @@ def main():
                         "single GPU: the configuration BASELINE.json's metric is quoted on"),
                        "schedule": args.schedule, "dependent_steps_per_sweep": n_batches,
                        "alpha": cfg["alpha"], "beta": cfg["beta"], "gamma": cfg["gamma"],
-                       "parallelism": ("rows sharded x%d, per-step exchange: %s"
-                                       % (world, "in-kernel peer-mapped slabs"
-                                          if os.environ.get("SPFM_PEER", "1") != "0" else
-                                          ("host-shm (rehearsal)"
-                                           if os.environ.get("SPFM_COMM") == "shm" else "RCCL")))
-                       if world > 1 else "single GPU"},
+                       "parallelism": ("rows sharded over %d ranks (one process per GPU), per-step "
+                                       "exchange: %s; control plane gloo, communicator %s"
+                                       % (ranks_seen,
+                                          "in-kernel peer-mapped slabs (no collective)"
+                                          if peer_exchange else "one all-reduce per dependent step",
+                                          "host-shm (ranks share a device: rehearsal)"
+                                          if os.environ.get("SPFM_COMM") == "shm" else "RCCL"))
+                       if world > 1 else "single GPU",
+                       "ranks_seen": ranks_seen,
+                       "devices_used": min(world, int(os.environ.get("SPFM_BENCH_NDEV", world))),
+                       "launcher": os.environ.get("SPFM_BENCH_LAUNCHER", "external"),
+                       "persistent_fallbacks": fallbacks,
+                       "setup_per_rank": setups},
             "roofline": roof,
             "cpu_baseline": cpu,
             "iteration_alg_GBs": round(iter_gbs, 2),

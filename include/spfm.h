@@ -71,6 +71,10 @@ void spfm_destroy(spfm_handle h);
 const char* spfm_last_error(spfm_handle h);
 /* library / device identification, e.g. "gfx950:sramecc+:xnack-" */
 int spfm_device_name(spfm_handle h, char* out, int cap);
+/* 12 hex digits: hash of the library's sources at build time (csrc/build.sh).  No handle and
+ * no device needed.  Measurements kept under profiles/ record it, so a counter file is only
+ * ever quoted for the code it was collected with. */
+const char* spfm_build_tag(void);
 
 /* -- data ------------------------------------------------------------------
  * Replaces get_dataset(X, order="fortran") (dataset.py:119-123, CSCDataset

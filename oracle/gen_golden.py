@@ -28,6 +28,9 @@ Fixture families:
   g7  API behaviours (n_iter_ semantics, stale P_ in pbcd callbacks, messages)
   g8  all-subsets model: the reference's own test cells + sparse trajectories
   g9  psgd solver: the reference's own test grid, prox operators, sparse trajectories
+  g10 regularizer eval() of all six plug-ins (2-D and stacked 3-D inputs, both `transpose`
+      settings, degrees 2-4 and -1) -- never called by a solver, but part of the plug-in
+      surface a user of the reference can call
 """
 import contextlib
 import io
@@ -755,7 +758,33 @@ def gen_g9():
     save("g9_psgd.npz", **out)
 
 
+# -------------------------------------------------------------------- g10
+def gen_g10():
+    """eval() of the six regularizers (regularizer/*.py: l1.py:17-18, l21.py:19-21,
+    squaredl12.py:20-22, squaredl21.py:23-25, omegati.py:19-47, omegacs.py:22-39)."""
+    rng = np.random.RandomState(10)
+    out = {}
+    P2 = rng.randn(7, 4)          # (n_features, n_components) in the psgd / pbcd convention
+    P3 = rng.randn(3, 7, 4)       # a stack (e.g. the orders of P_)
+    out["P2"], out["P3"] = P2, P3
+    for name, P in (("P2", P2), ("P3", P3)):
+        out["l1|%s" % name] = np.asarray(REGULARIZATION["l1"]().eval(P, 2))
+        for tr in (False, True):
+            out["l21|%s|t%d" % (name, tr)] = np.asarray(REGULARIZATION["l21"](tr).eval(P))
+            out["squaredl12|%s|t%d" % (name, tr)] = np.asarray(
+                REGULARIZATION["squaredl12"](tr).eval(P))
+            out["squaredl21|%s|t%d" % (name, tr)] = np.asarray(
+                REGULARIZATION["squaredl21"](tr).eval(P))
+        for deg in (2, 3, 4, -1):
+            out["omegati|%s|deg%d" % (name, deg)] = np.asarray(
+                REGULARIZATION["omegati"]().eval(P, deg))
+        for deg in (2, 3, 4):
+            out["omegacs|%s|deg%d" % (name, deg)] = np.asarray(
+                REGULARIZATION["omegacs"]().eval(P, deg))
+    save("g10_reg_eval.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for g in which:
         globals()["gen_" + g]()

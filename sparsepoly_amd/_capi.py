@@ -22,7 +22,7 @@ SCHEDULES = {"exact": 0, "colored": 1}
 
 # every symbol include/spfm.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "spfm_create", "spfm_destroy", "spfm_last_error", "spfm_device_name", "spfm_set_data_csc", "spfm_set_data_csr",
+    "spfm_create", "spfm_destroy", "spfm_last_error", "spfm_device_name", "spfm_build_tag", "spfm_set_data_csc", "spfm_set_data_csr",
     "spfm_set_params", "spfm_get_params", "spfm_configure", "spfm_init_pred", "spfm_get_y_pred",
     "spfm_loss_sum", "spfm_predict_csr", "spfm_set_schedule", "spfm_set_schedule_raw",
     "spfm_get_schedule", "spfm_schedule_build",
@@ -59,6 +59,8 @@ def load():
     L.spfm_last_error.argtypes = [_h]
     L.spfm_last_error.restype = C.c_char_p
     L.spfm_device_name.argtypes = [_h, C.c_char_p, C.c_int]
+    L.spfm_build_tag.argtypes = []
+    L.spfm_build_tag.restype = C.c_char_p
     L.spfm_set_data_csc.argtypes = [_h, C.c_int64, C.c_int32, _lp, _ip, _dp, _dp]
     L.spfm_set_data_csr.argtypes = [_h, C.c_int64, C.c_int32, _lp, _ip, _dp, _dp]
     L.spfm_set_params.argtypes = [_h, C.c_int, C.c_int, C.c_int32, _dp, _dp, _dp]
@@ -97,7 +99,7 @@ def load():
     L.spfm_debug_branch_counts.argtypes = [_h, C.POINTER(C.c_uint32), C.c_int]
     for name in SYMBOLS:
         f = getattr(L, name)
-        if name not in ("spfm_destroy", "spfm_last_error"):
+        if name not in ("spfm_destroy", "spfm_last_error", "spfm_build_tag"):
             f.restype = C.c_int
     _lib = L
     return L
@@ -116,3 +118,8 @@ def i32(a):
 def i64(a):
     a = np.ascontiguousarray(a, dtype=np.int64)
     return a, a.ctypes.data_as(_lp)
+
+
+def build_tag():
+    """Hash of the library's sources at build time (``spfm_build_tag``)."""
+    return load().spfm_build_tag().decode()

@@ -49,8 +49,14 @@ enum {
     BR_COUNT = 8
 };
 __device__ unsigned g_branch_count[BR_COUNT];
+// Counted once per step that took the branch.  REDUNDANT = true: the chain runs in every
+// workgroup of the launch (the persistent passes; pcd_chain_sync_kernel, up to the workgroup's own
+// column) -- the LAST workgroup of the grid runs the step's whole chain exactly once and counts;
+// false: one workgroup runs the chain (whichever it is), it counts.
+template <bool REDUNDANT = true>
 __device__ __forceinline__ void count_branch(int which, int lane) {
-    if (lane == 0) atomicAdd(&g_branch_count[which], 1u);
+    if (lane == 0 && (!REDUNDANT || blockIdx.x == gridDim.x - 1))
+        atomicAdd(&g_branch_count[which], 1u);
 }
 
 // ------------------------------------------------------------------ helpers
@@ -178,6 +184,11 @@ __global__ void begin_pass_kernel(Ctl* ctl, const int32_t* comp_order, const dou
         ctl->lam = lams[s];
         ctl->pass += 1;
     }
+}
+
+// undo of begin_pass_kernel's counter step for a pass that was announced but not launched
+__global__ void unbegin_pass_kernel(Ctl* ctl) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctl->pass -= 1;
 }
 
 // sum viol_col[0..d) -> out[0]  (one workgroup, fixed order => deterministic)

@@ -10,6 +10,7 @@
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -200,6 +201,22 @@ struct spfm_engine {
     bool fuse_chain = true;  // fused chain+sync kernel for batches of <= 64 columns
     int max_batch_opt = 4096;
 
+    // Recovery from a persistent pass that could not run to its end (a workgroup not resident,
+    // a peer that never answers): the epoch is all-or-nothing like the reference's
+    // (pcd.py:71-137).  Parameters and regularizer state are snapshot before the launches; after
+    // a time-out they are restored, y_pred is recomputed from them (the arguments of the last
+    // spfm_init_pred) and the epoch is redone on the multi-kernel engine, which this handle then
+    // keeps using.  `pers_fallbacks` counts the events (option "persistent_fallbacks").
+    bool pers_failed = false;
+    int pers_fallbacks = 0;
+    std::string pers_reason;
+    unsigned spin_max = 1u << 21;  // polls of one in-kernel wait before the pass gives up
+    int debug_drop = 0;            // test hook: the next N persistent launches lack a workgroup
+    bool have_pred_args = false;
+    int pa_degree = 0, pa_lin = 0, pa_lower = 0;
+    DevBuf snapP, snapW, snapC;
+    std::map<const void*, int> resident_cache;  // kernel -> workgroups that can be resident
+
     // persistent row-block pass (single GPU, pcd): one launch per component pass
     bool persistent = true;
     int prb_G = 64;
@@ -229,10 +246,12 @@ struct spfm_engine {
     // stream when that differs from the pcd / cd_linear pass's
     bool pb_persistent = true;
     int pbprb_G = 256;
+    int pbprb_owners = 0;   // dedicated owner workgroups (measured, no gain; off)
+    int pb_GO = 0;          // what the installed stream was built for
     int probe_xcd = 0, probe_lds = 60 * 1024;  // diagnostics (spfm_debug_exchange_cost)
     bool pb_stream_ready = false;
     int pb_stream_G = 0, pb_stream_NG = 0;
-    DevBuf pb_sp, pb_erow, pb_eval, pb_meta, pb_slabA, pb_slabB, pb_slabC, pb_stamps;
+    DevBuf pb_sp, pb_erow, pb_eval, pb_meta, pb_slabA, pb_slabB, pb_slabC, pb_stamps, pb_rec;
     bool pb_stamp_on = false;
     int pbprb_active = 0;  // what the last pbcd epoch used
     int pb_dbg = 0;
@@ -265,7 +284,9 @@ struct spfm_engine {
     // Layout (doubles): [0, 16K) pcd / cd_linear [2][n_ranks][64][2]; [16K, ...) pbcd
     // [2][64][n_ranks][64].
     static constexpr size_t kPeerPcdOff = 0, kPeerPbOff = 16 * 1024;
-    static constexpr size_t kPeerDoubles = kPeerPbOff + (size_t)2 * 64 * 8 * 64;
+    static constexpr size_t kPeerProbeOff = kPeerPbOff + (size_t)2 * 64 * 8 * 64;  // [8] handshake
+    static constexpr size_t kPeerDoubles = kPeerProbeOff + 64;
+    int peer_generation = 0;  // connects so far (the handshake word differs per connect)
     void* peer_own = nullptr;
     std::vector<void*> peer_ptr;     // [n_ranks] mapped bases ([rank] = own)
     DevBuf peer_tab_pcd, peer_tab_pb;  // device tables of the per-kernel region pointers
@@ -332,6 +353,12 @@ struct spfm_engine {
         ps.nnz += nnz_launch;
         (void)hipEventRecord(ps.ev[ps.used], stream);
         prof_armed = true;
+    }
+    void prof_cancel(int which, int64_t nnz_launch) {  // the launch announced by prof_begin was not made
+        if (!prof_armed) return;
+        prof[which].launches--;
+        prof[which].nnz -= nnz_launch;
+        prof_armed = false;
     }
     void prof_end(int which) {
         if (!prof_armed) return;
@@ -796,13 +823,25 @@ struct spfm_engine {
                 // ... with the 64-column pass's rows in LDS; when the row blocks of 64 workgroups
                 // do not fit (float storage: > ~1.1 M rows per GPU; double storage: never) its
                 // step costs 5.7 us and the break-even is 80 columns
-                int lds_max = 0;
+                // Decided from GLOBAL inputs only (the conflict structure's row count over the
+                // ranks, the loss, the options): every rank of a sharded run must
+                // cut its sweep into the same steps, or the exchange of the replicated chain
+                // mismatches.  Same LDS formula as pcd_pass_prb (degree 2: one cache value).
+                int lds_max = 0, ncu = 0;
                 HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock,
                                            device));
-                const bool rows_fit = dtype == SPFM_F32 && prb_lds &&
-                                      (loss == SPFM_LOSS_SQUARED || y_pm1) &&
-                                      sizeof(double) * kPrbLdsFixed + (size_t)((n + 63) / 64) * 9 + 16 <=
-                                          (size_t)lds_max;
+                HIPC(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+                const int nr_eff = dist() ? n_ranks : 1;
+                const int64_t rows_rank = (rows + nr_eff - 1) / nr_eff;  // largest row shard
+                const int Gp = std::max(1, std::min(prb_G, ncu));
+                const size_t lds_lr = sizeof(double) * kPrbLdsFixed +
+                                      (size_t)((rows_rank + Gp - 1) / Gp) *
+                                          (4 + (loss == SPFM_LOSS_SQUARED ? 4 : 5)) + 16;
+                // (a non-squared loss keeps its rows in LDS only when all targets are +-1 --
+                // the classifiers' case; that rank-local fact is deliberately NOT part of the
+                // decision, which must come out the same on every rank without a collective:
+                // rank 0 alone may be colouring, bench.py / a cached Schedule)
+                const bool rows_fit = dtype == SPFM_F32 && prb_lds && lds_lr <= (size_t)lds_max;
                 const double limit = rows_fit ? (double)wide_min_cols : 0.72 * (double)wide_min_cols;
                 if (widest > 64 && mean_cols < limit)
                     schedule_colored(rows, d, cp, ci, indices_feature, 64, order, batch_ptr);
@@ -953,6 +992,10 @@ struct spfm_engine {
 
     int init_pred(int degree, int fit_linear, int add_lower) {
         if (!have_data || !have_params) FAIL(SPFM_ERR_INVALID, "init_pred: no data/params");
+        have_pred_args = true;
+        pa_degree = degree;
+        pa_lin = fit_linear;
+        pa_lower = add_lower;
         return dtype == SPFM_F32 ? init_pred_t<float>(degree, fit_linear, add_lower)
                                  : init_pred_t<double>(degree, fit_linear, add_lower);
     }
@@ -1120,7 +1163,10 @@ struct spfm_engine {
             constexpr bool MGc = decltype(mg_tag)::value;
             HIPC(hipFuncSetAttribute((const void*)lin_prb_kernel<T, LOSS, LRc, MGc>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((lin_prb_kernel<T, LOSS, LRc, MGc>), dim3(prb_G), dim3(kPrbThreads),
+            if (!resident_ok((const void*)lin_prb_kernel<T, LOSS, LRc, MGc>, kPrbThreads, lds, prb_G))
+                return kNotResident;
+            hipLaunchKernelGGL((lin_prb_kernel<T, LOSS, LRc, MGc>), dim3(launch_groups(prb_G)),
+                               dim3(kPrbThreads),
                                lds, stream, pa, prb_eval.as<T>(), yy.as<T>(),
                                prow_old.as<double>(), prb_cn.as<double>(), w.as<double>(), alpha,
                                mu, prb_viol.as<double>());
@@ -1139,6 +1185,7 @@ struct spfm_engine {
             lrc = pa.n_ranks > 1
                       ? launch(std::integral_constant<int, 0>{}, std::true_type{}, kPrbLds)
                       : launch(std::integral_constant<int, 0>{}, std::false_type{}, kPrbLds);
+        if (lrc == kNotResident) prof_cancel(4, nnz);
         if (lrc) return lrc;
         prof_end(4);
         hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
@@ -1155,22 +1202,38 @@ struct spfm_engine {
         }
     }
 
+    void mark_not_resident(const char* what) {
+        pers_failed = true;
+        pers_fallbacks += 1;
+        pers_reason = std::string(what) + ": its workgroups cannot all be resident on this device";
+    }
+
     int cd_linear_epoch(double alpha, double* viol) {
         int rc = epoch_prologue();
         if (rc) return rc;
-        if (wide_usable()) {
-            rc = dtype == SPFM_F32 ? lin_wide<float>(alpha) : lin_wide<double>(alpha);
+        const bool wide = wide_usable();
+        if (wide || prb_usable()) {
+            const char* what = wide ? "wide persistent cd_linear pass" : "persistent cd_linear pass";
+            rc = snapshot_state(w.as<double>(), (size_t)d, snapW);
+            if (rc) return rc;
+            if (wide) rc = dtype == SPFM_F32 ? lin_wide<float>(alpha) : lin_wide<double>(alpha);
+            else rc = dtype == SPFM_F32 ? lin_prb_loss<float>(alpha) : lin_prb_loss<double>(alpha);
+            if (rc == kNotResident) {  // nothing was launched: the multi-kernel engine takes over
+                mark_not_resident(what);
+                return cd_linear_epoch(alpha, viol);
+            }
             if (rc) return rc;
             rc = epoch_epilogue(viol);
             if (rc) return rc;
-            return pb_check_abort();
-        }
-        if (prb_usable()) {
-            rc = dtype == SPFM_F32 ? lin_prb_loss<float>(alpha) : lin_prb_loss<double>(alpha);
+            bool aborted = false;
+            rc = persistent_aborted(&aborted);
             if (rc) return rc;
-            rc = epoch_epilogue(viol);
-            if (rc) return rc;
-            return prb_check_abort();
+            if (aborted) {  // all-or-nothing (cd_linear.py:8-33): back to the epoch's start, redo
+                rc = recover_from_abort(w.as<double>(), (size_t)d, snapW, what);
+                if (rc) return rc;
+                return cd_linear_epoch(alpha, viol);
+            }
+            return SPFM_OK;
         }
         const std::string key = fkey("lin", {alpha}, {loss, sched_version});
         rc = run_cached(key, [&]() {
@@ -1239,8 +1302,94 @@ struct spfm_engine {
     // ---------------------------------------------------- persistent row-block pass
     // (several ranks: the persistent passes need the peer-mapped exchange slabs)
     bool prb_usable() const {
-        return persistent && (!dist() || peer_ready) && max_batch_cols <= 64 &&
+        return persistent && !pers_failed && (!dist() || peer_ready) && max_batch_cols <= 64 &&
                nnz < ((int64_t)1 << 31) && n > 0;
+    }
+
+    // ---- residency and recovery of the persistent passes
+    // All workgroups of a persistent launch must be resident at once (they wait for each other
+    // inside the kernel).  `fn` with `threads` threads and `lds` bytes of dynamic LDS: do G
+    // workgroups fit the device (times the ranks that share it in a one-GPU rehearsal)?
+    bool resident_ok(const void* fn, int threads, size_t lds, int G) {
+        int per_cu = 0;
+        auto it = resident_cache.find(fn);
+        if (it != resident_cache.end()) {
+            per_cu = it->second;
+        } else {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) !=
+                hipSuccess) {
+                (void)hipGetLastError();
+                per_cu = 1;  // unknown: the in-kernel time-out stays the safety net
+            }
+            resident_cache[fn] = per_cu;
+        }
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
+            return true;
+        const int64_t sharers = shm.hdr ? n_ranks : 1;  // host-shm communicator: ranks on one GPU
+        return (int64_t)per_cu * ncu >= (int64_t)G * sharers;
+    }
+    static constexpr int kNotResident = 1;  // internal: the launch was not made, nothing changed
+    int launch_groups(int G) {  // test hook: a launch that lacks its last workgroup times out
+        if (debug_drop > 0 && G > 1) {
+            --debug_drop;
+            return G - 1;
+        }
+        return G;
+    }
+    int snapshot_state(const double* params, size_t count, DevBuf& dst) {
+        HIPC(dst.alloc(sizeof(double) * count));
+        HIPC(hipMemcpyAsync(dst.p, params, sizeof(double) * count, hipMemcpyDeviceToDevice, stream));
+        const size_t nc = kMaxDegree + 2;
+        HIPC(snapC.alloc(sizeof(double) * nc * 3));
+        HIPC(hipMemcpyAsync(snapC.p, cache.p, sizeof(double) * nc * 2, hipMemcpyDeviceToDevice,
+                            stream));
+        HIPC(hipMemcpyAsync(snapC.as<double>() + nc * 2, dcache.p, sizeof(double) * nc,
+                            hipMemcpyDeviceToDevice, stream));
+        return SPFM_OK;
+    }
+    // did the persistent launches of this epoch time out?  With several ranks the answer is
+    // agreed on (sum of the flags), so that all of them redo the epoch together.
+    int persistent_aborted(bool* out) {
+        *out = false;
+        if (!prb_abort.p) return SPFM_OK;
+        unsigned flag = 0;
+        HIPC(hipMemcpyAsync(&flag, prb_abort.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        HIPC(hipStreamSynchronize(stream));
+        double any = flag ? 1.0 : 0.0;
+        if (dist()) {
+            HIPC(hipMemcpyAsync(scalar.as<double>() + 6, &any, sizeof(double),
+                                hipMemcpyHostToDevice, stream));
+            HIPC(hipStreamSynchronize(stream));
+            int rc = allreduce(scalar.as<double>() + 6, 1);
+            if (rc) return rc;
+            HIPC(hipMemcpyAsync(&any, scalar.as<double>() + 6, sizeof(double),
+                                hipMemcpyDeviceToHost, stream));
+            HIPC(hipStreamSynchronize(stream));
+        }
+        if (flag) HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
+        *out = any != 0.0;
+        return SPFM_OK;
+    }
+    // after a time-out: parameters and regularizer state back to the epoch's start, y_pred
+    // recomputed from them, the persistent passes switched off for this handle
+    int recover_from_abort(double* params, size_t count, const DevBuf& src, const char* what) {
+        pers_failed = true;
+        pers_fallbacks += 1;
+        pers_reason = std::string(what) +
+                      " timed out waiting for its workgroups (not all resident, or a peer GPU "
+                      "did not answer)";
+        if (!have_pred_args)
+            FAIL(SPFM_ERR_RUNTIME, pers_reason + "; the model is half-updated (no spfm_init_pred "
+                                                 "call to recompute y_pred from)");
+        const size_t nc = kMaxDegree + 2;
+        HIPC(hipMemcpyAsync(params, src.p, sizeof(double) * count, hipMemcpyDeviceToDevice, stream));
+        HIPC(hipMemcpyAsync(cache.p, snapC.p, sizeof(double) * nc * 2, hipMemcpyDeviceToDevice,
+                            stream));
+        HIPC(hipMemcpyAsync(dcache.p, snapC.as<double>() + nc * 2, sizeof(double) * nc,
+                            hipMemcpyDeviceToDevice, stream));
+        clear_graphs();
+        return init_pred(pa_degree, pa_lin, pa_lower);
     }
 
     template <typename T>
@@ -1305,6 +1454,7 @@ struct spfm_engine {
         a.rows_per = (int)std::max<int64_t>((n + prb_G - 1) / prb_G, 1);
         a.n_rows = (int)n;
         a.abort_flag = prb_abort.as<unsigned>();
+        a.spin_max = spin_max;
         a.stamps = prb_stamp_on ? prb_stamps.as<long long>() : nullptr;
         a.n_ranks = peer_ready ? n_ranks : 1;
         a.rank = rank;
@@ -1334,6 +1484,9 @@ struct spfm_engine {
                  "prb_stamps: built for float storage, squared loss and degree 2 with prb_lds=1 "
                  "or degree 3 with prb_lds=0 only");
         const PrbArgs pa = prb_args();
+        if (prb_stamp_on && pa.n_ranks > 1)
+            FAIL(SPFM_ERR_UNSUPPORTED,
+                 "prb_stamps: the timer instantiation has no cross-GPU stage (single rank only)");
         int lds_max = 0;
         HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
         const size_t lds_lr = sizeof(double) * kPrbLdsFixed +
@@ -1370,15 +1523,21 @@ struct spfm_engine {
                 HIPC(hipFuncSetAttribute(
                     (const void*)pcd_prb_kernel<T, M, LOSS, LRc, STc, RGc, MGc>,
                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, LRc, STc, RGc, MGc>), dim3(prb_G),
-                                   dim3(kPrbThreads), lds, stream, c, pa, prb_eval.as<T>(),
+                if (!resident_ok((const void*)pcd_prb_kernel<T, M, LOSS, LRc, STc, RGc, MGc>,
+                                 kPrbThreads, lds, prb_G))
+                    return kNotResident;
+                hipLaunchKernelGGL((pcd_prb_kernel<T, M, LOSS, LRc, STc, RGc, MGc>),
+                                   dim3(launch_groups(prb_G)), dim3(kPrbThreads), lds, stream, c, pa, prb_eval.as<T>(),
                                    A.as<T>(), (size_t)n * Kind<M>::AS, yy.as<T>(),
                                    prow_old.as<double>(), Po, d, reg, cb, mu, beta, gamma, eta,
                                    prb_viol.as<double>());
                 return SPFM_OK;
             };
-            if constexpr (STc) return launch(std::false_type{});  // timers: single GPU only
-            else return pa.n_ranks > 1 ? launch(std::true_type{}) : launch(std::false_type{});
+            if constexpr (STc) {  // timers: single GPU only (refused above for several ranks)
+                return launch(std::false_type{});
+            } else {
+                return pa.n_ranks > 1 ? launch(std::true_type{}) : launch(std::false_type{});
+            }
         };
         using std::integral_constant;
         int lrc = SPFM_OK;
@@ -1415,6 +1574,7 @@ struct spfm_engine {
         }
         if (!launched)
             lrc = go(integral_constant<int, 0>{}, std::false_type{}, integral_constant<int, -1>{});
+        if (lrc == kNotResident) prof_cancel(0, nnz);
         if (lrc) return lrc;
         prof_end(0);
         hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
@@ -1470,23 +1630,10 @@ struct spfm_engine {
         return SPFM_OK;
     }
 
-    int prb_check_abort() {
-        if (!prb_ready) return SPFM_OK;
-        unsigned flag = 0;
-        HIPC(hipMemcpyAsync(&flag, prb_abort.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        HIPC(hipStreamSynchronize(stream));
-        if (flag) {
-            (void)hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream);
-            FAIL(SPFM_ERR_RUNTIME,
-                 "persistent pass timed out waiting for its workgroups (not all resident?)");
-        }
-        return SPFM_OK;
-    }
-
     // ------------------------------------------------------ wide persistent passes
     bool wide_usable() const {
-        return persistent && wide_on && (!dist() || peer_ready) && max_batch_cols > 64 &&
-               max_batch_cols <= 512 && nnz < ((int64_t)1 << 31) && n > 0;
+        return persistent && !pers_failed && wide_on && (!dist() || peer_ready) &&
+               max_batch_cols > 64 && max_batch_cols <= 512 && nnz < ((int64_t)1 << 31) && n > 0;
     }
 
     template <typename T>
@@ -1550,6 +1697,7 @@ struct spfm_engine {
         a.rows_per = (int)std::max<int64_t>((n + wide_G - 1) / wide_G, 1);
         a.n_rows = (int)n;
         a.abort_flag = prb_abort.as<unsigned>();
+        a.spin_max = spin_max;
         a.n_ranks = peer_ready ? n_ranks : 1;
         a.rank = rank;
         a.slabC = peer_ready ? peer_tab_pb.as<double*>() : nullptr;
@@ -1568,7 +1716,7 @@ struct spfm_engine {
         HIPC(hipMemsetAsync(w_slabA.p, 0, w_slabA.bytes, stream));
         HIPC(hipMemsetAsync(w_slabB.p, 0, w_slabB.bytes, stream));
         {
-            int prc = peer_clear(kPeerPbOff, kPeerDoubles - kPeerPbOff);
+            int prc = peer_clear(kPeerPbOff, kPeerProbeOff - kPeerPbOff);
             if (prc) return prc;
         }
         a.stamps = nullptr;
@@ -1590,45 +1738,33 @@ struct spfm_engine {
             }
             return SPFM_OK;
         };
+        // one launch site: residency check, test hook, launch
+        auto fire = [&](auto* fn, size_t lds) -> int {
+            HIPC(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+            if (!resident_ok((const void*)fn, kPcdwThreads, lds, a.G)) return kNotResident;
+            hipLaunchKernelGGL(fn, dim3(launch_groups(a.G)), dim3(kPcdwThreads), lds, stream, a, pp,
+                               w_eval.as<T>(), Aptr, yy.as<T>(), rec);
+            HIPC(hipGetLastError());
+            return SPFM_OK;
+        };
         if constexpr (can_lr && KIND == 0) {
             if (wide_stamp_on) {  // diagnostic instantiations (tools/pcdw_stamp_probe.py)
                 HIPC(wide_stamps.alloc(sizeof(long long) * 16 * (size_t)a.G));
                 HIPC(hipMemsetAsync(wide_stamps.p, 0, wide_stamps.bytes, stream));
                 a.stamps = wide_stamps.as<long long>();
                 const size_t lds = use_lr ? std::max(lds_lr, kPrbLds) : kPrbLds;
-                if (use_lr) {
-                    HIPC(hipFuncSetAttribute((const void*)pcdw_kernel<T, KIND, 1, true>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL((pcdw_kernel<T, KIND, 1, true>), dim3(a.G),
-                                       dim3(kPcdwThreads), lds, stream, a, pp, w_eval.as<T>(), Aptr,
-                                       yy.as<T>(), rec);
-                } else {
-                    HIPC(hipFuncSetAttribute((const void*)pcdw_kernel<T, KIND, 0, true>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL((pcdw_kernel<T, KIND, 0, true>), dim3(a.G),
-                                       dim3(kPcdwThreads), lds, stream, a, pp, w_eval.as<T>(), Aptr,
-                                       yy.as<T>(), rec);
-                }
-                HIPC(hipGetLastError());
+                int frc = use_lr ? fire(&pcdw_kernel<T, KIND, 1, true>, lds)
+                                 : fire(&pcdw_kernel<T, KIND, 0, true>, lds);
+                if (frc) return frc;
                 return unpack();
             }
         }
         if constexpr (can_lr) {
-            if (use_lr) {
-                const size_t lds = std::max(lds_lr, kPrbLds);
-                HIPC(hipFuncSetAttribute((const void*)pcdw_kernel<T, KIND, 1>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((pcdw_kernel<T, KIND, 1>), dim3(a.G), dim3(kPcdwThreads), lds,
-                                   stream, a, pp, w_eval.as<T>(), Aptr, yy.as<T>(), rec);
-                HIPC(hipGetLastError());
-                return SPFM_OK;
-            }
+            if (use_lr) return fire(&pcdw_kernel<T, KIND, 1>, std::max(lds_lr, kPrbLds));
         }
-        HIPC(hipFuncSetAttribute((const void*)pcdw_kernel<T, KIND, 0>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrbLds));
-        hipLaunchKernelGGL((pcdw_kernel<T, KIND, 0>), dim3(a.G), dim3(kPcdwThreads), kPrbLds, stream,
-                           a, pp, w_eval.as<T>(), Aptr, yy.as<T>(), rec);
-        HIPC(hipGetLastError());
+        int frc = fire(&pcdw_kernel<T, KIND, 0>, kPrbLds);
+        if (frc) return frc;
         return unpack();
     }
 
@@ -1669,6 +1805,7 @@ struct spfm_engine {
         pp.viol_pos = prb_viol.as<double>();
         prof_begin(0, nnz);
         rc = wide_launch<T, 0>(a, pp, A.as<T>());
+        if (rc == kNotResident) prof_cancel(0, nnz);
         if (rc) return rc;
         prof_end(0);
         hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
@@ -1702,23 +1839,12 @@ struct spfm_engine {
         pp.viol_pos = prb_viol.as<double>();
         prof_begin(4, nnz);
         rc = wide_launch<T, 1>(a, pp, (T*)nullptr);
+        if (rc == kNotResident) prof_cancel(4, nnz);
         if (rc) return rc;
         prof_end(4);
         hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
                            d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());
         HIPC(hipGetLastError());
-        return SPFM_OK;
-    }
-
-    int pb_check_abort() {
-        unsigned flag = 0;
-        HIPC(hipMemcpyAsync(&flag, prb_abort.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        HIPC(hipStreamSynchronize(stream));
-        if (flag) {
-            (void)hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream);
-            FAIL(SPFM_ERR_RUNTIME,
-                 "persistent pbcd pass timed out waiting for its workgroups (not all resident?)");
-        }
         return SPFM_OK;
     }
 
@@ -1795,16 +1921,33 @@ struct spfm_engine {
         rc = dtype == SPFM_F32 ? pcd_precompute_all_dispatch<float>(M, order_idx)
                                : pcd_precompute_all_dispatch<double>(M, order_idx);
         if (rc) return rc;
-        const bool use_prb = prb_usable();
-        const bool use_wide = wide_usable() && M == 2;
+        bool use_prb = prb_usable();
+        bool use_wide = wide_usable() && M == 2;
+        const bool pers_epoch = use_prb || use_wide;
+        double* Po_epoch = P.as<double>() + (size_t)order_idx * k * d;
+        if (pers_epoch) {
+            rc = snapshot_state(Po_epoch, (size_t)k * d, snapP);
+            if (rc) return rc;
+        }
         for (int pass = 0; pass < n_comp; ++pass) {
+            rc = SPFM_OK;
             if (use_wide) {
                 rc = dtype == SPFM_F32 ? pcd_pass_wide<float>(order_idx, beta, gamma, eta)
                                        : pcd_pass_wide<double>(order_idx, beta, gamma, eta);
             } else if (use_prb) {
                 rc = dtype == SPFM_F32 ? pcd_prb_dispatch<float>(M, order_idx, beta, gamma, eta)
                                        : pcd_prb_dispatch<double>(M, order_idx, beta, gamma, eta);
-            } else {
+            }
+            if (rc == kNotResident) {
+                // the pass was not launched (its helper kernels only picked the component and
+                // took snapshots): this and the following passes run on the multi-kernel engine.
+                // The component counter was advanced by begin_pass_kernel: step it back.
+                mark_not_resident(use_wide ? "wide persistent pcd pass" : "persistent pcd pass");
+                use_prb = use_wide = false;
+                hipLaunchKernelGGL(unbegin_pass_kernel, dim3(1), dim3(1), 0, stream, ctl.as<Ctl>());
+                HIPC(hipGetLastError());
+            }
+            if (!use_wide && !use_prb) {
                 rc = run_cached(key, [&]() {
                     return dtype == SPFM_F32
                                ? pcd_pass_dispatch<float>(M, order_idx, beta, gamma, eta)
@@ -1816,8 +1959,18 @@ struct spfm_engine {
         pt_valid = false;  // the passes rewrote P; the (d,k) image is stale again
         rc = epoch_epilogue(viol);
         if (rc) return rc;
-        if (use_wide) return pb_check_abort();
-        return use_prb ? prb_check_abort() : SPFM_OK;
+        if (pers_epoch) {
+            bool aborted = false;
+            rc = persistent_aborted(&aborted);
+            if (rc) return rc;
+            if (aborted) {  // all-or-nothing (pcd.py:71-137): back to the epoch's start, redo
+                rc = recover_from_abort(Po_epoch, (size_t)k * d, snapP,
+                                        use_wide ? "wide persistent pcd pass" : "persistent pcd pass");
+                if (rc) return rc;
+                return pcd_epoch(order_idx, degree, beta, gamma, eta, ic, n_comp, viol);
+            }
+        }
+        return SPFM_OK;
     }
 
     // ------------------------------------------------------------------- pbcd
@@ -1883,8 +2036,49 @@ struct spfm_engine {
     // ------------------------------------------------ persistent pbcd pass (one launch)
     static bool pbprb_degree_ok(int M) { return M == 0 || M == 2 || M == 3 || M == 4; }
     bool pbprb_usable(int M) const {
-        return persistent && pb_persistent && (!dist() || peer_ready) && max_batch_cols <= 64 &&
-               nnz < ((int64_t)1 << 31) && n > 0 && k <= 62 && pbprb_degree_ok(M);
+        return persistent && !pers_failed && pb_persistent && (!dist() || peer_ready) &&
+               max_batch_cols <= 64 && nnz < ((int64_t)1 << 31) && n > 0 && k <= 62 &&
+               pbprb_degree_ok(M);
+    }
+
+    // host-side audit of build_pb_stream's output against what the kernel assumes: group
+    // boundaries monotone and ending at nnz; every entry a valid CSC position whose row lies in
+    // the workgroup's block; slot index inside the group < 64 / NG; a group's entries sorted by
+    // slot; at most 64 columns per step.  Returns nullptr or what is wrong.
+    const char* validate_pb_stream(int G, int NG, const std::vector<int32_t>& gsp,
+                                   const std::vector<int32_t>& src,
+                                   const std::vector<uint8_t>& meta) const {
+        const int nb = n_batches();
+        const size_t stride = (size_t)NG + 1;
+        const int64_t rows_per = std::max<int64_t>((n + G - 1) / G, 1);
+        const int qm = 64 / NG;
+        if (gsp.size() != (size_t)G * nb * stride + 1) return "boundary table has the wrong size";
+        if ((int64_t)src.size() != nnz || (int64_t)meta.size() != nnz) return "entry count != nnz";
+        for (int b = 0; b < nb; ++b)
+            if (batch_ptr[b + 1] - batch_ptr[b] > 64) return "a step has more than 64 columns";
+        for (size_t t = 0; t + 1 < gsp.size(); ++t)
+            if (gsp[t] > gsp[t + 1] || gsp[t] < 0) return "group boundaries not monotone";
+        if (gsp.back() != (int32_t)nnz) return "group boundaries do not end at nnz";
+        for (int g = 0; g < G; ++g)
+            for (int b = 0; b < nb; ++b)
+                for (int grp = 0; grp < NG; ++grp) {
+                    const size_t at = ((size_t)g * nb + b) * stride + (size_t)grp;
+                    int prev_slot = 0;
+                    for (int32_t e = gsp[at]; e < gsp[at + 1]; ++e) {
+                        const int32_t pos = src[(size_t)e];
+                        if (pos < 0 || pos >= nnz) return "entry points outside the CSC arrays";
+                        const int64_t row = h_cidx[(size_t)pos];
+                        if (row < 0 || row >= n) return "row index out of range";
+                        if (row / rows_per != g) return "entry outside its workgroup's row block";
+                        const int slot = meta[(size_t)e] & 0x7f;
+                        if (slot >= qm) return "slot index >= slots per group";
+                        if (slot < prev_slot) return "a group's entries are not sorted by slot";
+                        prev_slot = slot;
+                        if (grp + slot * NG >= batch_ptr[b + 1] - batch_ptr[b])
+                            return "slot beyond the step's columns";
+                    }
+                }
+        return nullptr;
     }
 
     // entry stream (workgroup, step, slot, row) for G row blocks; shares the pcd pass's when
@@ -1893,11 +2087,24 @@ struct spfm_engine {
     int ensure_pb_stream(int NG) {
         int ncu = 0;
         HIPC(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
-        int G = std::max(1, std::min(pbprb_G, ncu));
-        if (pb_stream_ready && pb_stream_G == G && pb_stream_NG == NG) return SPFM_OK;
+        // pbprb_groups workgroups in all: GO dedicated owners + G row workgroups
+        const int Gtot = std::max(1, std::min(pbprb_G, ncu));
+        int GO = pbprb_owners;
+        GO = std::max(0, std::min({GO, 64, Gtot - 1}));
+        const int G = Gtot - GO;
+        if (pb_stream_ready && pb_stream_G == G && pb_stream_NG == NG && pb_GO == GO)
+            return SPFM_OK;
+        pb_GO = GO;
         std::vector<int32_t> gsp, src;
         std::vector<uint8_t> meta;
         build_pb_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, G, NG, gsp, src, meta);
+        // every bound pbcd_prb_kernel indexes with, checked on the host for problems where that
+        // is free (and on request, SPFM_VALIDATE=1): an out-of-range row or slot index would be
+        // a device memory fault, i.e. a dead process
+        if (nnz < ((int64_t)1 << 22) || getenv("SPFM_VALIDATE")) {
+            const char* bad = validate_pb_stream(G, NG, gsp, src, meta);
+            if (bad) FAIL(SPFM_ERR_RUNTIME, std::string("internal: pbcd entry stream: ") + bad);
+        }
         DevBuf d_src;
         HIPC(d_src.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
         HIPC(pb_sp.alloc(sizeof(int32_t) * gsp.size()));
@@ -1906,7 +2113,7 @@ struct spfm_engine {
         HIPC(pb_meta.alloc((size_t)(nnz > 0 ? nnz : 1) + 256));
         HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
         HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
-        HIPC(pb_stamps.alloc(sizeof(long long) * 16 * (size_t)G));
+        HIPC(pb_stamps.alloc(sizeof(long long) * 16 * (size_t)(G + GO)));
         HIPC(hipMemsetAsync(pb_stamps.p, 0, pb_stamps.bytes, stream));
         HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
         HIPC(hipMemcpyAsync(pb_sp.p, gsp.data(), sizeof(int32_t) * gsp.size(),
@@ -1936,9 +2143,13 @@ struct spfm_engine {
         int rc = ensure_pb_stream<T>(kPbPrbThreads / L);
         if (rc) return rc;
         const int G = pb_stream_G;
-        hipLaunchKernelGGL((pbcd_precompute_kernel<T, M>), dim3(cdiv(n * k, kBlock)), dim3(kBlock),
-                           0, stream, n, k, rptr.as<int64_t>(), ridx.as<int32_t>(), rval.as<T>(),
-                           Po, A.as<T>());
+        // the rows' state as packed records (cache values, yhat, y: one line per row at k <= 30,
+        // degree 2, float): the precompute pass of pbcd.py:18-33 writes them
+        constexpr int AS = Kind<M>::AS;
+        HIPC(pb_rec.alloc(sizeof(T) * (size_t)n * AS * L + 256));
+        hipLaunchKernelGGL((pbprb_pack_kernel<T, M, L>), dim3(cdiv(n * L, kBlock)), dim3(kBlock), 0,
+                           stream, n, k, rptr.as<int64_t>(), ridx.as<int32_t>(), rval.as<T>(), Po,
+                           yy.as<T>(), pb_rec.as<T>());
         const bool chained = (reg == SPFM_REG_SQUAREDL21 || reg == SPFM_REG_OMEGACS);
         if (chained) {
             hipLaunchKernelGGL(pbcd_norms_kernel, dim3(cdiv((int64_t)d * 64, kBlock)),
@@ -1951,11 +2162,12 @@ struct spfm_engine {
         HIPC(hipMemsetAsync(pb_slabA.p, 0, sizeof(double) * 2 * 64 * (size_t)G * L, stream));
         HIPC(hipMemsetAsync(pb_slabB.p, 0, sizeof(double) * 2 * 64 * L, stream));
         {
-            int prc = peer_clear(kPeerPbOff, kPeerDoubles - kPeerPbOff);
+            int prc = peer_clear(kPeerPbOff, kPeerProbeOff - kPeerPbOff);
             if (prc) return prc;
         }
         PbPrbArgs a;
         a.G = G;
+        a.GO = pb_GO;
         a.nb = n_batches();
         a.bptr = d_bptr.as<int32_t>();
         a.jsched = d_order.as<int32_t>();
@@ -1967,6 +2179,7 @@ struct spfm_engine {
         a.rows_per = (int)std::max<int64_t>((n + G - 1) / G, 1);
         a.n_rows = (int)n;
         a.abort_flag = prb_abort.as<unsigned>();
+        a.spin_max = spin_max;
         a.n_ranks = peer_ready ? n_ranks : 1;
         a.rank = rank;
         a.slabC = peer_ready ? peer_tab_pb.as<double*>() : nullptr;
@@ -1983,13 +2196,19 @@ struct spfm_engine {
         a.dbg_out = pb_dbgbuf.as<unsigned>();
         const int ncache = top_degree > 0 ? top_degree + 1 : 1;
         prof_begin(2, nnz);
-        auto go = [&](auto stamp_tag) -> int {
+        auto go = [&](auto stamp_tag, auto down_tag) -> int {
             constexpr bool STc = decltype(stamp_tag)::value;
+            constexpr bool DWc = decltype(down_tag)::value;
             const size_t lds = std::max(kPrbLds, pbcd_prb_lds_bytes<T, M, L>());
-            HIPC(hipFuncSetAttribute((const void*)pbcd_prb_kernel<T, M, L, STc>,
+            const int grid = G + (DWc ? pb_GO : 0);
+            HIPC(hipFuncSetAttribute((const void*)pbcd_prb_kernel<T, M, L, STc, DWc>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((pbcd_prb_kernel<T, M, L, STc>), dim3(G), dim3(kPbPrbThreads),
-                               lds, stream, a, pb_eval.as<T>(), A.as<T>(), yy.as<T>(), Po, k, d,
+            if (!resident_ok((const void*)pbcd_prb_kernel<T, M, L, STc, DWc>, kPbPrbThreads, lds,
+                             grid))
+                return kNotResident;
+            hipLaunchKernelGGL((pbcd_prb_kernel<T, M, L, STc, DWc>), dim3(launch_groups(grid)),
+                               dim3(kPbPrbThreads),
+                               lds, stream, a, pb_eval.as<T>(), pb_rec.as<T>(), Po, k, d,
                                lams.as<double>(), loss, reg, rs, ncache, mu, beta, gamma, eta,
                                prb_viol.as<double>());
             return SPFM_OK;
@@ -1997,13 +2216,23 @@ struct spfm_engine {
         constexpr bool can_stamp = std::is_same<T, float>::value && M == 2 && L == 32;
         if (pb_stamp_on && !can_stamp)
             FAIL(SPFM_ERR_UNSUPPORTED, "pbprb_stamps: built for float storage, degree 2, k <= 30");
+        const bool down = pb_GO > 0;
         if constexpr (can_stamp) {
-            rc = pb_stamp_on ? go(std::true_type{}) : go(std::false_type{});
+            if (pb_stamp_on)
+                rc = down ? go(std::true_type{}, std::true_type{})
+                          : go(std::true_type{}, std::false_type{});
+            else
+                rc = down ? go(std::false_type{}, std::true_type{})
+                          : go(std::false_type{}, std::false_type{});
         } else {
-            rc = go(std::false_type{});
+            rc = down ? go(std::false_type{}, std::true_type{})
+                      : go(std::false_type{}, std::false_type{});
         }
+        if (rc == kNotResident) prof_cancel(2, nnz);
         if (rc) return rc;
         prof_end(2);
+        hipLaunchKernelGGL((pbprb_unpack_kernel<T, AS, L>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                           n, pb_rec.as<T>(), yy.as<T>());
         hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
                            d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());
         HIPC(hipGetLastError());
@@ -2063,13 +2292,28 @@ struct spfm_engine {
         pbprb_active = 0;
         if (pbprb_usable(kind_of(degree))) {
             pbprb_active = 1;
+            double* Pt_epoch = Pt.as<double>() + (size_t)order_idx * k * d;
+            rc = snapshot_state(Pt_epoch, (size_t)k * d, snapP);
+            if (rc) return rc;
             rc = dtype == SPFM_F32
                      ? pbcd_prb_dispatch<float>(kind_of(degree), order_idx, beta, gamma, eta)
                      : pbcd_prb_dispatch<double>(kind_of(degree), order_idx, beta, gamma, eta);
+            if (rc == kNotResident) {  // nothing launched but the epoch's set-up kernels
+                mark_not_resident("persistent pbcd pass");
+                return pbcd_epoch(order_idx, degree, beta, gamma, eta, viol);
+            }
             if (rc) return rc;
             rc = epoch_epilogue(viol);
             if (rc) return rc;
-            return pb_check_abort();
+            bool aborted = false;
+            rc = persistent_aborted(&aborted);
+            if (rc) return rc;
+            if (aborted) {  // all-or-nothing (pbcd.py:82-148): back to the epoch's start, redo
+                rc = recover_from_abort(Pt_epoch, (size_t)k * d, snapP, "persistent pbcd pass");
+                if (rc) return rc;
+                return pbcd_epoch(order_idx, degree, beta, gamma, eta, viol);
+            }
+            return SPFM_OK;
         }
         const std::string key = fkey("pbcd", {beta, gamma, eta},
                                      {order_idx, degree, loss, reg, sched_version});
@@ -2439,6 +2683,11 @@ void spfm_destroy(spfm_handle h) {
 
 const char* spfm_last_error(spfm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+#ifndef SPFM_BUILD_TAG
+#define SPFM_BUILD_TAG "untagged"
+#endif
+const char* spfm_build_tag(void) { return SPFM_BUILD_TAG; }
+
 int spfm_device_name(spfm_handle h, char* out, int cap) {
     if (!h || !out || cap <= 0) return SPFM_ERR_INVALID;
     snprintf(out, (size_t)cap, "%s", h->devname.c_str());
@@ -2673,14 +2922,17 @@ int spfm_peer_alloc(spfm_handle h, char* handle64) {
     if (!h->peer_own) {
         void* p = nullptr;
         // fine-grained device memory: remote stores become visible to local polling loads
-        // without a kernel boundary; plain hipMalloc is the fall-back
-        if (hipExtMallocWithFlags(&p, sizeof(double) * spfm_engine::kPeerDoubles,
-                                  hipDeviceMallocFinegrained) != hipSuccess) {
+        // without a kernel boundary.  There is NO coarse-grained fall-back: plain hipMalloc
+        // memory maps just as well over IPC, but does not promise that visibility, and the first
+        // persistent pass would spin into its time-out -- the caller takes the per-step
+        // collective instead when this fails (sparsepoly_amd.distributed.connect_peers).
+        hipError_t ae = hipExtMallocWithFlags(&p, sizeof(double) * spfm_engine::kPeerDoubles,
+                                              hipDeviceMallocFinegrained);
+        if (ae != hipSuccess) {
             (void)hipGetLastError();
-            if (hipMalloc(&p, sizeof(double) * spfm_engine::kPeerDoubles) != hipSuccess) {
-                h->err = "peer slab allocation failed";
-                return SPFM_ERR_RUNTIME;
-            }
+            h->err = std::string("peer slab: fine-grained device memory is not available (") +
+                     hipGetErrorString(ae) + "); use the per-step collective";
+            return SPFM_ERR_RUNTIME;
         }
         if (hipMemset(p, 0, sizeof(double) * spfm_engine::kPeerDoubles) != hipSuccess) {
             (void)hipFree(p);
@@ -2743,10 +2995,40 @@ int spfm_peer_connect(spfm_handle h, int n_ranks, int rank, const char* handles)
         h->err = "peer table upload failed";
         return SPFM_ERR_RUNTIME;
     }
+    // handshake: every rank's store into every slab must reach a kernel that is already polling
+    // (what the persistent passes assume); all ranks are in this call together
+    {
+        DevBuf okb;
+        int ok = 0;
+        h->peer_generation += 1;
+        const unsigned long long word = 0x5350464d00000000ull + (unsigned)h->peer_generation;
+        const unsigned long long ticks = 100ull * 1000 * 1000 * 10;  // 10 s of the 100 MHz counter
+        if (okb.alloc(sizeof(int) * 4) != hipSuccess ||
+            hipMemsetAsync(okb.p, 0, sizeof(int) * 4, h->stream) != hipSuccess) {
+            h->err = "peer handshake: allocation failed";
+            return SPFM_ERR_RUNTIME;
+        }
+        hipLaunchKernelGGL(peer_probe_kernel, dim3(1), dim3(kWave), 0, h->stream,
+                           h->peer_tab_pcd.as<double*>(),
+                           spfm_engine::kPeerProbeOff - spfm_engine::kPeerPcdOff, n_ranks, rank,
+                           word, ticks, okb.as<int>());
+        if (hipMemcpyAsync(&ok, okb.p, sizeof(int), hipMemcpyDeviceToHost, h->stream) !=
+                hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) {
+            h->err = "peer handshake kernel failed";
+            return SPFM_ERR_RUNTIME;
+        }
+        if (!ok) {
+            h->err = "peer handshake timed out: a peer's store into this GPU's exchange slab did "
+                     "not become visible to a running kernel (use the per-step collective)";
+            return SPFM_ERR_RUNTIME;
+        }
+    }
     h->peer_ready = true;
     h->have_schedule = false;  // the step cap depends on the engine: set the schedule again
     h->prb_ready = false;
     h->pb_stream_ready = false;
+    h->wide_ready = false;
     h->clear_graphs();
     return SPFM_OK;
 }
@@ -2795,6 +3077,16 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->prb_ready = false;
     } else if (k == "prb_stamps") {
         h->prb_stamp_on = value != 0;
+    } else if (k == "debug_spin_max") {  // test hook: polls before a persistent pass gives up
+        if (value < 64) {
+            h->err = "debug_spin_max must be >= 64";
+            return SPFM_ERR_INVALID;
+        }
+        h->spin_max = (unsigned)value;
+    } else if (k == "debug_drop_group") {  // test hook: the next `value` persistent launches
+        h->debug_drop = value;             // lack their last workgroup (they time out)
+    } else if (k == "persistent_failed") {  // 0: try the persistent passes again
+        h->pers_failed = value != 0;
     } else if (k == "psgd_graph_sweeps") {
         if (value < 0 || value > 64) {
             h->err = "psgd_graph_sweeps must be in 0..64";
@@ -2840,6 +3132,13 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->wide_stamp_on = value != 0;
     } else if (k == "pbprb_stamps") {
         h->pb_stamp_on = value != 0;
+    } else if (k == "pbprb_owners") {  // dedicated owner workgroups (default 0)
+        if (value < 0 || value > 64) {
+            h->err = "pbprb_owners must be in 0..64";
+            return SPFM_ERR_INVALID;
+        }
+        h->pbprb_owners = value;
+        h->pb_stream_ready = false;
     } else if (k == "pbprb_groups") {
         if (value < 1) {
             h->err = "pbprb_groups must be >= 1";
@@ -2886,9 +3185,15 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "wide_active") *value = h->have_schedule && h->wide_usable();
     else if (k == "wide_lds_active") *value = h->wide_lr_active;
     else if (k == "pbprb_groups") *value = h->pbprb_G;
+    else if (k == "pbprb_owners") *value = h->pb_GO;
     else if (k == "pbprb_active") *value = h->pbprb_active;
     else if (k == "persistent_active")
         *value = h->have_schedule && (h->prb_usable() || h->wide_usable());
+    else if (k == "persistent_fallbacks") *value = h->pers_fallbacks;
+    else if (k == "persistent_failed") *value = h->pers_failed;
+    else if (k == "n_ranks") *value = h->dist() ? h->n_ranks : 1;
+    else if (k == "peer_ready") *value = h->peer_ready;
+    else if (k == "wide_min_cols") *value = h->wide_min_cols;
     else {
         h->err = "unknown option: " + k;
         return SPFM_ERR_INVALID;
@@ -2915,7 +3220,7 @@ int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap) {
         return nv;
     }
     if (h->pb_stamp_on && h->pb_stream_ready && out) {  // persistent pbcd pass's timers
-        const int nv = 16 * h->pb_stream_G;
+        const int nv = 16 * (h->pb_stream_G + h->pb_GO);
         if (cap < nv) return SPFM_ERR_INVALID;
         if (hipMemcpy(out, h->pb_stamps.p, sizeof(long long) * (size_t)nv,
                       hipMemcpyDeviceToHost) != hipSuccess)
@@ -2990,6 +3295,7 @@ int spfm_debug_exchange_cost(spfm_handle h, int groups, int ncols, int readers_m
     a.G = groups;
     a.slab = slab.as<double>();
     a.abort_flag = abortw.as<unsigned>();
+    a.spin_max = 1u << 21;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
         return SPFM_ERR_RUNTIME;

@@ -450,7 +450,7 @@ __device__ __forceinline__ void pbcd_chain_serial_chunk(int lane, int cnt, bool 
         double strength;
         if (reg == REG_SQL21) {
             if (cache[0] < nj) {  // squaredl21.py:48-49
-                count_branch(BR_SQL21_RESUM, lane);
+                count_branch<PRIV>(BR_SQL21_RESUM, lane);
                 PBCD_FLUSH_NORMS
                 double a = 0.0;
                 for (int jj = lane; jj < d; jj += kWave) a += norm_at(jj, i, l2n_mine);
@@ -469,7 +469,7 @@ __device__ __forceinline__ void pbcd_chain_serial_chunk(int lane, int cnt, bool 
             for (int t = 1; t < kMaxDegree + 2; ++t)
                 if (t < top_ncache && dcache[t] < mn) mn = dcache[t];
             if (mn < 0) {  // omegacs.py:90-96
-                count_branch(BR_OMEGACS_DCACHE, lane);
+                count_branch<PRIV>(BR_OMEGACS_DCACHE, lane);
                 PBCD_FLUSH_NORMS
                 double cc[kMaxDegree + 2];
 #pragma unroll
@@ -519,7 +519,7 @@ __device__ __forceinline__ void pbcd_chain_serial_chunk(int lane, int cnt, bool 
             for (int t = 1; t < kMaxDegree + 2; ++t)
                 if (t < top_ncache && cache[t] < mn) mn = cache[t];
             if (mn < 0) {  // __recompute_cache_bcd(degree)
-                count_branch(BR_OMEGACS_CACHE, lane);
+                count_branch<PRIV>(BR_OMEGACS_CACHE, lane);
                 PBCD_FLUSH_NORMS
                 double cc[kMaxDegree + 2];
 #pragma unroll

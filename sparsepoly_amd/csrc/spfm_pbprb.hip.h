@@ -16,8 +16,19 @@ namespace spfm {
 // ---------------------------------------------------- persistent pbcd pass (PBPRB)
 //
 // pbcd.pbcd_epoch (optimizer/pbcd.py:82-148) as ONE launch.  Workgroup g owns the rows
-// [g*rows_per, (g+1)*rows_per): their state (A[i, :, :], yhat_i; 124 bytes per row at degree 2,
-// k = 30 -- no LDS residency) stays in global memory and is read and written by the owner only.
+// [g*rows_per, (g+1)*rows_per): their state stays in global memory (no LDS residency) and is read
+// and written by the owner only.
+//
+// Row records (round 3).  A row's state is ONE packed record of AS slices of L elements (L = the
+// lanes of a slot group, k <= L - 2): slice t holds A[i, t+1, 0..k) and zero padding; slice 0
+// carries yhat_i at lane L-2 and y_i at lane L-1.  float storage, k <= 30, degree 2: exactly
+// one 128-byte line per row -- the gather of a row (cache values AND prediction AND target) is
+// one line instead of a 120-byte run straddling two lines plus an 8-byte (yhat, y) word
+// elsewhere, and the scatter rewrites the whole line with one store instruction per group
+// (every lane its own element: the cache values, the padding, lane L-2 the updated yhat, lane
+// L-1 the target) instead of partial-line write-through stores of A and a 4-byte store of
+// yhat.  Packed by pbprb_pack_kernel (which is pbcd._precompute_A_all_degree, pbcd.py:18-33,
+// writing this layout) at the start of the epoch; pbprb_unpack_kernel returns yhat to `yy`.
 //
 // Exchange.  A step's payload is k + 1 sums per column (pbcd.py:60-67: grad[s] and
 // sum_s inv_step_sizes[s]), too much for the flat all-to-all of the pcd pass, so it is a
@@ -58,7 +69,9 @@ namespace spfm {
 // per-slot scalar sums (sum dA^2, did-the-block-move, ||Delta||_1) use a transposing butterfly.
 
 struct PbPrbArgs {
-    int G;                 // workgroups
+    int G;                 // row workgroups (each owns a block of rows)
+    int GO;                // dedicated owner workgroups in front of them in the grid (0: the row
+                           // workgroups own the slots themselves)
     int nb;                // steps in the sweep
     const int32_t* bptr;   // [nb+1]
     const int32_t* jsched; // [d] column ids in visiting order
@@ -69,6 +82,7 @@ struct PbPrbArgs {
     double* slabB;         // [2][64][L]    published block updates
     int rows_per, n_rows;
     unsigned* abort_flag;
+    unsigned spin_max;     // polls of one wait before the pass gives up (default 2^21)
     int n_ranks, rank;     // multi-GPU: ranks sharing the sweep
     double* const* slabC;  // [n_ranks] slabC[r] = GPU r's [2][64][n_ranks][L] (peer-mapped)
     long long* stamps;     // [G][16] diagnostic phase timers or nullptr
@@ -81,7 +95,7 @@ constexpr int kPbPrbThreads = 512;
 __device__ __forceinline__ bool pbprb_poll_fail(const PbPrbArgs& a, unsigned& spins) {
     if ((++spins & 63u) == 0) {
         if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-            spins > (1u << 21)) {
+            spins > a.spin_max) {
             __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return true;
         }
@@ -262,17 +276,260 @@ __device__ __forceinline__ void pbprb_chain_step(int lane, int ncols, int j, dou
     pbprb_chain_slow<M>(lane, ncols, j, njl, l2, st0, d, reg, rs, top_ncache, scal, state, l2n_out);
 }
 
+// pbcd._precompute_A_all_degree (pbcd.py:18-33; all-subsets: pbcd_all.py:9-20) writing the
+// packed row records of the persistent pass (see the header): thread per (row, lane of the
+// record); lanes < k run the row's DP for their component, lane L-2 / L-1 copy (yhat, y).
+template <typename T, int M, int L>
+__global__ __launch_bounds__(kBlock) void pbprb_pack_kernel(
+    int64_t n, int k, const int64_t* __restrict__ rptr, const int32_t* __restrict__ ridx,
+    const T* __restrict__ rval, const double* __restrict__ P /* (d,k) */,
+    const T* __restrict__ yy, T* __restrict__ R) {
+    constexpr int AS = Kind<M>::AS;
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (tid >= n * L) return;
+    const int64_t i = tid / L;
+    const int l = (int)(tid - i * L);
+    T* ri = R + (size_t)i * AS * L;
+    if (l >= k) {
+#pragma unroll
+        for (int t = 0; t < AS; ++t) ri[(size_t)t * L + l] = (T)0;
+        if (l == L - 2) ri[l] = yy[2 * (size_t)i];
+        if (l == L - 1) ri[l] = yy[2 * (size_t)i + 1];
+        return;
+    }
+    if constexpr (M == 0) {
+        double a = 1.0;
+        for (int64_t ii = rptr[i]; ii < rptr[i + 1]; ++ii)
+            a *= 1.0 + P[(size_t)ridx[ii] * k + l] * (double)rval[ii];
+        ri[l] = (T)a;
+    } else {
+        double a[M];
+        a[0] = 1.0;
+#pragma unroll
+        for (int t = 1; t < M; ++t) a[t] = 0.0;
+        for (int64_t ii = rptr[i]; ii < rptr[i + 1]; ++ii) {
+            const double p = P[(size_t)ridx[ii] * k + l];
+            const double x = (double)rval[ii];
+#pragma unroll
+            for (int t = M - 1; t >= 1; --t) a[t] += a[t - 1] * p * x;
+        }
+#pragma unroll
+        for (int t = 1; t < M; ++t) ri[(size_t)(t - 1) * L + l] = (T)a[t];
+    }
+}
+
+// the epoch's predictions back into `yy` (the other passes' home of (yhat, y))
+template <typename T, int AS, int L>
+__global__ void pbprb_unpack_kernel(int64_t n, const T* __restrict__ R, T* __restrict__ yy) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) yy[2 * (size_t)i] = R[(size_t)i * AS * L + (L - 2)];
+}
+
+// Dedicated OWNER workgroup o of the persistent pbcd pass (round 3; grid = GO owners + G row
+// workgroups).  With the slots owned by row workgroups, the owner's poll, reduction and step sit
+// on the critical path of a workgroup that also has rows to sum and scatter, and every other
+// workgroup waits for it; an owner without rows starts polling at once, and the row workgroups
+// issue their prefetch while the exchange is in flight.  Owner o serves the slots o, o + GO, ...
+// (< 64): per step and slot it sums the G partial vectors in fixed order, adds the other GPUs'
+// vectors, takes pbcd._update's step (pbcd.py:68-78) with the cache-independent part of
+// prox_bcd and publishes the result -- exactly the work of phase 2 below.
+template <typename T, int L, bool STAMP>
+__device__ __forceinline__ void pbprb_owner_role(const PbPrbArgs& a, int o, const double* __restrict__ P,
+                                                 int k, const double* __restrict__ lams, int reg,
+                                                 double mu, double beta, double gamma, double eta,
+                                                 double* lds) {
+    constexpr int NG = kPbPrbThreads / L;
+    double* sh_red = lds;  // [2][NG][L]
+    int* sh_ok = reinterpret_cast<int*>(lds + 2 * NG * L);
+    const int tid = threadIdx.x, lane = tid % L, grp = tid / L;
+    const bool kl = lane < k;
+    const double lam = kl ? lams[lane] : 0.0;
+    if (tid == 0) *sh_ok = 1;
+    __syncthreads();
+    long long acc[4] = {0, 0, 0, 0};
+    long long tprev = STAMP ? clock64() : 0;
+    int c0 = a.bptr[0], c1 = a.bptr[min(1, a.nb)];
+    int c2 = a.bptr[min(2, a.nb)], c3 = a.bptr[min(3, a.nb)];
+    int buf = 0;
+    bool alive = true;
+    for (int b = 0; b < a.nb && alive; ++b) {
+        const int ncols = c1 - c0;
+        const int c4 = a.bptr[min(b + 4, a.nb)];
+        const int nw = max(ncols, c3 - c2);  // slots (re)written this step, see the row role
+        const unsigned long long tag = prb_tag(b);
+        const int par = b & 1;
+        const double* slabA = a.slabA + (size_t)par * 64 * a.G * L;
+        double* slabB = a.slabB + (size_t)par * 64 * L;
+        if (o >= ncols) {
+            // No slot of this step to wait for -- but an owner must never run ahead of the row
+            // workgroups: its zero-rewrites below would clobber slabB words that a step still in
+            // progress has to read, and the tags repeat every six steps.  Pace on the step
+            // itself: the slot-0 vector of one row workgroup (slot 0 is written at every step).
+            // Any one will do: a row workgroup that has published step b has collected step
+            // b-1, which needed every row workgroup's partials of step b-1, i.e. everybody is
+            // done with step b-2 -- the last user of this parity's buffers.
+            const double* pace = slabA + (size_t)(o % a.G) * L + lane;
+            unsigned spins = 0;
+            while ((prb_load_granule(pace) & 3ull) != tag) {
+                if (pbprb_poll_fail(a, spins)) {
+                    *sh_ok = 0;
+                    break;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!*sh_ok) {
+                alive = false;
+                break;
+            }
+        }
+        for (int q = o; q < nw; q += a.GO) {
+            if (q >= ncols) {
+                // slot unused in this step but read at the buffer's next use: rewritten now
+                if (grp == 0) {
+                    prb_store_granule(slabB + (size_t)q * L + lane, 0.0, tag);
+                    if (a.n_ranks > 1) {
+                        const size_t off = ((size_t)par * 64 + q) * a.n_ranks * L;
+                        for (int rr = 0; rr < a.n_ranks; ++rr)
+                            prb_store_granule_sys(a.slabC[rr] + off + (size_t)a.rank * L + lane, 0.0,
+                                                  tag);
+                    }
+                }
+                continue;
+            }
+            // the column's block (group 0's lanes), in flight during the poll
+            const int j = a.jsched[c0 + q];
+            const double pold = (grp == 0 && kl) ? P[(size_t)j * k + lane] : 0.0;
+            double* red = sh_red + (size_t)buf * NG * L;
+            buf ^= 1;
+            {   // group `grp` sums the source workgroups grp, grp + NG, ... in that order
+                double tot = 0.0;
+                constexpr int GU = (L == 32) ? 16 : 8;
+                for (int s0 = grp; s0 < a.G; s0 += NG * GU) {
+                    unsigned long long t[GU];
+                    unsigned spins = 0;
+                    bool ok = true;
+                    for (;;) {
+                        bool all = true;
+#pragma unroll
+                        for (int u = 0; u < GU; ++u) {
+                            const int src = s0 + u * NG;
+                            t[u] = (src < a.G)
+                                       ? prb_load_granule(slabA + ((size_t)q * a.G + src) * L + lane)
+                                       : tag;
+                            all = all && ((t[u] & 3ull) == tag);
+                        }
+                        if (all) break;
+                        if (pbprb_poll_fail(a, spins)) {
+                            ok = false;
+                            break;
+                        }
+                    }
+                    if (!ok) {
+                        *sh_ok = 0;
+                        break;
+                    }
+#pragma unroll
+                    for (int u = 0; u < GU; ++u)
+                        if (s0 + u * NG < a.G)
+                            tot += __longlong_as_double((long long)(t[u] & ~3ull));
+                }
+                red[grp * L + lane] = tot;
+            }
+            if constexpr (STAMP) {
+                if (tid == 0) {
+                    const long long tn = clock64();
+                    acc[0] += tn - tprev;
+                    tprev = tn;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // part sums in LDS
+            if (!*sh_ok) {
+                alive = false;
+                break;
+            }
+            if (grp == 0) {
+                double tot = red[lane];
+#pragma unroll
+                for (int w = 1; w < NG; ++w) tot += red[w * L + lane];
+                if (a.n_ranks > 1) {
+                    // one xGMI hop: this GPU's vector into every GPU's slabC[slot][rank], then
+                    // the n_ranks vectors of the own slabC summed in rank order
+                    const size_t off = ((size_t)par * 64 + q) * a.n_ranks * L;
+                    for (int rr = 0; rr < a.n_ranks; ++rr)
+                        prb_store_granule_sys(a.slabC[rr] + off + (size_t)a.rank * L + lane, tot, tag);
+                    double gt = 0.0;
+                    bool ok = true;
+                    const double* mine = a.slabC[a.rank];
+                    for (int rr = 0; rr < a.n_ranks && ok; ++rr) {
+                        unsigned long long t;
+                        unsigned spins = 0;
+                        for (;;) {
+                            t = prb_load_granule_sys(mine + off + (size_t)rr * L + lane);
+                            if ((t & 3ull) == tag) break;
+                            if (pbprb_poll_fail(a, spins)) {
+                                ok = false;
+                                break;
+                            }
+                        }
+                        gt += __longlong_as_double((long long)(t & ~3ull));
+                    }
+                    if (!ok) *sh_ok = 0;  // (seen at the next barrier; the abort word is set)
+                    tot = gt;
+                }
+                // pbcd._update (pbcd.py:68-79) up to the cache-dependent part of prox_bcd
+                const double hsum = pb_bcast<L>(tot, L - 2, grp);  // grp == 0 here
+                double inv = hsum * mu;
+                inv += beta;
+                const double st0 = eta * gamma / inv;
+                double v = 0.0;
+                if (kl) {
+                    double gr = tot * lam;
+                    gr += beta * pold;
+                    gr /= inv;
+                    v = pold - eta * gr;
+                    if (reg == REG_L1) {  // l1.py:44-45, element-wise
+                        const double sg = (v > 0) ? 1.0 : ((v < 0) ? -1.0 : 0.0);
+                        const double m = fabs(v) - st0;
+                        v = sg * (m > 0.0 ? m : 0.0);
+                    } else if (reg == REG_SQL21) {
+                        v /= 1 + 2 * st0;  // squaredl21.py:46
+                    }
+                }
+                const double l2 = sqrt(pb_group_allsum<L>(v * v));
+                const double outv = (lane == L - 2) ? l2 : ((lane == L - 1) ? st0 : v);
+                prb_store_granule(slabB + (size_t)q * L + lane, outv, tag);
+            }
+            if constexpr (STAMP) {
+                if (tid == 0) {
+                    const long long tn = clock64();
+                    acc[1] += tn - tprev;
+                    tprev = tn;
+                }
+            }
+        }
+        c0 = c1;
+        c1 = c2;
+        c2 = c3;
+        c3 = c4;
+    }
+    if (STAMP && a.stamps != nullptr && tid == 0) {
+        a.stamps[(size_t)(a.G + o) * 16 + 2] = acc[0];  // owner poll
+        a.stamps[(size_t)(a.G + o) * 16 + 3] = acc[1];  // reduce + step + publish
+    }
+}
+
 template <typename T>
 struct PbESet {  // lane u <-> entry e0 + u of the group (u < min(cnt, L))
     int e0, cnt;
     int row, meta;
     T x;
-    T yh, yt;
 };
 
-template <typename T, int M, int L, bool STAMP = false>
+// DOWN = true: the grid's first a.GO workgroups are dedicated owners (pbprb_owner_role), the
+// row workgroups behind them skip phase 2 altogether.
+template <typename T, int M, int L, bool STAMP = false, bool DOWN = false>
 __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
-    PbPrbArgs a, const T* __restrict__ eval, T* __restrict__ A, T* __restrict__ yy,
+    PbPrbArgs a, const T* __restrict__ eval, T* __restrict__ R /* packed row records */,
     double* __restrict__ P /* (d,k) */, int k, int d, const double* __restrict__ lams, int loss,
     int reg, RegState rs, int top_ncache, double mu, double beta, double gamma, double eta,
     double* __restrict__ viol_pos) {
@@ -285,6 +542,13 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     constexpr int ER = ER0 >= 8 ? (ER0 / 8) * 8 : (ER0 >= 4 ? 4 : (ER0 >= 2 ? 2 : 1));
     using ESet = PbESet<T>;
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    if constexpr (DOWN) {
+        if ((int)blockIdx.x < a.GO) {
+            pbprb_owner_role<T, L, STAMP>(a, (int)blockIdx.x, P, k, lams, reg, mu, beta, gamma, eta,
+                                          dyn_lds);
+            return;
+        }
+    }
     double* sh_red = dyn_lds;                    // [2][NG][L] owner part sums
     double* sh_pt = dyn_lds + 2 * NG * L;        // [64][L] published vectors of the step
     double* sh_scal = sh_pt + 64 * L;            // [64][4] l2, st0, f, -
@@ -294,16 +558,15 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     int* sh_ok = reinterpret_cast<int*>(sh_rm + 2 * NG * L);
     // row buffers [2][NW][ER][AS][64]: a wave's slice is written lane-linearly by LDS-DMA
     T* sh_rows = reinterpret_cast<T*>(sh_ok + 4);
-    const typename Vec2<T>::type* yy2 = reinterpret_cast<const typename Vec2<T>::type*>(yy);
-    const int g = blockIdx.x;
+    const int g = DOWN ? (int)blockIdx.x - a.GO : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid % L, grp = tid / L;
     const int wlane = tid & 63, wave = tid >> 6;
     const int gb = grp * L;  // the group's slice of the per-entry LDS arrays
-    const size_t rowlen = (size_t)AS * k;
+    constexpr size_t rowlen = (size_t)AS * L;  // elements of one packed row record
     const bool kl = lane < k;
     const double lam = kl ? lams[lane] : 0.0;
     const bool chained = (reg == REG_SQL21 || reg == REG_OMEGACS);
-    const bool fixed_owner = a.G >= 64;
+    const bool fixed_owner = !DOWN && a.G >= 64;
     const int oq = fixed_owner ? pbprb_owned_slot(a.G, g, 0) : -1;  // the slot this WG owns
     if (wave == 0 && wlane < 2 * (kMaxDegree + 2)) {
         const int t = wlane % (kMaxDegree + 2);
@@ -340,20 +603,14 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         s.row = v ? a.erow[e0 + lane] : 0;
         s.meta = v ? (int)a.emeta[e0 + lane] : 0;
         s.x = v ? eval[e0 + lane] : (T)0;
-        s.yh = (T)0;
-        s.yt = (T)0;
     };
     auto rows_at = [&](int par, int u, int t) __attribute__((always_inline)) -> T* {
         return sh_rows + ((((size_t)par * NW + wave) * ER + u) * AS + t) * 64;
     };
-    // rows (-> LDS buffer `par`) and lane-parallel (yhat, y) of a set; hz = 0: the entries not
-    // flagged, 1: the flagged ones (after the barrier that ends the step which updated them)
+    // packed rows of a set (-> LDS buffer `par`); hz = 0: the entries not flagged, 1: the flagged
+    // ones (after the barrier that ends the step which updated them).  Every lane fetches its own
+    // element of the record: the group's L lanes take one contiguous, aligned slice.
     auto fetch_rows = [&](ESet& s, int par, int hz) __attribute__((always_inline)) {
-        if (lane < s.cnt && ((s.meta >> 7) & 1) == hz) {
-            const typename Vec2<T>::type yv = yy2[s.row];
-            s.yh = yv.x;
-            s.yt = yv.y;
-        }
         const int2* rm_ = sh_rm + par * NG * L + gb;
         const int nf = min(s.cnt, ER);
         // wave-uniform trip count (the two groups of a wave differ in nf): the LDS-DMA's
@@ -369,17 +626,17 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
 #pragma unroll
             for (int uu = 0; uu < 4; ++uu) {
                 const int u = ub + uu;
-                if (u < nf && ((rm[uu].y >> 7) & 1) == hz && kl) {
+                if (u < nf && ((rm[uu].y >> 7) & 1) == hz) {
                     const size_t base = (size_t)rm[uu].x * rowlen + lane;
 #pragma unroll
                     for (int t = 0; t < AS; ++t) {
                         if constexpr (sizeof(T) == 4) {
                             // sc1: served by L2, past the CU's L1 (rows are read once)
-                            __builtin_amdgcn_global_load_lds(A + base + (size_t)t * k,
+                            __builtin_amdgcn_global_load_lds(R + base + (size_t)t * L,
                                                              rows_at(par, min(u, ER - 1), t), 4, 0,
                                                              16);
                         } else {
-                            rows_at(par, min(u, ER - 1), t)[wlane] = A[base + (size_t)t * k];
+                            rows_at(par, min(u, ER - 1), t)[wlane] = R[base + (size_t)t * L];
                         }
                     }
                 }
@@ -454,12 +711,17 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
 
         // ---- phase 0: rows this step shares with the previous one (after its barrier)
         fetch_rows(cur, par, 1);
-        {   // lane-parallel dloss and x -> LDS for the group's broadcast reads
-            const double dl = (lane < cur.cnt) ? dloss_dev(loss, (double)cur.yh, (double)cur.yt)
-                                                : 0.0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed in LDS
+        wave_lds_sync();
+        {   // lane u <-> entry u: dloss from the record's (yhat, y) (lanes L-2, L-1 of slice 0),
+            // with x -> LDS for the group's broadcast reads
+            double dl = 0.0;
+            if (lane < nfast) {
+                const T* r0 = rows_at(par, lane, 0) + (wlane - lane);
+                dl = dloss_dev(loss, (double)r0[L - 2], (double)r0[L - 1]);
+            }
             sh_xd[gb + lane] = make_double2((double)cur.x, dl);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed in LDS
         wave_lds_sync();
         PB_STAMP(0)
         // ---- phase 1: partial sums of the own rows (pbcd.py:56-67), published per slot
@@ -500,12 +762,11 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             const int i = a.erow[e];
             const int qi = (int)a.emeta[e] & 7;
             const double x = (double)eval[e];
-            const typename Vec2<T>::type yv = yy2[i];
-            const double dl = dloss_dev(loss, (double)yv.x, (double)yv.y);
+            const T* ri = R + (size_t)i * rowlen;
+            const double dl = dloss_dev(loss, (double)ri[L - 2], (double)ri[L - 1]);
             double ad[AS];
 #pragma unroll
-            for (int t = 0; t < AS; ++t)
-                ad[t] = kl ? (double)A[(size_t)i * rowlen + (size_t)t * k + lane] : 0.0;
+            for (int t = 0; t < AS; ++t) ad[t] = kl ? (double)ri[(size_t)t * L + lane] : 0.0;
             const double p = pb_sel(po, qi);
             const double dprev = kl ? grad_factor<M>(ad, x, p) : 0.0;
             pb_acc<QM>(gs, qi, dl * dprev);
@@ -531,7 +792,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         PB_STAMP(1)
 
         // ---- phase 2: owners reduce their slot over the workgroups and take the step
-        const int n_rounds = fixed_owner ? 1 : (nw + a.G - 1) / a.G;
+        const int n_rounds = DOWN ? 0 : (fixed_owner ? 1 : (nw + a.G - 1) / a.G);
         for (int r = 0; r < n_rounds; ++r) {
             const int q = fixed_owner ? oq : pbprb_owned_slot(a.G, g, r);
             const bool own = q >= 0 && q < ncols;
@@ -647,7 +908,11 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         // in front of the collect poll: vmcnt retires in order, so the first tag check waits for
         // these loads too -- but everybody waits about that long for the owners anyway.  (In
         // front of the owner poll it delays the owners themselves: 13.1 vs 12.4 us per step;
-        // behind the collect poll its issue time sits on the critical path: 14.1.)
+        // behind the collect poll its issue time sits on the critical path: 14.1.  Round 3:
+        // waves 1..7 polling at once with an empty load queue and prefetching during wave 0's
+        // chain instead: 12.1 vs 11.0 -- the totals arrive ~5 us after the publish whoever polls
+        // and however early; the exchange is bound by the burst of 2 MB of partial vectors that
+        // all workgroups write, and the owners read, at the same instant.)
         int b3e0, b3e1;
         bounds(b + 3, b3e0, b3e1);
         load_entries(nn, b2e0, b2e1);
@@ -758,11 +1023,10 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             }
         }
         {
-            // per slot (static registers po / up / lu), per entry: new cache row, then the
-            // prediction decrement sum_s lam_s Delta_s dA_s by one DPP all-reduce; the lane that
-            // holds the entry's yhat (lane u) applies it
-            double ynew = (double)cur.yh;
-            bool ymoved = false;
+            // per slot (static registers po / up / lu), per entry: the new record -- cache values
+            // in the component lanes, the prediction minus sum_s lam_s Delta_s dA_s (one DPP
+            // all-reduce) in lane L-2, the target in lane L-1, zeros in the padding -- written
+            // back as whole slices (slice 0 of float storage, k <= 30: one full 128-byte line)
 #pragma unroll
             for (int t = 0; t < QM; ++t) {
                 if (mv[t] == 0.0) continue;  // block did not move: exact no-op (group-uniform)
@@ -773,35 +1037,35 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                     double ad[AS];
 #pragma unroll
                     for (int tt = 0; tt < AS; ++tt) ad[tt] = (double)rows_at(par, u, tt)[wlane];
+                    // lane L-2 holds yhat_old in ad[0], lane L-1 the target
                     if constexpr (M == 0) {  // pbcd_all.py:121-127
                         const double a0 = kl ? ad[0] : 0.0;
                         double a1 = a0 / (1.0 + x * pol);
                         a1 *= 1.0 + x * pnl;
-                        if (kl) A[base] = (T)a1;
                         const double d_old = pb_group_allsum<L>(kl ? lam * a0 : 0.0);
                         const double d_new = pb_group_allsum<L>(kl ? lam * a1 : 0.0);
-                        if (lane == u) {
-                            ynew = (ynew - d_old) + d_new;
-                            ymoved = true;
-                        }
+                        double outv = kl ? a1 : 0.0;
+                        if (lane == L - 2) outv = (ad[0] - d_old) + d_new;
+                        if (lane == L - 1) outv = ad[0];
+                        R[base] = (T)outv;
                     } else {
+                        double nv[AS];
                         double dprev = x;
 #pragma unroll
                         for (int tt = 1; tt < M; ++tt) {
-                            const double avv = ad[tt - 1];
+                            const double avv = kl ? ad[tt - 1] : 0.0;
                             const double dcur = x * (avv - pol * dprev);
-                            if (kl) A[base + (size_t)(tt - 1) * k] = (T)(avv - upl * dprev);
+                            nv[tt - 1] = kl ? avv - upl * dprev : 0.0;
                             dprev = dcur;
                         }
                         const double dec = pb_group_allsum<L>(kl ? lul * dprev : 0.0);
-                        if (lane == u) {
-                            ynew -= dec;
-                            ymoved = true;
-                        }
+                        if (lane == L - 2) nv[0] = ad[0] - dec;
+                        if (lane == L - 1) nv[0] = ad[0];
+#pragma unroll
+                        for (int tt = 0; tt < AS; ++tt) R[base + (size_t)tt * L] = (T)nv[tt];
                     }
                 }
             }
-            if (ymoved) yy[2 * (size_t)cur.row] = (T)ynew;
         }
         for (int u = ER; u < cur.cnt; ++u) {  // slow path
             const int e = cur.e0 + u;
@@ -809,23 +1073,23 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             const int qi = (int)a.emeta[e] & 7;
             if (pb_sel(mv, qi) == 0.0) continue;
             const double x = (double)eval[e];
-            const double y0 = (double)yy[2 * (size_t)i];
+            T* ri = R + (size_t)i * rowlen;
+            const double y0 = (double)ri[L - 2];
             const double pol = pb_sel(po, qi), upl = pb_sel(up, qi);
-            const size_t base = (size_t)i * rowlen;
             if constexpr (M == 0) {
                 const double pnl = pb_sel(pn, qi);
                 double d_old = 0.0, d_new = 0.0;
                 if (kl) {
-                    const double a0 = (double)A[base + lane];
+                    const double a0 = (double)ri[lane];
                     double a1 = a0 / (1.0 + x * pol);
                     a1 *= 1.0 + x * pnl;
-                    A[base + lane] = (T)a1;
+                    ri[lane] = (T)a1;
                     d_old = lam * a0;
                     d_new = lam * a1;
                 }
                 d_old = group_sum(d_old, L);
                 d_new = group_sum(d_new, L);
-                if (lane == 0) yy[2 * (size_t)i] = (T)((y0 - d_old) + d_new);
+                if (lane == 0) ri[L - 2] = (T)((y0 - d_old) + d_new);
             } else {
                 const double lul = pb_sel(lu, qi);
                 double accv = 0.0;
@@ -833,15 +1097,15 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                     double dprev = x;
 #pragma unroll
                     for (int t = 1; t < M; ++t) {
-                        const double avv = (double)A[base + (size_t)(t - 1) * k + lane];
+                        const double avv = (double)ri[(size_t)(t - 1) * L + lane];
                         const double dcur = x * (avv - pol * dprev);
-                        A[base + (size_t)(t - 1) * k + lane] = (T)(avv - upl * dprev);
+                        ri[(size_t)(t - 1) * L + lane] = (T)(avv - upl * dprev);
                         dprev = dcur;
                     }
                     accv = lul * dprev;
                 }
                 accv = group_sum(accv, L);
-                if (lane == 0) yy[2 * (size_t)i] = (T)(y0 - accv);
+                if (lane == 0) ri[L - 2] = (T)(y0 - accv);
             }
         }
         PB_STAMP(7)

@@ -44,6 +44,7 @@ struct PcdwArgs {
     double* slabB;          // [2][32][32]    totals
     int rows_per, n_rows;
     unsigned* abort_flag;
+    unsigned spin_max;     // polls of one wait before the pass gives up (default 2^21)
     int n_ranks, rank;
     double* const* slabC;   // [n_ranks] peer-mapped [2][32][n_ranks][32]
     long long* stamps;      // diagnostic (STAMP instantiation): [G][16] cycles per phase, thread 0
@@ -73,7 +74,7 @@ constexpr int kPcdwEPT = 8;
 __device__ __forceinline__ bool pcdw_poll_fail(const PcdwArgs& a, unsigned& spins) {
     if ((++spins & 63u) == 0) {
         if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-            spins > (1u << 21)) {
+            spins > a.spin_max) {
             __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return true;
         }

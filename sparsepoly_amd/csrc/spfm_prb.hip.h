@@ -43,6 +43,7 @@ struct PrbArgs {
     int rows_per;          // rows per workgroup (row block g = [g*rows_per, (g+1)*rows_per))
     int n_rows;            // n_samples
     unsigned* abort_flag;  // [1]
+    unsigned spin_max;     // polls of one wait before the pass gives up (default 2^21)
     long long* stamps;     // diagnostic: [G][16] accumulated cycles per phase (8 control-wave,
                            // 8 worker-wave values), or nullptr
     // multi-GPU (n_ranks > 1): after the local sweep every workgroup holds this GPU's per-slot
@@ -138,7 +139,7 @@ __device__ __forceinline__ bool prb_cross_gpu(const PrbArgs& a, int g, int b, in
             if (all) break;
             if ((++spins & 63u) == 0) {
                 if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-                    spins > (1u << 21)) {
+                    spins > a.spin_max) {
                     __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                     return false;
@@ -227,7 +228,7 @@ __device__ __forceinline__ bool prb_collect_quarter(const PrbArgs& a, int b, int
                 if ((++spins & 63u) == 0) {
                     if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_AGENT) ||
-                        spins > (1u << 21)) {
+                        spins > a.spin_max) {
                         __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                         ok = false;
@@ -1093,7 +1094,7 @@ __device__ __forceinline__ bool prb_poll(const PrbArgs& a, const double* p,
         if (all) break;
         if ((++spins & 63u) == 0) {
             if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-                spins > (1u << 21)) {
+                spins > a.spin_max) {
                 __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
@@ -1214,6 +1215,38 @@ __global__ __launch_bounds__(768) void exchange_probe_kernel(PrbArgs a, int roun
         __syncthreads();
         if (!ok_flag) break;
     }
+}
+
+// ---- connect-time handshake of the in-kernel cross-GPU exchange ------------------------
+// What the persistent passes rely on, checked once per spfm_peer_connect: a system-scope store
+// into a peer-mapped slab becomes visible to a kernel that is ALREADY RUNNING on the owning GPU
+// and polls with system-scope loads (fine-grained memory; coarse-grained memory only promises
+// visibility at kernel boundaries).  Lane r stores `word` into rank r's probe region at this
+// rank's position and polls the own region at position r until rank r's word arrives; bounded
+// by wall-clock ticks (wall_clock64: the 100 MHz constant counter), since the ranks enter this kernel milliseconds
+// apart.  ok[0] = 1 when every rank's word arrived.
+__global__ __launch_bounds__(kWave) void peer_probe_kernel(double* const* slabs, size_t off,
+                                                           int n_ranks, int rank,
+                                                           unsigned long long word,
+                                                           unsigned long long max_ticks, int* ok) {
+    const int r = threadIdx.x;
+    bool good = true;
+    if (r < n_ranks) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(slabs[r] + off) + rank, word,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long* mine =
+            reinterpret_cast<const unsigned long long*>(slabs[rank] + off) + r;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != word) {
+            if (wall_clock64() - t0 > max_ticks) {
+                good = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    const bool all = __all(good);
+    if (threadIdx.x == 0) ok[0] = all ? 1 : 0;
 }
 
 // out[pos] = v[desc[pos].j]

@@ -49,12 +49,9 @@ def _case(seed):
                 gamma=float(rng.choice([1e-3, 1e-2, 0.1])), alpha=float(rng.choice([1e-2, 1.0])))
 
 
-@pytest.mark.parametrize("precision", ["f64", "f32"])
-@pytest.mark.parametrize("seed", range(42))
-def test_random_problem_matches_oracle(oracle, seed, precision):
+def _check_case(oracle, c, precision, seed, extra_opts=None):
     from sparsepoly_amd.engine import HipEngine
 
-    c = _case(seed)
     if precision == "f32":  # float storage (LDS-resident row blocks where they apply)
         c["X"].data[:] = c["X"].data.astype(np.float32)
         c["y"] = c["y"].astype(np.float32).astype(np.float64)
@@ -65,7 +62,9 @@ def test_random_problem_matches_oracle(oracle, seed, precision):
     P0 = 0.05 * rng.randn(n_orders, k, d)
     lams = np.sign(rng.randn(k))
     eng = HipEngine(0, precision)
-    for key, val in c["opts"].items():
+    opts = dict(c["opts"])
+    opts.update(extra_opts or {})
+    for key, val in opts.items():
         eng.set_option(key, val)
     eng.set_data(X, y)
     eng.set_params(P0, np.zeros(d), lams)
@@ -84,6 +83,8 @@ def test_random_problem_matches_oracle(oracle, seed, precision):
         viol.append(v)
     P, w = eng.get_params()
     yp = eng.get_y_pred()
+    info = dict(fallbacks=eng.get_option("persistent_fallbacks"),
+                pbprb=eng.get_option("pbprb_active"))
     eng.close()
     fm = oracle.OracleFM(degree=degree, loss=c["loss"], n_components=k, solver=c["solver"],
                          regularizer=c["reg"], alpha=c["alpha"], beta=c["beta"], gamma=c["gamma"],
@@ -95,6 +96,35 @@ def test_random_problem_matches_oracle(oracle, seed, precision):
     np.testing.assert_allclose(w, fm.w_, rtol=0, atol=pa, err_msg=msg)
     np.testing.assert_allclose(viol, [h[0] for h in fm.history], rtol=vr, atol=pa, err_msg=msg)
     np.testing.assert_allclose(yp, fm.y_pred_, rtol=0, atol=ya, err_msg=msg)
+    return info
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("seed", range(42))
+def test_random_problem_matches_oracle(oracle, seed, precision):
+    _check_case(oracle, _case(seed), precision, seed)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("groups", [256, 200, 7])
+@pytest.mark.parametrize("seed", [3, 6])
+def test_regression_first_pbcd_cases_with_more_than_30_components(oracle, seed, groups, precision):
+    """The two shapes on which the persistent pbcd pass failed during its bring-up (round 2): the
+    first pbcd cases of this file's order, both with k = 33 components -- the 64-lane-per-group
+    instantiation (8 groups x 8 slots), which no other test reaches first -- on tiny matrices
+    where most of the 256 workgroups own no row (rows_per = 1) and a step has fewer columns than
+    slot groups:
+      seed 3: pbcd / l1, degree 2, 65 x 65, 473 entries (a process abort inside spfm_pbcd_epoch,
+              gpurun_out/t5.log 09:10 -- a device memory fault of the work-in-progress kernel, 22
+              minutes before its first commit 0bbb95f);
+      seed 6: pbcd / omegacs, degree 3 (explicit lower order), 64 x 2, 128 entries ("timed out
+              waiting for its workgroups", t8.log 09:42; fixed in f1c2ad3).
+    Here with the default, a non-power-of-two and a tiny workgroup count; the persistent pass must
+    run (no silent fallback) and equal the oracle.  The library now also checks the host-built
+    entry stream of such small problems against every bound the kernel indexes with
+    (validate_pb_stream) before the first launch."""
+    info = _check_case(oracle, _case(seed), precision, seed, {"pbprb_groups": groups})
+    assert info["pbprb"] == 1 and info["fallbacks"] == 0, info
 
 
 @pytest.mark.parametrize("seed", range(24))

@@ -57,12 +57,18 @@ def _run(case, world, rank, shm_name, precision, engine="multi_kernel", hq=None)
     eng = HipEngine(0, precision)
     if engine == "multi_kernel":
         eng.set_option("persistent", 0)   # the multi-kernel engine in both runs
+    elif engine == "persistent_peer_owners":
+        # persistent pbcd pass with DEDICATED owner workgroups (48 owners + 80 row workgroups
+        # per rank; two co-resident kernels fill the 256 CUs), cross-GPU stage in the owners
+        eng.set_option("pbprb_groups", 128)
+        eng.set_option("pbprb_owners", 48)
+        eng.set_option("pcdw_groups", 64)
     else:
         eng.set_option("pbprb_groups", 64)  # two co-resident persistent kernels: 2 x 64 CUs
         eng.set_option("pcdw_groups", 64)
     if world > 1:
         eng.comm_init_shm(shm_name, world, rank)
-        if engine == "persistent_peer":
+        if engine.startswith("persistent_peer"):
             mine = eng.peer_alloc()
             for r in range(world):
                 if r != rank:
@@ -91,9 +97,10 @@ def _run(case, world, rank, shm_name, precision, engine="multi_kernel", hq=None)
     P, w = eng.get_params()
     yp = eng.get_y_pred()
     active = (eng.get_option("persistent_active"), eng.get_option("pbprb_active"))
+    extra = (eng.get_option("pbprb_owners"), eng.get_option("persistent_fallbacks"))
     eng.close()
     return dict(P=P, w=w, viol=np.array(viol), loss=np.array(losses), y_pred=yp, order=order,
-                rows=(lo, hi), active=active)
+                rows=(lo, hi), active=active, extra=extra)
 
 
 def _worker(case, world, rank, shm_name, precision, q, engine, hq):
@@ -103,8 +110,9 @@ def _worker(case, world, rank, shm_name, precision, q, engine, hq):
         q.put((rank, repr(e)))
 
 
-@pytest.mark.parametrize("engine", ["multi_kernel", "persistent_peer"])
-@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("case,engine",
+                         [(c, e) for c in sorted(CASES) for e in ("multi_kernel", "persistent_peer")]
+                         + [("pbcd_cs", "persistent_peer_owners")])
 def test_two_row_shards_on_one_gpu(oracle, case, engine):
     solver, reg, degree, k, loss, beta, gamma = CASES[case]
     shm_name = "/spfm_test_%d_%s_%s" % (os.getpid(), case, engine)
@@ -138,8 +146,11 @@ def test_two_row_shards_on_one_gpu(oracle, case, engine):
     assert np.array_equal(a["order"], b["order"])
     # equals the unsharded engine (summation order of the partial sums differs: 1e-10)
     one = _run(case, 1, 0, None, "f64", engine)
-    if engine == "persistent_peer":  # the persistent passes really ran, with two ranks
+    if engine.startswith("persistent_peer"):  # the persistent passes really ran, with two ranks
         assert a["active"] == ((1, 0) if solver == "pcd" else (1, 1)), a["active"]
+        assert a["extra"][1] == 0, a["extra"]       # no fallback to the multi-kernel engine
+        if engine == "persistent_peer_owners":
+            assert a["extra"][0] == 48, a["extra"]  # dedicated owner workgroups
     assert np.array_equal(one["order"], a["order"])
     np.testing.assert_allclose(a["P"], one["P"], rtol=0, atol=1e-10)
     np.testing.assert_allclose(a["w"], one["w"], rtol=0, atol=1e-10)

@@ -86,12 +86,15 @@ def test_eval_and_full_prox_against_definitions():
     assert np.isclose(R["l1"]().eval(P), np.abs(P).sum())
     assert np.isclose(R["l21"]().eval(P), np.linalg.norm(P, axis=1).sum())
     assert np.isclose(R["squaredl21"]().eval(P), np.linalg.norm(P, axis=1).sum() ** 2)
-    assert np.isclose(R["squaredl12"]().eval(P.T), (np.abs(P.T).sum(axis=1) ** 2).sum())
-    # e_2 of the magnitudes = ((sum)^2 - sum of squares) / 2
-    a = np.abs(P[:, 0])
-    assert np.isclose(R["omegati"]().eval(P[:, 0], 2), (a.sum() ** 2 - (a * a).sum()) / 2)
-    nrm = np.linalg.norm(P, axis=1)
-    assert np.isclose(R["omegacs"]().eval(P, 2), (nrm.sum() ** 2 - (nrm * nrm).sum()) / 2)
+    # P is (n_features, n_components) for eval (the reference's convention); squaredl12's default
+    # transpose=True squares the l1 norm of every component (column)
+    assert np.isclose(R["squaredl12"]().eval(P), (np.abs(P).sum(axis=0) ** 2).sum())
+    # e_2 of the magnitudes = ((sum)^2 - sum of squares) / 2, summed over the components
+    a = np.abs(P)
+    assert np.isclose(R["omegati"]().eval(P, 2),
+                      ((a.sum(axis=0) ** 2 - (a * a).sum(axis=0)) / 2).sum())
+    # (omegacs.eval reshapes its input instead of transposing it, omegacs.py:35: no closed form
+    # to compare with -- it is pinned by the reference's values in test_eval_equals_reference)
     # full-matrix prox: optimality of 0.5 ||U - V||^2 + c ||u||_1^2 per component (subgradient)
     c = 0.3
     V = P.copy()
@@ -128,3 +131,68 @@ def test_constraints_and_errors():
         REGULARIZATION["l21"]().init_cache_pcd(2, D, K)
     with pytest.raises(ValueError):
         REGULARIZATION["omegati"]().init_cache_pbcd(2, D, K)
+
+
+# ---------------------------------------------------------------- eval (g10: reference values)
+def _eval_cases():
+    for name in ("P2", "P3"):
+        yield "l1", name, {}, (2,)
+        for tr in (False, True):
+            for reg in ("l21", "squaredl12", "squaredl21"):
+                yield reg, name, {"transpose": tr}, ()
+        for deg in (2, 3, 4, -1):
+            yield "omegati", name, {}, (deg,)
+        for deg in (2, 3, 4):
+            yield "omegacs", name, {}, (deg,)
+
+
+@pytest.mark.parametrize("regname,pname,kwargs,args", list(_eval_cases()))
+def test_eval_equals_reference(regname, pname, kwargs, args):
+    """eval() with the reference's axis conventions ((..., n_features, n_components) input,
+    `transpose` swapping the roles of the axes; l1.py:17-18, l21.py:19-21, squaredl12.py:20-22,
+    squaredl21.py:23-25, omegati.py:19-47, omegacs.py:22-39) against values the reference's own
+    objects returned (oracle/gen_golden.py g10)."""
+    z = load_golden("g10_reg_eval.npz")
+    key = "%s|%s" % (regname, pname)
+    if "transpose" in kwargs:
+        key += "|t%d" % kwargs["transpose"]
+    if regname in ("omegati", "omegacs"):
+        key += "|deg%d" % args[0]
+    got = REGULARIZATION[regname](**kwargs).eval(z[pname], *args)
+    want = z[key]
+    assert np.shape(got) == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+
+
+def test_transpose_defaults_and_psgd_hooks():
+    """constructor defaults (squaredl12.py:17 transpose=True; l21.py:16, squaredl21.py:20 False),
+    the pbcd protocol refusing transposed group regularizers (l21.py:24-25, squaredl21.py:31-32),
+    init_cache_psgd present on the psgd regularizers, the all-subsets state attribute."""
+    assert REGULARIZATION["squaredl12"]().transpose is True
+    assert REGULARIZATION["l21"]().transpose is False
+    assert REGULARIZATION["squaredl21"]().transpose is False
+    for name in ("l21", "squaredl21"):
+        with pytest.raises(ValueError):
+            REGULARIZATION[name](True).init_cache_pbcd(2, D, K)
+    for name in ("l1", "l21", "squaredl12", "squaredl21"):
+        REGULARIZATION[name]().init_cache_psgd(2, D, K)
+    r = REGULARIZATION["squaredl12"](False)
+    r.init_cache_pcd(2, D, K)
+    assert r._cache.shape == (D,)
+    for name, init in (("omegati", "init_cache_pcd"), ("omegacs", "init_cache_pbcd")):
+        r = REGULARIZATION[name]()
+        getattr(r, init)(-1, D, K)
+        assert r._cache_all_subsets == 1.0
+
+
+def test_squaredl12_cache_update_order_is_the_references():
+    """squaredl12.py:47-50 subtracts the old magnitude, then adds the new one: (c - a) + b, which
+    is not bit-equal to c + (b - a)."""
+    r = REGULARIZATION["squaredl12"]()
+    r.init_cache_pcd(2, 3, 1)
+    P = np.array([[0.1, 1e-17, 0.3]])
+    r.compute_cache_pcd(P, 2, 0)
+    c0, a = r._cache[0], r._abs_p[1]
+    P[0, 1] = 0.7
+    r.update_cache_pcd(P, 2, 0, 1)
+    assert r._cache[0] == (c0 - a) + 0.7

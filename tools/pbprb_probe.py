@@ -27,6 +27,8 @@ for G in groups:
     for stamps in (0, 1):
         eng = HipEngine(0, "f32")
         eng.set_option("pbprb_groups", G)
+        if "PB_OWNERS" in os.environ:
+            eng.set_option("pbprb_owners", int(os.environ["PB_OWNERS"]))
         eng.set_option("pbprb_stamps", stamps)
         eng.set_option("pbprb_dbg", int(os.environ.get("PB_DBG", 0)))
         eng.set_data(Xc, y)
@@ -40,18 +42,26 @@ for G in groups:
         for _ in range(reps):
             v.append(eng.pbcd_epoch(0, 2, 1.0, 1e-3, 1.0))
         dt = (time.perf_counter() - t0) / reps
-        out = dict(G=G, stamps=stamps, reg=reg, ms_per_pbcd_epoch=round(dt * 1e3, 2),
+        out = dict(G=G, owners=eng.get_option("pbprb_owners"), stamps=stamps, reg=reg,
+                   ms_per_pbcd_epoch=round(dt * 1e3, 2),
                    steps=eng.n_batches, us_per_step=round(dt * 1e6 / eng.n_batches, 3),
                    active=eng.get_option("pbprb_active"), viol=[round(float(x), 3) for x in v])
         if int(os.environ.get("PB_DBG", 0)) & 8:
             out["dbg"] = [int(x) for x in eng.debug_prb_stamps().ravel()[:16]]
         elif stamps:
-            st = eng.debug_prb_stamps()[:, :10].astype(np.float64) / eng.n_batches
+            st_all = eng.debug_prb_stamps()[:, :10].astype(np.float64) / eng.n_batches
+            n_own = out["owners"]
+            st = st_all[:len(st_all) - n_own] if n_own else st_all   # row workgroups
+            own = st_all[len(st_all) - n_own:] if n_own else None
             scale = (dt * 1e9 / eng.n_batches) / st[0].sum()  # cycles -> ns via the wall time
             out["cycles_per_step_wg0"] = round(float(st[0].sum()))
             out["phase_ns_wg0"] = dict(zip(PHASES, [round(float(x * scale)) for x in st[0]]))
             out["phase_ns_wg1"] = dict(zip(PHASES, [round(float(x * scale)) for x in st[min(1, len(st) - 1)]]))
             out["phase_ns_mean"] = dict(zip(PHASES, [round(float(x * scale)) for x in st.mean(0)]))
             out["phase_ns_max"] = dict(zip(PHASES, [round(float(x * scale)) for x in st.max(0)]))
+            if own is not None:  # dedicated owners: poll (col 2), reduce + step + publish (col 3)
+                busy = own[own[:, 2] > 0]
+                out["owner_ns_mean"] = {"poll": round(float(busy[:, 2].mean() * scale)),
+                                        "reduce+step+publish": round(float(busy[:, 3].mean() * scale))}
         print(json.dumps(out), flush=True)
         eng.close()

@@ -443,9 +443,13 @@ def main():
         e2.pcd_epoch(0, DEGREE, cfg["beta"], cfg["gamma"], ETA0, ic[:3])
         torch.cuda.synchronize()
         t_pass = (time.perf_counter() - t1) / 3
+        relax_steps = int(e2.get_option("relax_steps"))
         e2.close()
         extras["exact_schedule"] = {
             "dependent_steps_per_sweep": nb2, "schedule_build_s": round(ts, 2),
+            # degree-2 pcd passes run the reference order as merged steps whose shared rows the
+            # chains replay; cd_linear keeps the strict steps
+            "merged_steps_per_pcd_sweep": relax_steps,
             "ms_per_iteration": round(1e3 * (t_lin + K * t_pass * (DEGREE - 1)), 1),
             "measured": "1 cd_linear epoch (%.0f ms) + 3 top-order component passes (%.0f ms "
                         "each), extrapolated to %d passes per order" % (1e3 * t_lin, 1e3 * t_pass, K),

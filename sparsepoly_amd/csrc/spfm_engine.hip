@@ -39,7 +39,11 @@ void build_pb_stream(int64_t, const int64_t*, const int32_t*, const std::vector<
                      std::vector<int32_t>&, std::vector<uint8_t>&);
 void build_rowblock_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
                            const std::vector<int32_t>&, int, int, std::vector<int32_t>&,
-                           std::vector<int32_t>&, std::vector<uint32_t>&);
+                           std::vector<int32_t>&, std::vector<uint32_t>&, const uint8_t*);
+void schedule_relax(int64_t, int32_t, const int64_t*, const int32_t*, const int32_t*, int, int,
+                    std::vector<int32_t>&, std::vector<int32_t>&, std::vector<int32_t>&,
+                    std::vector<int32_t>&, std::vector<int64_t>&, std::vector<int64_t>&,
+                    std::vector<int16_t>&, std::vector<uint8_t>&);
 }  // namespace spfm
 
 using namespace spfm;
@@ -234,6 +238,14 @@ struct spfm_engine {
     DevBuf wide_stamps;
     DevBuf w_rec;  // packed row records of the wide pcd pass (rows in global memory)
     static constexpr size_t kPrbLds = 84 * 1024;  // > half of the CU's 160 KiB: 1 WG per CU
+    // relaxed runs: for a schedule of tiny steps (the reference order: 2.6 columns
+    // per step) the degree-2 pcd pass merges consecutive steps into runs of ~20 columns whose few
+    // shared rows the chains replay; its own boundaries, entry stream and conflict tables
+    bool relax_on = true;
+    int relax_state = 0;  // 0 not tried for this schedule, 1 in use, -1 not worth it
+    std::vector<int32_t> r_batch_ptr;
+    int relax_has_long = 0;
+    DevBuf r_bptr, r_sp, r_erow, r_eval, r_lmask, r_cfptr, r_cf, r_clist, r_cslab;
     // wide persistent passes (spfm_pcdw.hip.h): steps of up to 512 columns, degree-2 pcd and
     // cd_linear; chosen when the schedule has a step of more than 64 columns
     bool wide_on = true;
@@ -883,6 +895,7 @@ struct spfm_engine {
         prb_ready = false;
         pb_stream_ready = false;
         wide_ready = false;
+        relax_state = 0;
         ++sched_version;
         clear_graphs();
         return alloc_work();
@@ -1402,7 +1415,7 @@ struct spfm_engine {
         std::vector<int32_t> sp, src;
         std::vector<uint32_t> lmask;
         build_rowblock_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, prb_G, prb_long,
-                              sp, src, lmask);
+                              sp, src, lmask, nullptr);
         prb_has_long = 0;
         for (uint32_t m : lmask) prb_has_long |= (m != 0u);
         HIPC(prb_lmask.alloc(sizeof(uint32_t) * lmask.size()));
@@ -1459,6 +1472,99 @@ struct spfm_engine {
         a.n_ranks = peer_ready ? n_ranks : 1;
         a.rank = rank;
         a.xslab = peer_ready ? peer_tab_pcd.as<double*>() : nullptr;
+        a.cf_ptr = nullptr;
+        a.cf = nullptr;
+        a.clist = nullptr;
+        a.cslab = nullptr;
+        return a;
+    }
+
+    // ---- relaxed runs for schedules of tiny steps (degree-2 pcd pass, one GPU)
+    // worth trying: the persistent 64-column pass is in use and the strict steps are narrow
+    bool relax_candidate() const {
+        return relax_on && prb_usable() && !dist() && n_batches() > 0 &&
+               (double)d / (double)n_batches() < 12.0;
+    }
+    template <typename T>
+    int ensure_relax() {
+        if (relax_state != 0) return SPFM_OK;
+        relax_state = -1;
+        int rc = ensure_prb<T>();  // workgroup count, col_norm / viol buffers, abort word
+        if (rc) return rc;
+        std::vector<int32_t> cf_ptr, cf_row, cf_qq, sp, src;
+        std::vector<int64_t> cf_ia, cf_ib;
+        std::vector<int16_t> clist;
+        std::vector<uint8_t> skip;
+        std::vector<uint32_t> lmask;
+        schedule_relax(n, d, h_cptr.data(), h_cidx.data(), order.data(), 64, 64, r_batch_ptr, cf_ptr,
+                       cf_row, cf_qq, cf_ia, cf_ib, clist, skip);
+        const int nbr = (int)r_batch_ptr.size() - 1;
+        if ((double)nbr > 0.6 * (double)n_batches()) return SPFM_OK;  // not worth a second stream
+        build_rowblock_stream(n, h_cptr.data(), h_cidx.data(), order, r_batch_ptr, prb_G, prb_long, sp,
+                              src, lmask, skip.data());
+        relax_has_long = 0;
+        for (uint32_t m : lmask) relax_has_long |= (m != 0u);
+        const size_t ne = src.size(), ncf = cf_row.size();
+        // the conflict rows' x values, in the storage type
+        std::vector<PrbConf<T>> hcf(ncf ? ncf : 1);
+        {
+            std::vector<T> hv((size_t)(nnz > 0 ? nnz : 1));
+            HIPC(hipMemcpy(hv.data(), cval.p, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToHost));
+            for (size_t c = 0; c < ncf; ++c) {
+                hcf[c].row = cf_row[c];
+                hcf[c].qq = cf_qq[c];
+                hcf[c].xa = hv[(size_t)cf_ia[c]];
+                hcf[c].xb = hv[(size_t)cf_ib[c]];
+            }
+        }
+        DevBuf d_src;
+        HIPC(d_src.alloc(sizeof(int32_t) * (ne ? ne : 1)));
+        HIPC(r_bptr.alloc(sizeof(int32_t) * r_batch_ptr.size()));
+        HIPC(r_sp.alloc(sizeof(int32_t) * sp.size()));
+        HIPC(r_lmask.alloc(sizeof(uint32_t) * lmask.size()));
+        HIPC(r_erow.alloc(sizeof(int32_t) * (ne ? ne : 1)));
+        HIPC(r_eval.alloc(sizeof(T) * (ne ? ne : 1)));
+        HIPC(r_cfptr.alloc(sizeof(int32_t) * cf_ptr.size()));
+        HIPC(r_cf.alloc(sizeof(PrbConf<T>) * hcf.size()));
+        HIPC(r_clist.alloc(sizeof(int16_t) * clist.size() + 16));
+        HIPC(r_cslab.alloc(sizeof(double) * 2 * 64 * 4));
+        HIPC(hipMemcpyAsync(r_bptr.p, r_batch_ptr.data(), sizeof(int32_t) * r_batch_ptr.size(),
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(r_sp.p, sp.data(), sizeof(int32_t) * sp.size(), hipMemcpyHostToDevice,
+                            stream));
+        HIPC(hipMemcpyAsync(r_lmask.p, lmask.data(), sizeof(uint32_t) * lmask.size(),
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(r_cfptr.p, cf_ptr.data(), sizeof(int32_t) * cf_ptr.size(),
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(r_cf.p, hcf.data(), sizeof(PrbConf<T>) * hcf.size(),
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(r_clist.p, clist.data(), sizeof(int16_t) * clist.size(),
+                            hipMemcpyHostToDevice, stream));
+        if (ne > 0) {
+            HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * ne, hipMemcpyHostToDevice,
+                                stream));
+            hipLaunchKernelGGL((prb_gather_kernel<T>), dim3(cdiv((int64_t)ne, 256)), dim3(256), 0,
+                               stream, (int64_t)ne, d_src.as<int32_t>(), cidx.as<int32_t>(),
+                               cval.as<T>(), r_erow.as<int32_t>(), r_eval.as<T>());
+            HIPC(hipGetLastError());
+        }
+        HIPC(hipStreamSynchronize(stream));
+        relax_state = 1;
+        return SPFM_OK;
+    }
+    PrbArgs relax_args() {
+        PrbArgs a = prb_args();
+        a.nb = (int)r_batch_ptr.size() - 1;
+        a.bptr = r_bptr.as<int32_t>();
+        a.sp = r_sp.as<int32_t>();
+        a.lmask = r_lmask.as<uint32_t>();
+        a.has_long = relax_has_long;
+        a.erow = r_erow.as<int32_t>();
+        a.stamps = nullptr;
+        a.cf_ptr = r_cfptr.as<int32_t>();
+        a.cf = r_cf.p;
+        a.clist = r_clist.as<int16_t>();
+        a.cslab = r_cslab.as<double>();
         return a;
     }
 
@@ -1483,13 +1589,23 @@ struct spfm_engine {
             FAIL(SPFM_ERR_UNSUPPORTED,
                  "prb_stamps: built for float storage, squared loss and degree 2 with prb_lds=1 "
                  "or degree 3 with prb_lds=0 only");
-        const PrbArgs pa = prb_args();
+        // relaxed runs: a schedule of tiny steps -- the reference order -- is run
+        // as merged steps of ~20 columns by the CR instantiation (degree 2, one GPU)
+        bool relaxed = false;
+        if constexpr (M == 2) {
+            if (relax_candidate() && !prb_stamp_on) {
+                rc = ensure_relax<T>();
+                if (rc) return rc;
+                relaxed = relax_state == 1;
+            }
+        }
+        const PrbArgs pa = relaxed ? relax_args() : prb_args();
         if (prb_stamp_on && pa.n_ranks > 1)
             FAIL(SPFM_ERR_UNSUPPORTED,
                  "prb_stamps: the timer instantiation has no cross-GPU stage (single rank only)");
         int lds_max = 0;
         HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
-        const size_t lds_lr = sizeof(double) * kPrbLdsFixed +
+        const size_t lds_lr = sizeof(double) * (kPrbLdsFixed + (relaxed ? kPrbLdsCR : 0)) +
                               (size_t)pa.rows_per * (4 * Kind<M>::AS + (LRV == 1 ? 4 : 5)) + 16;
         const bool use_lr = can_lr && prb_lds && lds_lr <= (size_t)lds_max &&
                             (LRV == 1 || y_pm1);
@@ -1506,6 +1622,7 @@ struct spfm_engine {
         hipLaunchKernelGGL(snapshot_row_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, c, Po, d,
                            d_desc.as<ColDesc>(), prow_old.as<double>());
         HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));  // tag 0 = "not yet"
+        if (relaxed) HIPC(hipMemsetAsync(r_cslab.p, 0, r_cslab.bytes, stream));
         {
             int prc = peer_clear(kPeerPcdOff, kPeerPbOff);
             if (prc) return prc;
@@ -1542,8 +1659,34 @@ struct spfm_engine {
         using std::integral_constant;
         int lrc = SPFM_OK;
         bool launched = false;
+        if constexpr (M == 2) {
+            if (relaxed) {
+                auto launch_cr = [&](auto lr_tag) -> int {
+                    constexpr int LRc = decltype(lr_tag)::value;
+                    const size_t lds = LRc != 0 ? lds_bytes : kPrbLds;
+                    auto* fn = pcd_prb_kernel<T, 2, LOSS, LRc, false, -1, false, true>;
+                    HIPC(hipFuncSetAttribute((const void*)fn,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    if (!resident_ok((const void*)fn, kPrbThreads, lds, prb_G)) return kNotResident;
+                    hipLaunchKernelGGL(fn, dim3(launch_groups(prb_G)), dim3(kPrbThreads), lds, stream,
+                                       c, pa, r_eval.as<T>(), A.as<T>(), (size_t)n * Kind<2>::AS,
+                                       yy.as<T>(), prow_old.as<double>(), Po, d, reg, cb, mu, beta,
+                                       gamma, eta, prb_viol.as<double>());
+                    return SPFM_OK;
+                };
+                launched = true;
+                bool done = false;
+                if constexpr (can_lr) {
+                    if (use_lr) {
+                        lrc = launch_cr(integral_constant<int, LRV>{});
+                        done = true;
+                    }
+                }
+                if (!done) lrc = launch_cr(integral_constant<int, 0>{});
+            }
+        }
         if constexpr (can_lr) {
-            if (use_lr) {
+            if (use_lr && !launched) {
                 launched = true;
                 if constexpr (can_stamp) {
                     if (prb_stamp_on)
@@ -3075,6 +3218,9 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         }
         h->prb_long = value;
         h->prb_ready = false;
+    } else if (k == "relax") {  // merged steps for schedules of tiny steps
+        h->relax_on = value != 0;
+        h->relax_state = 0;
     } else if (k == "prb_stamps") {
         h->prb_stamp_on = value != 0;
     } else if (k == "debug_spin_max") {  // test hook: polls before a persistent pass gives up
@@ -3189,6 +3335,9 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "pbprb_active") *value = h->pbprb_active;
     else if (k == "persistent_active")
         *value = h->have_schedule && (h->prb_usable() || h->wide_usable());
+    else if (k == "relax") *value = h->relax_on;
+    else if (k == "relax_steps")
+        *value = h->relax_state == 1 ? (int)h->r_batch_ptr.size() - 1 : 0;
     else if (k == "persistent_fallbacks") *value = h->pers_fallbacks;
     else if (k == "persistent_failed") *value = h->pers_failed;
     else if (k == "n_ranks") *value = h->dist() ? h->n_ranks : 1;

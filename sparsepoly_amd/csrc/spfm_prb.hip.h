@@ -52,6 +52,20 @@ struct PrbArgs {
     // slab in rank order -- one more hop, no collective, bit-identical totals on every GPU
     int n_ranks, rank;
     double* const* xslab;  // [n_ranks] peer pointers; xslab[r] = GPU r's [2][n_ranks][64][2]
+    // relaxed runs (CR instantiation of pcd_prb_kernel; spfm_schedule.cpp schedule_relax): the
+    // conflict rows of a step -- rows shared by two of its columns -- are not in the entry
+    // stream; their owners publish the row state, every workgroup's chain replays them
+    const int32_t* cf_ptr;  // [nb+1] conflict rows of a step
+    const void* cf;         // PrbConf<T>[]: row, slots of the two columns, their two x values
+    const int16_t* clist;   // [d][8] per column position: conflict index | role << 8, -1 none
+    double* cslab;          // [2][64][4] tagged granules: (yhat or residual, y, A[i,1]) of a row
+};
+
+template <typename T>
+struct __attribute__((aligned(8))) PrbConf {
+    int32_t row;
+    int32_t qq;  // slot of the earlier column | slot of the later column << 8
+    T xa, xb;    // the row's entries in the two columns
 };
 
 
@@ -249,6 +263,53 @@ __device__ __forceinline__ bool prb_collect_quarter(const PrbArgs& a, int b, int
     return ok;
 }
 
+// One column's step, prox and cache update of pcd._update (pcd.py:61-68; l1.py:32-33,
+// squaredl12.py:47-57, omegati.py:76-99 at degree 2), wave-uniform: the serial form of
+// pcd_chain_lanes<2> used by the relaxed-run chain, where a column's sums depend on the
+// deltas of the columns in front of it.  `cache` as in pcd_chain_lanes.
+__device__ __forceinline__ double pcd_prox_one2(int reg, double p_old, double g, double h,
+                                                double lam, double mu, double beta, double gamma,
+                                                double eta, double (&cache)[3], int lane) {
+    double inv = h * mu;
+    inv += beta;
+    double upd = g * lam;
+    upd += beta * p_old;
+    const double rinv = recip_nr(inv);
+    upd *= rinv;
+    const double pin = p_old - eta * upd;
+    const double st = (eta * gamma) * rinv;
+    if (reg == REG_L1) {
+        const double sg = (pin > 0) ? 1.0 : ((pin < 0) ? -1.0 : 0.0);
+        const double m = fabs(pin) - st;
+        return sg * (m > 0.0 ? m : 0.0);
+    }
+    const double ab = fabs(p_old);
+    if (reg == REG_SQL12) {
+        const double den = 1 + 2 * st;
+        const double rden = recip_nr(den);
+        const double pp = pin * rden;
+        const double app = fabs(pp);
+        const double tt = (2 * st) * rden;
+        const double sg = (pp > 0) ? 1.0 : -1.0;
+        const double others = cache[0] - ab;
+        const double m = fma(-tt, others, app);
+        const double r = (m > 0) ? m : 0.0;
+        cache[0] = others + r;
+        return sg * r;
+    }
+    // REG_OMEGATI, degree 2: u = max(c - a, 0); r = max(|p| - s u, 0); c' = u + r
+    const double apin = fabs(pin);
+    const double sg = (pin > 0) ? 1.0 : -1.0;
+    const double v = cache[1] - ab;
+    const bool pos = !(v < 0);
+    const double u = pos ? v : 0.0;
+    const double m = apin - st * u;
+    const double r = (m > 0) ? m : 0.0;
+    if (!pos) count_branch(BR_OMEGATI_CLIP, lane);
+    cache[1] = u + r;
+    return sg * r;
+}
+
 // The entries one thread owns in one step: 4 lanes share a slot, each keeps up to
 // PRB_PF entries (row, value) in registers; a slot with more than 4*PRB_PF entries in
 // this row block falls back to a reload loop for the rest.
@@ -339,7 +400,15 @@ constexpr int kPrbLdsFixed = 2560;  // doubles of fixed LDS (control data, part 
 // regularizer's code: -3.6 % per step on config 2); REGC = -1: taken from the argument.
 // MG = true: several GPUs share the sweep (cross-GPU stage behind the local sweep); a separate
 // instantiation, because even a never-taken branch in the control wave cost 2 % per step.
-template <typename T, int M, int LOSS, int LR, bool STAMP = false, int REGC = -1, bool MG = false>
+template <int NV>
+__device__ __forceinline__ bool prb_poll(const PrbArgs& a, const double* p, unsigned long long tag,
+                                         double* out);
+
+// CR = true: relaxed runs (steps whose columns may share rows, see PrbArgs / schedule_relax);
+// degree 2, single GPU.
+constexpr int kPrbLdsCR = 768;  // extra doubles of fixed LDS of the CR instantiation
+template <typename T, int M, int LOSS, int LR, bool STAMP = false, int REGC = -1, bool MG = false,
+          bool CR = false>
 __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     const Ctl* __restrict__ ctl, PrbArgs a, const T* __restrict__ eval, T* __restrict__ A_all,
     size_t a_stride, T* __restrict__ yy, const double* __restrict__ pold_sched,
@@ -373,8 +442,15 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                               (LR == 2 || LOSS == LOSS_SQUARED)),
                   "LDS-resident rows: float storage, one or two cache values per row");
     constexpr int AS = Kind<M>::AS;
+    static_assert(!CR || (M == 2 && !MG && !STAMP), "relaxed runs: degree 2, single GPU");
     const int row0 = LR ? g * a.rows_per : 0;
-    T* lds_a = reinterpret_cast<T*>(dyn_lds + kPrbLdsFixed);  // [rows_per][AS] A[i, 1..AS]
+    // CR: conflict-row tables of the step, behind the fixed block
+    double* sh_cs = dyn_lds + kPrbLdsFixed;            // [64][3] published state of the rows
+    double* sh_ci = sh_cs + 192;                       // [64][4] qa, qb, xa, xb
+    short* sh_cl = reinterpret_cast<short*>(sh_ci + 256);  // [64][8] per column: index | role << 8
+    double* sh_tot = sh_ci + 256 + 128;                // [64][2] column totals
+    int* sh_j = reinterpret_cast<int*>(sh_tot + 128);  // [64] column ids (workgroup 0)
+    T* lds_a = reinterpret_cast<T*>(dyn_lds + kPrbLdsFixed + (CR ? kPrbLdsCR : 0));  // [rows_per][AS] A[i, 1..AS]
     T* lds_r = lds_a + (size_t)a.rows_per * AS;                // [rows_per] residual or yhat
     unsigned char* lds_s = reinterpret_cast<unsigned char*>(lds_r + a.rows_per);  // y > 0
     if constexpr (LR != 0) {
@@ -408,6 +484,26 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     if (tid == 0) {
         *sh_ok = 1;
         *sh_go = 0;
+    }
+    // CR: the control wave's view of the conflict rows: lane c <-> conflict c of step b (cfc)
+    // and b+1 (cfn), lane q <-> conflict list of column q (clq / clqn); cp0..cp3 = cf_ptr[b..b+3]
+    int cp0 = 0, cp1 = 0, cp2 = 0, cp3 = 0;
+    PrbConf<T> cfc, cfn;
+    cfc.row = cfn.row = 0;
+    cfc.qq = cfn.qq = 0;
+    cfc.xa = cfc.xb = cfn.xa = cfn.xb = (T)0;
+    prb_u4 clq = {~0u, ~0u, ~0u, ~0u}, clqn = {~0u, ~0u, ~0u, ~0u};
+    if constexpr (CR) {
+        if (control) {
+            const PrbConf<T>* cfa = reinterpret_cast<const PrbConf<T>*>(a.cf);
+            cp0 = a.cf_ptr[0];
+            cp1 = a.cf_ptr[min(1, a.nb)];
+            cp2 = a.cf_ptr[min(2, a.nb)];
+            cp3 = a.cf_ptr[min(3, a.nb)];
+            if (lane < cp1 - cp0) cfc = cfa[cp0 + lane];
+            if (lane < c1 - c0)
+                clq = reinterpret_cast<const prb_u4*>(a.clist)[c0 + lane];
+        }
     }
     // diagnostic stamps (only when a.stamps != nullptr): cycles per phase, thread 0
     long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -457,6 +553,43 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             if (lane < ncols) {
                 pl = pold_sched[c0 + lane];
                 if (g == 0) jl = a.desc[c0 + lane].j;
+            }
+            if constexpr (CR) {
+                // conflict rows of this step: the owner publishes the row's state (as the
+                // workers would gather it); slots the buffer's next use will read are rewritten
+                // with zeros (stale tags, as for the column slots); tables -> LDS for the chain
+                const int nc = cp1 - cp0, ncw = max(nc, cp3 - cp2);
+                const unsigned long long ctag = prb_tag(b);
+                double* cs = a.cslab + (size_t)(b & 1) * 64 * 4 + (size_t)lane * 4;
+                if (lane < nc) {
+                    const int i = cfc.row;
+                    if (i / a.rows_per == g) {
+                        double y0, y1, a1;
+                        if constexpr (LR != 0) {
+                            y0 = (double)lds_r[i - row0];
+                            y1 = (LR == 1) ? 0.0 : (lds_s[i - row0] ? 1.0 : -1.0);
+                            a1 = (double)lds_a[i - row0];
+                        } else {
+                            const typename Vec2<T>::type yv = yy2[(size_t)i];
+                            y0 = (double)yv.x;
+                            y1 = (double)yv.y;
+                            a1 = (double)A[(size_t)i];
+                        }
+                        prb_store_granule(cs, y0, ctag);
+                        prb_store_granule(cs + 1, y1, ctag);
+                        prb_store_granule(cs + 2, a1, ctag);
+                    }
+                    sh_ci[lane * 4 + 0] = (double)(cfc.qq & 0xff);
+                    sh_ci[lane * 4 + 1] = (double)(cfc.qq >> 8);
+                    sh_ci[lane * 4 + 2] = (double)cfc.xa;
+                    sh_ci[lane * 4 + 3] = (double)cfc.xb;
+                } else if (lane < ncw && (lane % a.G) == g) {
+                    prb_store_granule(cs, 0.0, ctag);
+                    prb_store_granule(cs + 1, 0.0, ctag);
+                    prb_store_granule(cs + 2, 0.0, ctag);
+                }
+                *reinterpret_cast<prb_u4*>(sh_cl + lane * 8) = clq;
+                sh_j[lane] = jl;
             }
         } else if (worker) {
 #pragma unroll
@@ -630,6 +763,24 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             const bool ok = prb_collect_quarter<2>(a, b, part, lane, ncols, sh_quart, kPrbParts);
             if (!ok) *sh_ok = 0;
             PRB_HSTAMP(2)  // its part of the sweep
+            if constexpr (CR) {
+                if (control) {
+                    if (lane < cp1 - cp0) {  // the published states of the step's conflict rows
+                        double st3[3];
+                        if (!prb_poll<3>(a, a.cslab + (size_t)(b & 1) * 64 * 4 + (size_t)lane * 4,
+                                         prb_tag(b), st3))
+                            *sh_ok = 0;
+                        sh_cs[lane * 3 + 0] = st3[0];
+                        sh_cs[lane * 3 + 1] = st3[1];
+                        sh_cs[lane * 3 + 2] = st3[2];
+                    }
+                    // tables of step b+1 (consumed at its start)
+                    const PrbConf<T>* cfa = reinterpret_cast<const PrbConf<T>*>(a.cf);
+                    if (lane < cp2 - cp1) cfn = cfa[cp1 + lane];
+                    clqn = prb_u4{~0u, ~0u, ~0u, ~0u};
+                    if (lane < c2 - c1) clqn = reinterpret_cast<const prb_u4*>(a.clist)[c1 + lane];
+                }
+            }
         }
         // B3: part sums in LDS.  Raw barrier: only LDS traffic must have landed; the
         // prefetch loads just issued stay in flight across it (a __syncthreads() would
@@ -652,15 +803,111 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 if (!prb_cross_gpu<2>(a, g, b, lane, tot)) *sh_ok = 0;
             }
             const bool valid = lane < ncols;
-            const double res = pcd_chain_lanes<M>(REGC >= 0 ? REGC : reg, lane, ncols - 1, valid, pl,
-                                                  tot[0], tot[1],
-                                                  lam, mu, beta, gamma, eta, cache, sh_chain);
-            const double dl = valid ? (pl - res) : 0.0;
-            sh_delta[lane] = dl;
-            sh_pold[lane] = pl;
-            if (g == 0 && valid) {
-                ps[jl] = res;
-                viol_pos[c0 + lane] = fabs(dl);  // by position; folded into viol_col later
+            bool serial = false;
+            if constexpr (CR) serial = (cp1 - cp0) > 0;
+            if (!serial) {
+                const double res = pcd_chain_lanes<M>(REGC >= 0 ? REGC : reg, lane, ncols - 1, valid,
+                                                      pl, tot[0], tot[1], lam, mu, beta, gamma, eta,
+                                                      cache, sh_chain);
+                const double dl = valid ? (pl - res) : 0.0;
+                sh_delta[lane] = dl;
+                sh_pold[lane] = pl;
+                if (g == 0 && valid) {
+                    ps[jl] = res;
+                    viol_pos[c0 + lane] = fabs(dl);  // by position; folded into viol_col later
+                }
+            }
+            if constexpr (CR) {
+                if (serial) {
+                    // Relaxed run: the columns in order, one at a time (pcd.py:97-135 for the
+                    // rows that two columns of the step share).  A column's sums = the totals of
+                    // the row blocks (conflict rows left out) + its conflict rows replayed here
+                    // with the state the sequential sweep would find: the published state, after
+                    // the update of the row's EARLIER column when this is the later one.
+                    const int nc = cp1 - cp0;
+                    sh_tot[lane * 2] = tot[0];
+                    sh_tot[lane * 2 + 1] = tot[1];
+                    sh_pold[lane] = pl;
+                    sh_delta[lane] = 0.0;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    double cc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int t = 0; t <= M; ++t) cc[t] = cache[t];
+                    for (int q = 0; q < ncols; ++q) {
+                        double gq = sh_tot[2 * q], hq = sh_tot[2 * q + 1];
+                        const double plq = sh_pold[q];
+                        const int e = (lane < 8) ? (int)sh_cl[q * 8 + lane] : -1;
+                        double cg = 0.0, ch = 0.0;
+                        if (e >= 0) {
+                            const int c = e & 0xff;
+                            const double y0 = sh_cs[c * 3], y1 = sh_cs[c * 3 + 1],
+                                         a0 = sh_cs[c * 3 + 2];
+                            const double xa = sh_ci[c * 4 + 2], xb = sh_ci[c * 4 + 3];
+                            if ((e >> 8) == 0) {  // this column is the row's first
+                                const double dA = xa * (a0 - plq * xa);
+                                cg = dloss_dev(LOSS, y0, y1) * dA;
+                                ch = dA * dA;
+                            } else {  // the row as the earlier column left it (stored as T)
+                                const int qa = (int)sh_ci[c * 4];
+                                const double Da = sh_delta[qa], pa = sh_pold[qa];
+                                const double dAa = xa * (a0 - pa * xa);
+                                const double a1 = (double)(T)(a0 - Da * xa);
+                                const double y0n = (double)(T)(y0 - lam * Da * dAa);
+                                const double dAb = xb * (a1 - plq * xb);
+                                cg = dloss_dev(LOSS, y0n, y1) * dAb;
+                                ch = dAb * dAb;
+                            }
+                        }
+                        // lanes 0..7 -> every lane of the first row of 16 (fixed order)
+                        cg += dpp_move_d<0xB1, 0xf>(0.0, cg);
+                        ch += dpp_move_d<0xB1, 0xf>(0.0, ch);
+                        cg += dpp_move_d<0x4E, 0xf>(0.0, cg);
+                        ch += dpp_move_d<0x4E, 0xf>(0.0, ch);
+                        cg += dpp_move_d<0x124, 0xf>(0.0, cg);
+                        ch += dpp_move_d<0x124, 0xf>(0.0, ch);
+                        cg += dpp_move_d<0x128, 0xf>(0.0, cg);
+                        ch += dpp_move_d<0x128, 0xf>(0.0, ch);
+                        gq += readlane_d(cg, 0);
+                        hq += readlane_d(ch, 0);
+                        const double res = pcd_prox_one2(reg, plq, gq, hq, lam, mu, beta, gamma, eta,
+                                                         cc, lane);
+                        const double dlq = plq - res;
+                        if (lane == 0) {
+                            sh_delta[q] = dlq;
+                            if (g == 0) {
+                                ps[sh_j[q]] = res;
+                                viol_pos[c0 + q] = fabs(dlq);
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+#pragma unroll
+                    for (int t = 0; t <= M; ++t) cache[t] = cc[t];
+                    // the conflict rows' final state, by their owner: both updates in order
+                    if (lane < nc && cfc.row / a.rows_per == g) {
+                        const int i = cfc.row;
+                        const int qa = cfc.qq & 0xff, qb = cfc.qq >> 8;
+                        const double xa = (double)cfc.xa, xb = (double)cfc.xb;
+                        const double y0 = sh_cs[lane * 3], a0 = sh_cs[lane * 3 + 2];
+                        const double Da = sh_delta[qa], Db = sh_delta[qb];
+                        const double pa = sh_pold[qa], pb = sh_pold[qb];
+                        const double dAa = xa * (a0 - pa * xa);
+                        const double a1 = (double)(T)(a0 - Da * xa);
+                        const double y0n = (double)(T)(y0 - lam * Da * dAa);
+                        const double dAb = xb * (a1 - pb * xb);
+                        const T a2 = (T)(a1 - Db * xb);
+                        const T y0f = (T)(y0n - lam * Db * dAb);
+                        if constexpr (LR != 0) {
+                            lds_a[i - row0] = a2;
+                            lds_r[i - row0] = y0f;
+                        } else {
+                            A[(size_t)i] = a2;
+                            yy[2 * (size_t)i] = y0f;
+                        }
+                    }
+                }
             }
             PRB_STAMP(4)
         }
@@ -748,6 +995,16 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         ne1 = n2e1;
         lm0 = lm1;
         lm1 = lm2;
+        if constexpr (CR) {
+            if (control) {
+                cp0 = cp1;
+                cp1 = cp2;
+                cp2 = cp3;
+                cp3 = a.cf_ptr[min(b + 4, a.nb)];
+                cfc = cfn;
+                clq = clqn;
+            }
+        }
         c0 = c1;
         c1 = c2;
         c2 = c3;

@@ -46,6 +46,100 @@ void schedule_exact(int64_t n_rows, int32_t d, const int64_t* cptr, const int32_
     batch_ptr.push_back(d);
 }
 
+// RELAXED runs for the reference order (round 3).  `schedule_exact` cuts the visiting
+// order into maximal runs of pairwise row-disjoint columns -- 2.6 columns on BASELINE config 2,
+// so a sweep is 38 000 dependent steps that each pay a full exchange.  A relaxed run keeps
+// adding consecutive columns although they share a few rows with earlier columns of the run;
+// those CONFLICT ROWS are taken out of the row blocks' parallel partial sums and replayed, in
+// column order and with their true intermediate state, by the (redundant, local) chain of
+// every workgroup -- the dependency no longer crosses the exchange.  Same result as the
+// sequential sweep; ~20 columns per step.  Limits that keep the chain's tables small: <= 64
+// columns and <= `max_conf` conflict rows per run, a row touched by at most TWO columns of a run,
+// <= 8 conflict rows per column.
+//   rbptr            run boundaries over `order` (positions)
+//   cf_ptr[run+1]    conflict rows of a run: cf_row, cf_qq (slot of the earlier column | slot
+//                    of the later one << 8), cf_ia / cf_ib (CSC positions of the two entries)
+//   clist[pos*8+t]   the conflict rows of the column at position pos: index inside its run's
+//                    list | role << 8 (0 earlier, 1 later column of the row), -1 = none
+//   skip[ii]         1: CSC entry ii lies on a conflict row of its run (not in the entry stream)
+void schedule_relax(int64_t n_rows, int32_t d, const int64_t* cptr, const int32_t* cidx,
+                    const int32_t* order, int max_cols, int max_conf,
+                    std::vector<int32_t>& rbptr, std::vector<int32_t>& cf_ptr,
+                    std::vector<int32_t>& cf_row, std::vector<int32_t>& cf_qq,
+                    std::vector<int64_t>& cf_ia, std::vector<int64_t>& cf_ib,
+                    std::vector<int16_t>& clist, std::vector<uint8_t>& skip) {
+    constexpr int kPerCol = 8;
+    std::vector<int32_t> row_run((size_t)n_rows, -1), row_slot((size_t)n_rows, 0);
+    std::vector<uint8_t> row_cnt((size_t)n_rows, 0);
+    std::vector<int64_t> row_pos((size_t)n_rows, 0);
+    rbptr.assign(1, 0);
+    cf_ptr.assign(1, 0);
+    cf_row.clear();
+    cf_qq.clear();
+    cf_ia.clear();
+    cf_ib.clear();
+    clist.assign((size_t)d * kPerCol, (int16_t)-1);
+    skip.assign((size_t)cptr[d], 0);
+    int32_t run = 0, start = 0;
+    int percol[64];
+    for (int t = 0; t < 64; ++t) percol[t] = 0;
+    int nconf = 0;
+    int extra[64];
+    for (int32_t pos = 0; pos < d; ++pos) {
+        const int32_t j = order[pos];
+        int q = pos - start;
+        bool close = q >= max_cols;
+        if (!close && q > 0) {  // would the column fit the run's limits?
+            for (int t = 0; t < q; ++t) extra[t] = 0;
+            int mine = 0;
+            for (int64_t ii = cptr[j]; ii < cptr[j + 1] && !close; ++ii) {
+                const int32_t i = cidx[ii];
+                if (row_run[(size_t)i] != run) continue;
+                if (row_cnt[(size_t)i] >= 2) {
+                    close = true;  // a third column on the row
+                    break;
+                }
+                ++mine;
+                const int qa = row_slot[(size_t)i];
+                if (percol[qa] + (++extra[qa]) > kPerCol) close = true;
+            }
+            if (mine > kPerCol || nconf + mine > max_conf) close = true;
+        }
+        if (close) {
+            cf_ptr.push_back((int32_t)cf_row.size());
+            rbptr.push_back(pos);
+            ++run;
+            start = pos;
+            q = 0;
+            nconf = 0;
+            for (int t = 0; t < 64; ++t) percol[t] = 0;
+        }
+        for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
+            const int32_t i = cidx[ii];
+            if (row_run[(size_t)i] == run) {  // second column of this run on row i
+                const int qa = row_slot[(size_t)i];
+                const int c = nconf++;
+                cf_row.push_back(i);
+                cf_qq.push_back(qa | (q << 8));
+                cf_ia.push_back(row_pos[(size_t)i]);
+                cf_ib.push_back(ii);
+                skip[(size_t)row_pos[(size_t)i]] = 1;
+                skip[(size_t)ii] = 1;
+                clist[(size_t)(start + qa) * kPerCol + (size_t)percol[qa]++] = (int16_t)c;
+                clist[(size_t)pos * kPerCol + (size_t)percol[q]++] = (int16_t)(c | 0x100);
+                row_cnt[(size_t)i] = 2;
+            } else {
+                row_run[(size_t)i] = run;
+                row_cnt[(size_t)i] = 1;
+                row_slot[(size_t)i] = q;
+                row_pos[(size_t)i] = ii;
+            }
+        }
+    }
+    cf_ptr.push_back((int32_t)cf_row.size());
+    rbptr.push_back(d);
+}
+
 // COLORED: first-fit greedy colouring of the column conflict graph, visiting the
 // columns in `order`.  Every row keeps the list of colours already present in it (at
 // most its number of entries); a column marks the colours of all its rows in a small
@@ -454,7 +548,9 @@ void build_rowblock_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
                            const std::vector<int32_t>& order,
                            const std::vector<int32_t>& batch_ptr, int G, int long_thresh,
                            std::vector<int32_t>& sp, std::vector<int32_t>& src,
-                           std::vector<uint32_t>& lmask) {
+                           std::vector<uint32_t>& lmask, const uint8_t* skip) {
+    // skip (optional): CSC entries that are not part of the stream (relaxed runs: the entries
+    // on conflict rows, which the chains replay)
     const int nb = (int)batch_ptr.size() - 1;
     const int64_t rows_per = (n + G - 1) / G > 0 ? (n + G - 1) / G : 1;
     sp.assign((size_t)G * nb * 65 + 1, 0);
@@ -471,6 +567,7 @@ void build_rowblock_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
                 for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
                     const int64_t i = cidx[ii];
                     if (i < rlo || i >= rhi) continue;
+                    if (skip && skip[(size_t)ii]) continue;
                     sp[((size_t)(i / rows_per) * nb + b) * 65 + q]++;
                 }
             }
@@ -502,6 +599,7 @@ void build_rowblock_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
                 for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
                     const int64_t i = cidx[ii];
                     if (i < rlo || i >= rhi) continue;
+                    if (skip && skip[(size_t)ii]) continue;
                     src[(size_t)fill[((size_t)(i / rows_per) * nb + b) * 65 + q]++] = (int32_t)ii;
                 }
             }

@@ -231,7 +231,9 @@ struct spfm_engine {
     int prb_has_long = 0;
     int prb_long = kPrbLong;  // entries per (workgroup, step, slot) above which a slot is "long"
     DevBuf prb_sp, prb_erow, prb_eval, prb_slab, prb_abort, prow_old, d_bptr, prb_stamps,
-        prb_viol, prb_cn, prb_lmask;
+        prb_viol, prb_cn, prb_lmask, prb_rec;
+    bool prb_pack = true;    // degree-3 passes with rows in global memory: packed row records
+    int prb_pack_active = 0;  // what the last pcd pass used
     bool prb_stamp_on = false;
     int wide_min_cols = 110;     // mean class width below which 64-column steps are used instead
     bool wide_stamp_on = false;  // pcdw_stamps: phase timers of the wide pcd pass (float storage)
@@ -1476,6 +1478,7 @@ struct spfm_engine {
         a.cf = nullptr;
         a.clist = nullptr;
         a.cslab = nullptr;
+        a.rec = nullptr;
         return a;
     }
 
@@ -1599,7 +1602,11 @@ struct spfm_engine {
                 relaxed = relax_state == 1;
             }
         }
-        const PrbArgs pa = relaxed ? relax_args() : prb_args();
+        PrbArgs pa = relaxed ? relax_args() : prb_args();
+        // degree 3, float storage, rows in global memory: packed 16-byte row records
+        // (yhat, y, A[i,1], A[i,2]) for the pass's component (pcd_prb_kernel LR = 3)
+        constexpr bool can_pk = std::is_same<T, float>::value && M == 3;
+        bool packed = false;
         if (prb_stamp_on && pa.n_ranks > 1)
             FAIL(SPFM_ERR_UNSUPPORTED,
                  "prb_stamps: the timer instantiation has no cross-GPU stage (single rank only)");
@@ -1623,6 +1630,16 @@ struct spfm_engine {
                            d_desc.as<ColDesc>(), prow_old.as<double>());
         HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));  // tag 0 = "not yet"
         if (relaxed) HIPC(hipMemsetAsync(r_cslab.p, 0, r_cslab.bytes, stream));
+        if constexpr (can_pk) {
+            if (!use_lr && !prb_stamp_on && prb_pack) {
+                HIPC(prb_rec.alloc(sizeof(float) * 4 * (size_t)n));
+                pa.rec = prb_rec.p;
+                hipLaunchKernelGGL(prb_pack3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, c, n,
+                                   (size_t)n * 2, yy.as<float>(), A.as<float>(),
+                                   prb_rec.as<float4>());
+                packed = true;
+            }
+        }
         {
             int prc = peer_clear(kPeerPcdOff, kPeerPbOff);
             if (prc) return prc;
@@ -1634,7 +1651,7 @@ struct spfm_engine {
             constexpr int LRc = decltype(lr_tag)::value;
             constexpr bool STc = decltype(stamp_tag)::value;
             constexpr int RGc = decltype(reg_tag)::value;
-            const size_t lds = LRc != 0 ? lds_bytes : kPrbLds;
+            const size_t lds = (LRc == 1 || LRc == 2) ? lds_bytes : kPrbLds;
             auto launch = [&](auto mg_tag) -> int {
                 constexpr bool MGc = decltype(mg_tag)::value;
                 HIPC(hipFuncSetAttribute(
@@ -1709,6 +1726,12 @@ struct spfm_engine {
                 }
             }
         }
+        if constexpr (can_pk) {
+            if (!launched && packed) {
+                launched = true;
+                lrc = go(integral_constant<int, 3>{}, std::false_type{}, integral_constant<int, -1>{});
+            }
+        }
         if constexpr (can_stamp3) {
             if (!launched && prb_stamp_on) {
                 launched = true;
@@ -1717,9 +1740,16 @@ struct spfm_engine {
         }
         if (!launched)
             lrc = go(integral_constant<int, 0>{}, std::false_type{}, integral_constant<int, -1>{});
+        prb_pack_active = packed ? 1 : 0;
         if (lrc == kNotResident) prof_cancel(0, nnz);
         if (lrc) return lrc;
         prof_end(0);
+        if constexpr (can_pk) {
+            if (packed)
+                hipLaunchKernelGGL(prb_unpack3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, c, n,
+                                   (size_t)n * 2, prb_rec.as<float4>(), yy.as<float>(),
+                                   A.as<float>());
+        }
         hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
                            d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());
         HIPC(hipGetLastError());
@@ -3218,6 +3248,8 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         }
         h->prb_long = value;
         h->prb_ready = false;
+    } else if (k == "prb_pack") {  // packed row records for degree-3 passes (rows in global memory)
+        h->prb_pack = value != 0;
     } else if (k == "relax") {  // merged steps for schedules of tiny steps
         h->relax_on = value != 0;
         h->relax_state = 0;
@@ -3336,6 +3368,7 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "persistent_active")
         *value = h->have_schedule && (h->prb_usable() || h->wide_usable());
     else if (k == "relax") *value = h->relax_on;
+    else if (k == "prb_pack_active") *value = h->prb_pack_active;
     else if (k == "relax_steps")
         *value = h->relax_state == 1 ? (int)h->r_batch_ptr.size() - 1 : 0;
     else if (k == "persistent_fallbacks") *value = h->pers_fallbacks;

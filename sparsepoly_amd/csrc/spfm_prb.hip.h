@@ -59,6 +59,7 @@ struct PrbArgs {
     const void* cf;         // PrbConf<T>[]: row, slots of the two columns, their two x values
     const int16_t* clist;   // [d][8] per column position: conflict index | role << 8, -1 none
     double* cslab;          // [2][64][4] tagged granules: (yhat or residual, y, A[i,1]) of a row
+    void* rec;              // LR = 3: packed row records float4[n] of the pass's component
 };
 
 template <typename T>
@@ -263,53 +264,6 @@ __device__ __forceinline__ bool prb_collect_quarter(const PrbArgs& a, int b, int
     return ok;
 }
 
-// One column's step, prox and cache update of pcd._update (pcd.py:61-68; l1.py:32-33,
-// squaredl12.py:47-57, omegati.py:76-99 at degree 2), wave-uniform: the serial form of
-// pcd_chain_lanes<2> used by the relaxed-run chain, where a column's sums depend on the
-// deltas of the columns in front of it.  `cache` as in pcd_chain_lanes.
-__device__ __forceinline__ double pcd_prox_one2(int reg, double p_old, double g, double h,
-                                                double lam, double mu, double beta, double gamma,
-                                                double eta, double (&cache)[3], int lane) {
-    double inv = h * mu;
-    inv += beta;
-    double upd = g * lam;
-    upd += beta * p_old;
-    const double rinv = recip_nr(inv);
-    upd *= rinv;
-    const double pin = p_old - eta * upd;
-    const double st = (eta * gamma) * rinv;
-    if (reg == REG_L1) {
-        const double sg = (pin > 0) ? 1.0 : ((pin < 0) ? -1.0 : 0.0);
-        const double m = fabs(pin) - st;
-        return sg * (m > 0.0 ? m : 0.0);
-    }
-    const double ab = fabs(p_old);
-    if (reg == REG_SQL12) {
-        const double den = 1 + 2 * st;
-        const double rden = recip_nr(den);
-        const double pp = pin * rden;
-        const double app = fabs(pp);
-        const double tt = (2 * st) * rden;
-        const double sg = (pp > 0) ? 1.0 : -1.0;
-        const double others = cache[0] - ab;
-        const double m = fma(-tt, others, app);
-        const double r = (m > 0) ? m : 0.0;
-        cache[0] = others + r;
-        return sg * r;
-    }
-    // REG_OMEGATI, degree 2: u = max(c - a, 0); r = max(|p| - s u, 0); c' = u + r
-    const double apin = fabs(pin);
-    const double sg = (pin > 0) ? 1.0 : -1.0;
-    const double v = cache[1] - ab;
-    const bool pos = !(v < 0);
-    const double u = pos ? v : 0.0;
-    const double m = apin - st * u;
-    const double r = (m > 0) ? m : 0.0;
-    if (!pos) count_branch(BR_OMEGATI_CLIP, lane);
-    cache[1] = u + r;
-    return sg * r;
-}
-
 // The entries one thread owns in one step: 4 lanes share a slot, each keeps up to
 // PRB_PF entries (row, value) in registers; a slot with more than 4*PRB_PF entries in
 // this row block falls back to a reload loop for the rest.
@@ -404,9 +358,52 @@ template <int NV>
 __device__ __forceinline__ bool prb_poll(const PrbArgs& a, const double* p, unsigned long long tag,
                                          double* out);
 
+// pcd.py:124-133 at degree 3 on one packed row record (yhat, y, A[i,1], A[i,2])
+__device__ __forceinline__ void pcd_sync_entry_rec(size_t i, double x, double p_old, double upd,
+                                                   double lam, float4* __restrict__ rec) {
+    const float4 r = rec[i];
+    const double a1 = (double)r.z, a2 = (double)r.w;
+    const double d1 = x * (a1 - p_old * x);
+    const double d2 = x * (a2 - p_old * d1);
+    float4 o;
+    o.x = (float)((double)r.x - lam * upd * d2);
+    o.y = r.y;
+    o.z = (float)(a1 - upd * x);
+    o.w = (float)(a2 - upd * d1);
+    rec[i] = o;
+}
+
+// rows of component ctl->s as packed records, and back (degree 3, float; pcd_prb_kernel LR = 3)
+__global__ void prb_pack3_kernel(const Ctl* __restrict__ ctl, int64_t n, size_t a_stride,
+                                 const float* __restrict__ yy, const float* __restrict__ A_all,
+                                 float4* __restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float* A = A_all + (size_t)ctl->s * a_stride;
+        float4 r;
+        r.x = yy[2 * i];
+        r.y = yy[2 * i + 1];
+        r.z = A[2 * i];
+        r.w = A[2 * i + 1];
+        rec[i] = r;
+    }
+}
+__global__ void prb_unpack3_kernel(const Ctl* __restrict__ ctl, int64_t n, size_t a_stride,
+                                   const float4* __restrict__ rec, float* __restrict__ yy,
+                                   float* __restrict__ A_all) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float* A = A_all + (size_t)ctl->s * a_stride;
+        const float4 r = rec[i];
+        yy[2 * i] = r.x;
+        A[2 * i] = r.z;
+        A[2 * i + 1] = r.w;
+    }
+}
+
 // CR = true: relaxed runs (steps whose columns may share rows, see PrbArgs / schedule_relax);
 // degree 2, single GPU.
-constexpr int kPrbLdsCR = 768;  // extra doubles of fixed LDS of the CR instantiation
+constexpr int kPrbLdsCR = 256;  // extra doubles of fixed LDS of the CR instantiation
 template <typename T, int M, int LOSS, int LR, bool STAMP = false, int REGC = -1, bool MG = false,
           bool CR = false>
 __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
@@ -438,22 +435,27 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     for (int t = 0; t <= M; ++t) cache[t] = cache_in[t];
 
     double* sh_long = dyn_lds + 1024;  // [64][4][2] wave partials of long slots
-    static_assert(LR == 0 || (Kind<M>::AS <= 2 && sizeof(T) == 4 &&
-                              (LR == 2 || LOSS == LOSS_SQUARED)),
+    // LR 1 / 2: rows resident in LDS; 3: rows in global memory as packed 16-byte records
+    // (yhat, y, A[i,1], A[i,2]) -- degree 3, float: one line per gather, one store per scatter
+    // instead of two lines and three 4-byte stores
+    constexpr bool LDSR = (LR == 1 || LR == 2);
+    constexpr bool PK = (LR == 3);
+    static_assert(!LDSR || (Kind<M>::AS <= 2 && sizeof(T) == 4 &&
+                            (LR == 2 || LOSS == LOSS_SQUARED)),
                   "LDS-resident rows: float storage, one or two cache values per row");
+    static_assert(!PK || (sizeof(T) == 4 && Kind<M>::AS == 2 && !CR),
+                  "packed row records: float storage, two cache values per row");
+    float4* __restrict__ rec = reinterpret_cast<float4*>(a.rec);
     constexpr int AS = Kind<M>::AS;
     static_assert(!CR || (M == 2 && !MG && !STAMP), "relaxed runs: degree 2, single GPU");
-    const int row0 = LR ? g * a.rows_per : 0;
-    // CR: conflict-row tables of the step, behind the fixed block
-    double* sh_cs = dyn_lds + kPrbLdsFixed;            // [64][3] published state of the rows
-    double* sh_ci = sh_cs + 192;                       // [64][4] qa, qb, xa, xb
-    short* sh_cl = reinterpret_cast<short*>(sh_ci + 256);  // [64][8] per column: index | role << 8
-    double* sh_tot = sh_ci + 256 + 128;                // [64][2] column totals
-    int* sh_j = reinterpret_cast<int*>(sh_tot + 128);  // [64] column ids (workgroup 0)
+    const int row0 = LDSR ? g * a.rows_per : 0;
+    // CR: per-conflict contributions of the step, behind the fixed block
+    double* sh_ce = dyn_lds + kPrbLdsFixed;  // [64][2] of a row's EARLIER column (constant)
+    double* sh_cv = sh_ce + 128;             // [64][2] of its LATER column (per round)
     T* lds_a = reinterpret_cast<T*>(dyn_lds + kPrbLdsFixed + (CR ? kPrbLdsCR : 0));  // [rows_per][AS] A[i, 1..AS]
     T* lds_r = lds_a + (size_t)a.rows_per * AS;                // [rows_per] residual or yhat
     unsigned char* lds_s = reinterpret_cast<unsigned char*>(lds_r + a.rows_per);  // y > 0
-    if constexpr (LR != 0) {
+    if constexpr (LDSR) {
         const int nr = min(a.rows_per, a.n_rows - row0);
         for (int il = tid; il < nr; il += kPrbThreads) {
             const typename Vec2<T>::type yv = yy2[(size_t)(row0 + il)];
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         double yh[PRB_PF], yt[PRB_PF], dlast[PRB_PF];
         double pl = 0.0;
         int jl = 0;
+        double cst[3] = {0.0, 0.0, 0.0};  // CR, control wave: state of conflict row `lane`
         if (control) {
             if (lane < ncols) {
                 pl = pold_sched[c0 + lane];
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             if constexpr (CR) {
                 // conflict rows of this step: the owner publishes the row's state (as the
                 // workers would gather it); slots the buffer's next use will read are rewritten
-                // with zeros (stale tags, as for the column slots); tables -> LDS for the chain
+                // with zeros (stale tags, as for the column slots)
                 const int nc = cp1 - cp0, ncw = max(nc, cp3 - cp2);
                 const unsigned long long ctag = prb_tag(b);
                 double* cs = a.cslab + (size_t)(b & 1) * 64 * 4 + (size_t)lane * 4;
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                     const int i = cfc.row;
                     if (i / a.rows_per == g) {
                         double y0, y1, a1;
-                        if constexpr (LR != 0) {
+                        if constexpr (LDSR) {
                             y0 = (double)lds_r[i - row0];
                             y1 = (LR == 1) ? 0.0 : (lds_s[i - row0] ? 1.0 : -1.0);
                             a1 = (double)lds_a[i - row0];
@@ -579,27 +582,27 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                         prb_store_granule(cs + 1, y1, ctag);
                         prb_store_granule(cs + 2, a1, ctag);
                     }
-                    sh_ci[lane * 4 + 0] = (double)(cfc.qq & 0xff);
-                    sh_ci[lane * 4 + 1] = (double)(cfc.qq >> 8);
-                    sh_ci[lane * 4 + 2] = (double)cfc.xa;
-                    sh_ci[lane * 4 + 3] = (double)cfc.xb;
                 } else if (lane < ncw && (lane % a.G) == g) {
                     prb_store_granule(cs, 0.0, ctag);
                     prb_store_granule(cs + 1, 0.0, ctag);
                     prb_store_granule(cs + 2, 0.0, ctag);
                 }
-                *reinterpret_cast<prb_u4*>(sh_cl + lane * 8) = clq;
-                sh_j[lane] = jl;
             }
         } else if (worker) {
 #pragma unroll
             for (int u = 0; u < PRB_PF; ++u) {  // all gathers in flight before any use
-                if constexpr (LR != 0) {
+                if constexpr (LDSR) {
                     const int il = cur.row[u] - row0;
                     yh[u] = (double)lds_r[il];
                     yt[u] = (LR == 1) ? 0.0 : (lds_s[il] ? 1.0 : -1.0);
 #pragma unroll
                     for (int t = 0; t < AS; ++t) av[u][t] = (double)lds_a[il * AS + t];
+                } else if constexpr (PK) {
+                    const float4 r = rec[(size_t)cur.row[u]];
+                    yh[u] = (double)r.x;
+                    yt[u] = (double)r.y;
+                    av[u][0] = (double)r.z;
+                    av[u][AS - 1] = (double)r.w;
                 } else {
                     const size_t i = (size_t)cur.row[u];
                     const typename Vec2<T>::type yv = yy2[i];
@@ -625,11 +628,17 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 const int i = a.erow[e];
                 const double x = (double)eval[e];
                 double a1[AS], y0, y1;
-                if constexpr (LR != 0) {
+                if constexpr (LDSR) {
                     y0 = (double)lds_r[i - row0];
                     y1 = (LR == 1) ? 0.0 : (lds_s[i - row0] ? 1.0 : -1.0);
 #pragma unroll
                     for (int t = 0; t < AS; ++t) a1[t] = (double)lds_a[(i - row0) * AS + t];
+                } else if constexpr (PK) {
+                    const float4 r = rec[(size_t)i];
+                    y0 = (double)r.x;
+                    y1 = (double)r.y;
+                    a1[0] = (double)r.z;
+                    a1[AS - 1] = (double)r.w;
                 } else {
                     const typename Vec2<T>::type yv = yy2[i];
                     y0 = (double)yv.x;
@@ -678,12 +687,18 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                         const int i = a.erow[e];
                         const double x = (double)eval[e];
                         double a1[Kind<M>::AS], y0, y1;
-                        if constexpr (LR != 0) {
+                        if constexpr (LDSR) {
                             y0 = (double)lds_r[i - row0];
                             y1 = (LR == 1) ? 0.0 : (lds_s[i - row0] ? 1.0 : -1.0);
 #pragma unroll
                             for (int t = 0; t < Kind<M>::AS; ++t)
                                 a1[t] = (double)lds_a[(i - row0) * Kind<M>::AS + t];
+                        } else if constexpr (PK) {
+                            const float4 r = rec[(size_t)i];
+                            y0 = (double)r.x;
+                            y1 = (double)r.y;
+                            a1[0] = (double)r.z;
+                            a1[Kind<M>::AS - 1] = (double)r.w;
                         } else {
                             const typename Vec2<T>::type yv = yy2[i];
                             y0 = (double)yv.x;
@@ -731,7 +746,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             // sooner -- costs 3 %: 271 -> 279 ms per epoch on config 2)
             if (tid == 64 + 255)  // last worker wave: this workgroup's partials are on their way
                 __hip_atomic_store(sh_go, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (LR != 0 && b + 1 < a.nb) {
+            if (LDSR && b + 1 < a.nb) {
                 // rows in LDS: the end-of-step barrier no longer drains vmcnt, so the
                 // streaming prefetch of step b+1 is issued BEFORE the exchange -- it has the
                 // whole sweep (which waits for the slowest workgroup anyway) to land
@@ -744,7 +759,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 if (!ok) *sh_ok = 0;
             }
             PRB_WSTAMP(2)  // granule sweep until every workgroup's partials are in
-            if (LR == 0 && b + 1 < a.nb) {
+            if (!LDSR && b + 1 < a.nb) {
                 // prefetch (after the exchange: vmcnt retires in order, so streaming loads
                 // issued earlier would delay every granule check): entries of step b+1
                 // (bounds already in registers), bounds of b+2
@@ -765,14 +780,10 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             PRB_HSTAMP(2)  // its part of the sweep
             if constexpr (CR) {
                 if (control) {
-                    if (lane < cp1 - cp0) {  // the published states of the step's conflict rows
-                        double st3[3];
+                    if (lane < cp1 - cp0) {  // the published state of "my" conflict row
                         if (!prb_poll<3>(a, a.cslab + (size_t)(b & 1) * 64 * 4 + (size_t)lane * 4,
-                                         prb_tag(b), st3))
+                                         prb_tag(b), cst))
                             *sh_ok = 0;
-                        sh_cs[lane * 3 + 0] = st3[0];
-                        sh_cs[lane * 3 + 1] = st3[1];
-                        sh_cs[lane * 3 + 2] = st3[2];
                     }
                     // tables of step b+1 (consumed at its start)
                     const PrbConf<T>* cfa = reinterpret_cast<const PrbConf<T>*>(a.cf);
@@ -819,87 +830,97 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             }
             if constexpr (CR) {
                 if (serial) {
-                    // Relaxed run: the columns in order, one at a time (pcd.py:97-135 for the
-                    // rows that two columns of the step share).  A column's sums = the totals of
-                    // the row blocks (conflict rows left out) + its conflict rows replayed here
-                    // with the state the sequential sweep would find: the published state, after
-                    // the update of the row's EARLIER column when this is the later one.
+                    // Relaxed run.  A column's sums = the totals of the row blocks (conflict rows
+                    // left out) + its conflict rows with the state the sequential sweep finds
+                    // (pcd.py:97-135): the published state for the row's EARLIER column, that state
+                    // after the earlier column's update for the LATER one.  Lane c works for
+                    // conflict row c, lane q for column q.  The later columns' terms depend on the
+                    // earlier columns' deltas, which depend (regularizer cache) on everything in
+                    // front of them: evaluated in rounds -- all terms from the current deltas, then
+                    // the whole chain (pcd_chain_lanes: exact for the sums it is given) -- until no
+                    // delta changes a bit.  Column q only depends on columns < q, so round r fixes
+                    // column r at the latest and the fixed point is the sequential result; the
+                    // couplings are weak (one row in ~500, a cache term of 1e-7), 3-5 rounds.
                     const int nc = cp1 - cp0;
-                    sh_tot[lane * 2] = tot[0];
-                    sh_tot[lane * 2 + 1] = tot[1];
+                    const int qa = cfc.qq & 0xff, qb = cfc.qq >> 8;
+                    const double xa = (double)cfc.xa, xb = (double)cfc.xb;
                     sh_pold[lane] = pl;
                     sh_delta[lane] = 0.0;
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
-                    double cc[3] = {0.0, 0.0, 0.0};
+                    double c2 = 0.0, pb = 0.0;
+                    if (lane < nc) {
+                        const double pa = sh_pold[qa];
+                        pb = sh_pold[qb];
+                        const double dAa = xa * (cst[2] - pa * xa);
+                        c2 = lam * dAa;
+                        sh_ce[lane * 2] = dloss_dev(LOSS, cst[0], cst[1]) * dAa;
+                        sh_ce[lane * 2 + 1] = dAa * dAa;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    // my column's conflict list (8 entries: index | role << 8, -1 = none)
+                    int le[8];
 #pragma unroll
-                    for (int t = 0; t <= M; ++t) cc[t] = cache[t];
-                    for (int q = 0; q < ncols; ++q) {
-                        double gq = sh_tot[2 * q], hq = sh_tot[2 * q + 1];
-                        const double plq = sh_pold[q];
-                        const int e = (lane < 8) ? (int)sh_cl[q * 8 + lane] : -1;
-                        double cg = 0.0, ch = 0.0;
-                        if (e >= 0) {
-                            const int c = e & 0xff;
-                            const double y0 = sh_cs[c * 3], y1 = sh_cs[c * 3 + 1],
-                                         a0 = sh_cs[c * 3 + 2];
-                            const double xa = sh_ci[c * 4 + 2], xb = sh_ci[c * 4 + 3];
-                            if ((e >> 8) == 0) {  // this column is the row's first
-                                const double dA = xa * (a0 - plq * xa);
-                                cg = dloss_dev(LOSS, y0, y1) * dA;
-                                ch = dA * dA;
-                            } else {  // the row as the earlier column left it (stored as T)
-                                const int qa = (int)sh_ci[c * 4];
-                                const double Da = sh_delta[qa], pa = sh_pold[qa];
-                                const double dAa = xa * (a0 - pa * xa);
-                                const double a1 = (double)(T)(a0 - Da * xa);
-                                const double y0n = (double)(T)(y0 - lam * Da * dAa);
-                                const double dAb = xb * (a1 - plq * xb);
-                                cg = dloss_dev(LOSS, y0n, y1) * dAb;
-                                ch = dAb * dAb;
-                            }
+                    for (int t = 0; t < 8; ++t) {
+                        const unsigned w = clq[t >> 1];
+                        le[t] = (int)(short)((t & 1) ? (w >> 16) : (w & 0xffffu));
+                    }
+                    double g0 = tot[0], h0 = tot[1];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (le[t] >= 0 && (le[t] >> 8) == 0) {
+                            g0 += sh_ce[(le[t] & 0xff) * 2];
+                            h0 += sh_ce[(le[t] & 0xff) * 2 + 1];
                         }
-                        // lanes 0..7 -> every lane of the first row of 16 (fixed order)
-                        cg += dpp_move_d<0xB1, 0xf>(0.0, cg);
-                        ch += dpp_move_d<0xB1, 0xf>(0.0, ch);
-                        cg += dpp_move_d<0x4E, 0xf>(0.0, cg);
-                        ch += dpp_move_d<0x4E, 0xf>(0.0, ch);
-                        cg += dpp_move_d<0x124, 0xf>(0.0, cg);
-                        ch += dpp_move_d<0x124, 0xf>(0.0, ch);
-                        cg += dpp_move_d<0x128, 0xf>(0.0, cg);
-                        ch += dpp_move_d<0x128, 0xf>(0.0, ch);
-                        gq += readlane_d(cg, 0);
-                        hq += readlane_d(ch, 0);
-                        const double res = pcd_prox_one2(reg, plq, gq, hq, lam, mu, beta, gamma, eta,
-                                                         cc, lane);
-                        const double dlq = plq - res;
-                        if (lane == 0) {
-                            sh_delta[q] = dlq;
-                            if (g == 0) {
-                                ps[sh_j[q]] = res;
-                                viol_pos[c0 + q] = fabs(dlq);
-                            }
+                    double cc0[M + 1];
+#pragma unroll
+                    for (int t = 0; t <= M; ++t) cc0[t] = cache[t];
+                    double dl = 0.0, res = pl;
+                    for (int round = 0; round <= ncols + 1; ++round) {
+                        if (lane < nc) {  // the later column's term of "my" row
+                            const double Da = sh_delta[qa];
+                            const double a1 = (double)(T)(cst[2] - Da * xa);
+                            const double y0n = (double)(T)(cst[0] - Da * c2);
+                            const double dAb = xb * (a1 - pb * xb);
+                            sh_cv[lane * 2] = dloss_dev(LOSS, y0n, cst[1]) * dAb;
+                            sh_cv[lane * 2 + 1] = dAb * dAb;
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_wave_barrier();
-                    }
+                        double gq = g0, hq = h0;
 #pragma unroll
-                    for (int t = 0; t <= M; ++t) cache[t] = cc[t];
+                        for (int t = 0; t < 8; ++t)
+                            if (le[t] >= 0 && (le[t] >> 8) != 0) {
+                                gq += sh_cv[(le[t] & 0xff) * 2];
+                                hq += sh_cv[(le[t] & 0xff) * 2 + 1];
+                            }
+#pragma unroll
+                        for (int t = 0; t <= M; ++t) cache[t] = cc0[t];
+                        res = pcd_chain_lanes<M>(reg, lane, ncols - 1, valid, pl, gq, hq, lam, mu,
+                                                 beta, gamma, eta, cache, sh_chain);
+                        const double dn = valid ? (pl - res) : 0.0;
+                        const bool same = __double_as_longlong(dn) == __double_as_longlong(dl);
+                        dl = dn;
+                        sh_delta[lane] = dl;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        if (__ballot(!same) == 0ull) break;
+                    }
+                    if (g == 0 && valid) {
+                        ps[jl] = res;
+                        viol_pos[c0 + lane] = fabs(dl);
+                    }
                     // the conflict rows' final state, by their owner: both updates in order
                     if (lane < nc && cfc.row / a.rows_per == g) {
                         const int i = cfc.row;
-                        const int qa = cfc.qq & 0xff, qb = cfc.qq >> 8;
-                        const double xa = (double)cfc.xa, xb = (double)cfc.xb;
-                        const double y0 = sh_cs[lane * 3], a0 = sh_cs[lane * 3 + 2];
                         const double Da = sh_delta[qa], Db = sh_delta[qb];
-                        const double pa = sh_pold[qa], pb = sh_pold[qb];
-                        const double dAa = xa * (a0 - pa * xa);
-                        const double a1 = (double)(T)(a0 - Da * xa);
-                        const double y0n = (double)(T)(y0 - lam * Da * dAa);
+                        const double a1 = (double)(T)(cst[2] - Da * xa);
+                        const double y0n = (double)(T)(cst[0] - Da * c2);
                         const double dAb = xb * (a1 - pb * xb);
                         const T a2 = (T)(a1 - Db * xb);
                         const T y0f = (T)(y0n - lam * Db * dAb);
-                        if constexpr (LR != 0) {
+                        if constexpr (LDSR) {
                             lds_a[i - row0] = a2;
                             lds_r[i - row0] = y0f;
                         } else {
@@ -929,14 +950,14 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                             double an = av[u][0] / (1.0 + x * p_old);
                             an *= 1.0 + x * (p_old - upd);
                             yn += lam * an;
-                            if constexpr (LR != 0) {
+                            if constexpr (LDSR) {
                                 lds_a[i - row0] = (T)an;
                                 lds_r[i - row0] = (T)yn;
                             } else {
                                 A[i] = (T)an;
                                 yy[2 * i] = (T)yn;
                             }
-                        } else if constexpr (LR != 0) {
+                        } else if constexpr (LDSR) {
                             const int il = (int)i - row0;
                             double dprev = x;
 #pragma unroll
@@ -947,6 +968,14 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                                 dprev = dcur;
                             }
                             lds_r[il] = (T)(yh[u] - lam * upd * dlast[u]);
+                        } else if constexpr (PK) {
+                            const double d1 = x * (av[u][0] - p_old * x);
+                            float4 o;
+                            o.x = (float)(yh[u] - lam * upd * dlast[u]);
+                            o.y = (float)yt[u];
+                            o.z = (float)(av[u][0] - upd * x);
+                            o.w = (float)(av[u][AS - 1] - upd * d1);
+                            rec[i] = o;
                         } else {
                             double dprev = x;
 #pragma unroll
@@ -961,9 +990,11 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                     }
                 }
                 for (int e = cur.e0 + sub + 4 * PRB_PF; e < cur.e1; e += 4) {
-                    if constexpr (LR != 0)
+                    if constexpr (LDSR)
                         pcd_sync_entry_lds<T, M>(a.erow[e] - row0, (double)eval[e], p_old, upd,
                                                  lam, lds_a, lds_r);
+                    else if constexpr (PK)
+                        pcd_sync_entry_rec((size_t)a.erow[e], (double)eval[e], p_old, upd, lam, rec);
                     else
                         pcd_sync_entry<T, M>((size_t)a.erow[e], (double)eval[e], p_old, upd, lam,
                                              A, yy);
@@ -979,9 +1010,12 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                     const double p_old = sh_pold[q];
                     const int le0 = spb[q], le1 = spb[q + 1];
                     for (int e = le0 + wt; e < le1; e += 256) {
-                        if constexpr (LR != 0)
+                        if constexpr (LDSR)
                             pcd_sync_entry_lds<T, M>(a.erow[e] - row0, (double)eval[e], p_old,
                                                      upd, lam, lds_a, lds_r);
+                        else if constexpr (PK)
+                            pcd_sync_entry_rec((size_t)a.erow[e], (double)eval[e], p_old, upd, lam,
+                                               rec);
                         else
                             pcd_sync_entry<T, M>((size_t)a.erow[e], (double)eval[e], p_old, upd,
                                                  lam, A, yy);
@@ -1012,7 +1046,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         PRB_WSTAMP(6)  // scatter issue
         // B5: rows move between slots from step to step.  With the rows in LDS only LDS
         // traffic has to land (the prefetch loads of the next step stay in flight).
-        if constexpr (LR != 0)
+        if constexpr (LDSR)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else
             __syncthreads();
@@ -1025,7 +1059,7 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
 #undef PRB_STAMP
 #undef PRB_HSTAMP
 #undef PRB_WSTAMP
-    if constexpr (LR != 0) {  // write the row block back (LR == 1: yhat = r + y)
+    if constexpr (LDSR) {  // write the row block back (LR == 1: yhat = r + y)
         __syncthreads();
         const int nr = min(a.rows_per, a.n_rows - row0);
         for (int il = tid; il < nr; il += kPrbThreads) {

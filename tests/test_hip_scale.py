@@ -281,18 +281,27 @@ def test_lds_resident_row_block_matches_global_path(oracle, loss, model, want_mo
     lams = np.ones(k) if model == "fm" else np.where(np.arange(k) % 2 == 0, 1.0, -1.0)
     ic = np.arange(k, dtype=np.int32)
     out = {}
-    for lds in (1, 0):
+    # (2 = rows in global memory WITHOUT the packed 16-byte row records of the degree-3 pass)
+    for lds in (1, 0, 2) if model == "fm3" else (1, 0):
         eng = HipEngine(0, "f32")
-        eng.set_option("prb_lds", lds)
+        eng.set_option("prb_lds", 1 if lds == 1 else 0)
+        if lds == 2:
+            eng.set_option("prb_pack", 0)
         eng.set_data(Xc, y)
         eng.set_params(P0, np.zeros(d), lams)
         eng.configure("pcd", loss, reg, degree)
         eng.init_pred(degree, False, False)
         order = eng.set_schedule("colored", np.arange(d, dtype=np.int32))
         viol = [eng.pcd_epoch(0, degree, beta, 1e-3, 1.0, ic) for _ in range(2)]
-        assert eng.get_option("prb_lds_active") == (want_mode if lds else 0)
+        assert eng.get_option("prb_lds_active") == (want_mode if lds == 1 else 0)
+        # degree 3 with the rows in global memory: packed (yhat, y, A1, A2) records by default
+        assert eng.get_option("prb_pack_active") == (1 if (model == "fm3" and lds == 0) else 0)
         out[lds] = (np.array(viol), eng.loss_sum(), eng.get_params()[0], eng.get_y_pred(), order)
         eng.close()
+    if model == "fm3":  # same arithmetic, same float rounding of the stored rows: same bits
+        np.testing.assert_array_equal(out[0][0], out[2][0])
+        np.testing.assert_array_equal(out[0][2], out[2][2])
+        np.testing.assert_array_equal(out[0][3], out[2][3])
     # the two variants round differently (residual vs prediction in float); degree 3 amplifies
     # that more than degree 2
     vt = 2e-5 if model == "fm3" else 2e-6

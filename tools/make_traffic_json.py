@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""profiles/r02_traffic.json from the rocprofv3 --pmc summaries of tools/profile_r02.sh:
+"""profiles/r03_traffic.json from the rocprofv3 --pmc summaries of tools/profile_r03.sh:
 per config and dominant kernel, FETCH_SIZE / WRITE_SIZE per launch in KB as reported (1 KB =
-1024 B; calibration of the counters: profiles/r01_traffic.json "_comment_v2").  bench.py uses
-the file for `roofline.traffic` only when `engine_tag` equals its own ENGINE_TAG.
+1024 B; calibration of the counters: profiles/r01_traffic.json "_comment_v2" and
+profiles/r03_fetch_calibration.txt).  `engine_tag` is the library's build tag (hash of its
+sources, spfm_build_tag) read from the very library the counters were collected with;
+bench.py quotes the file for `roofline.traffic` only when the library it runs has that tag.
 
-    python tools/make_traffic_json.py <engine_tag>
+    python tools/make_traffic_json.py            (on the GPU box, after tools/profile_r03.sh)
 """
 import json
 import os
@@ -27,18 +29,21 @@ def per_launch(path, prefix):
     return None
 
 
-out = {"engine_tag": sys.argv[1],
+sys.path.insert(0, ROOT)
+from sparsepoly_amd import _capi  # noqa: E402
+
+out = {"engine_tag": sys.argv[1] if len(sys.argv) > 1 else _capi.build_tag(),
        "_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes "
-                   "(tools/profile_r02.sh), bench.py --steps 1 --warmup 0; per-launch means in KB "
-                   "as reported; sources: profiles/r02_c<config>_pmc_{fetch,write}_summary.txt"}
+                   "(tools/profile_r03.sh), bench.py --steps 1 --warmup 0; per-launch means in KB "
+                   "as reported; sources: profiles/r03_c<config>_pmc_{fetch,write}_summary.txt"}
 for cfg, (name, prefix) in KERNELS.items():
-    f = os.path.join(PROF, "r02_c%d_pmc_fetch_summary.txt" % cfg)
-    w = os.path.join(PROF, "r02_c%d_pmc_write_summary.txt" % cfg)
+    f = os.path.join(PROF, "r03_c%d_pmc_fetch_summary.txt" % cfg)
+    w = os.path.join(PROF, "r03_c%d_pmc_write_summary.txt" % cfg)
     if not (os.path.exists(f) and os.path.exists(w)):
         continue
     a, b = per_launch(f, prefix), per_launch(w, prefix)
     if a and b:
         out["config%d" % cfg] = {name: {"fetch_kb_per_launch": a[1], "write_kb_per_launch": b[1],
                                         "launches": a[0]}}
-json.dump(out, open(os.path.join(PROF, "r02_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(PROF, "r03_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

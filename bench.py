@@ -124,6 +124,11 @@ def launch_ranks(n_ranks, argv):
         if shared:
             env["SPFM_DEVICE"] = str(r % ndev)
             env.setdefault("SPFM_COMM", "shm")
+            # the persistent kernels of all ranks on a device must be co-resident (the library
+            # checks and otherwise falls back to the multi-kernel engine): share the CUs out
+            per_dev = -(-n_ranks // ndev)
+            env.setdefault("SPFM_OPTS", "pcdw_groups=%d,pbprb_groups=%d,prb_groups=%d"
+                           % (240 // per_dev, 240 // per_dev, min(64, 240 // per_dev)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0, _ = procs[0].communicate()

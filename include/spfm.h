@@ -219,6 +219,12 @@ int spfm_comm_init_shm(spfm_handle h, const char* shm_name, int n_ranks, int ran
  * the persistent passes cap a step at 64 columns.  Works across the GPUs of one node (xGMI)
  * and -- for tests -- between processes that share one GPU. */
 int spfm_peer_alloc(spfm_handle h, char* handle64);
+/* Maps the peers' slabs and runs a handshake kernel: every rank stores one word into every
+ * slab and polls its own until all ranks' words arrived (10 s bound) -- what the persistent
+ * passes rely on (a system-scope store into a peer-mapped slab reaches a kernel that is already
+ * polling).  All ranks call it together.  The slab is fine-grained device memory; when that
+ * cannot be allocated, or the handshake fails, the call returns SPFM_ERR_RUNTIME and the caller
+ * keeps the per-step collective (sparsepoly_amd.distributed.connect_peers does, on all ranks). */
 int spfm_peer_connect(spfm_handle h, int n_ranks, int rank, const char* handles);
 
 /* -- instrumentation ----------------------------------------------------------
@@ -257,10 +263,30 @@ int spfm_set_use_graph(spfm_handle h, int on);
  * added; "wide" / "wide_min_cols" / "max_batch" also the coloured schedule built next (never an
  * order the caller passed as 'exact'). */
 int spfm_set_option(spfm_handle h, const char* key, int value);
+/* Round 3: "pbprb_owners" (dedicated owner workgroups of the persistent pbcd pass, in front of
+ * the row workgroups in the grid; default 0), "relax" (0/1, default 1: a schedule of tiny steps --
+ * the reference order, fewer than 12 columns per step on average -- is run by the degree-2 pcd
+ * pass as merged steps of ~20 consecutive columns whose shared rows the chains replay in order;
+ * same result as the sequential sweep), "prb_pack" (0/1, default 1: degree-3 passes with their
+ * rows in global memory work on packed 16-byte row records), "persistent_failed" (0: try the
+ * persistent passes again after a recorded fall-back), test hooks "debug_spin_max" (polls of one
+ * in-kernel wait before a persistent pass gives up, default 2^21) and "debug_drop_group" (the next
+ * N persistent launches lack their last workgroup, i.e. time out).
+ *
+ * Failure semantics of the persistent passes (all-or-nothing epochs, as the reference's epoch
+ * functions): if a pass cannot run to its end -- its workgroups are not all resident, a peer GPU
+ * does not answer -- the epoch's parameters and regularizer state are restored from a snapshot
+ * taken before the launches, y_pred is recomputed from them (arguments of the last
+ * spfm_init_pred), the epoch is redone on the multi-kernel engine and the handle keeps using that
+ * engine; with several ranks the decision is agreed on through the communicator.  The call
+ * still returns SPFM_OK; spfm_get_option("persistent_fallbacks") counts the events. */
 /* read back a tunable, or the derived "persistent_active" (1 if the next pcd epoch
  * will use the persistent pass: option on, single GPU, steps of <= 64 columns) and
  * "prb_lds_active" (what the last pcd pass used: 0 global rows, 1 LDS residual form,
- * 2 LDS prediction + label sign), "pbprb_active", "wide_active", "wide_lds_active" */
+ * 2 LDS prediction + label sign), "pbprb_active", "wide_active", "wide_lds_active",
+ * "prb_pack_active", "relax_steps" (merged steps per degree-2 pcd sweep, 0 = strict steps),
+ * "persistent_fallbacks", "persistent_failed", "n_ranks" (ranks of the attached communicator),
+ * "peer_ready" (in-kernel cross-GPU exchange connected and verified) */
 int spfm_get_option(spfm_handle h, const char* key, int* value);
 
 /* diagnostic ("prb_stamps" option): accumulated shader cycles per phase of the last
@@ -285,6 +311,11 @@ int spfm_debug_exchange_cost(spfm_handle h, int groups, int ncols, int readers_m
  * since the last reset -- out[0] omegati.py:97-98 (clip), out[1] omegacs.py:90-96, out[2]
  * omegacs.py:75-76, out[3] squaredl21.py:48-49 (out[4..7] reserved).  reset != 0 clears the
  * counters after reading.  Counters are per process (all handles of the device). */
+/* Diagnostic for the counter calibration (profiles/r03_fetch_calibration.txt): one launch that
+ * reads the persistent pass's entry stream (slot bounds, rows, values of every step, with the
+ * pass's own access pattern) and nothing else; bytes_out receives the bytes it requested.  Run
+ * under `rocprofv3 --pmc FETCH_SIZE` to see what the counter reports for that known quantity. */
+int spfm_debug_stream_probe(spfm_handle h, int64_t* bytes_out);
 int spfm_debug_branch_counts(spfm_handle h, unsigned* out8, int reset);
 
 #ifdef __cplusplus

@@ -30,7 +30,7 @@ SYMBOLS = [
     "spfm_pcd_epoch", "spfm_pbcd_epoch", "spfm_psgd_epoch", "spfm_comm_unique_id", "spfm_comm_init", "spfm_comm_init_shm", "spfm_peer_alloc", "spfm_peer_connect",
     "spfm_profile_enable", "spfm_profile_get", "spfm_profile_reset", "spfm_set_use_graph",
     "spfm_set_option", "spfm_get_option", "spfm_debug_prb_stamps", "spfm_debug_hop_latency", "spfm_debug_exchange_cost",
-    "spfm_debug_branch_counts",
+    "spfm_debug_branch_counts", "spfm_debug_stream_probe",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -97,6 +97,7 @@ def load():
     L.spfm_peer_alloc.argtypes = [_h, C.c_char_p]
     L.spfm_peer_connect.argtypes = [_h, C.c_int, C.c_int, C.c_char_p]
     L.spfm_debug_branch_counts.argtypes = [_h, C.POINTER(C.c_uint32), C.c_int]
+    L.spfm_debug_stream_probe.argtypes = [_h, _lp]
     for name in SYMBOLS:
         f = getattr(L, name)
         if name not in ("spfm_destroy", "spfm_last_error", "spfm_build_tag"):

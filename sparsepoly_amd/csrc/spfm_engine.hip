@@ -3515,6 +3515,38 @@ int spfm_debug_exchange_cost(spfm_handle h, int groups, int ncols, int readers_m
     return SPFM_OK;
 }
 
+int spfm_debug_stream_probe(spfm_handle h, int64_t* bytes_out) {
+    GUARD(h);
+    if (!h->have_schedule || !h->prb_usable()) {
+        h->err = "stream probe: needs a schedule the 64-column persistent pass can run";
+        return SPFM_ERR_INVALID;
+    }
+    int rc = h->dtype == SPFM_F32 ? h->ensure_prb<float>() : h->ensure_prb<double>();
+    if (rc) return rc;
+    DevBuf sink;
+    if (sink.alloc(sizeof(double) * (size_t)h->prb_G * kPrbThreads) != hipSuccess) {
+        h->err = "stream probe: allocation failed";
+        return SPFM_ERR_RUNTIME;
+    }
+    const PrbArgs a = h->prb_args();
+    if (h->dtype == SPFM_F32)
+        hipLaunchKernelGGL((prb_stream_probe_kernel<float>), dim3(h->prb_G), dim3(kPrbThreads), 0,
+                           h->stream, a, h->prb_eval.as<float>(), sink.as<double>());
+    else
+        hipLaunchKernelGGL((prb_stream_probe_kernel<double>), dim3(h->prb_G), dim3(kPrbThreads), 0,
+                           h->stream, a, h->prb_eval.as<double>(), sink.as<double>());
+    if (hipStreamSynchronize(h->stream) != hipSuccess) {
+        h->err = "stream probe kernel failed";
+        return SPFM_ERR_RUNTIME;
+    }
+    // requested bytes: per entry a 4-byte row id and a value; per (workgroup, step) the slot
+    // bounds of its columns (+1) as 4-byte words
+    if (bytes_out)
+        *bytes_out = h->nnz * (int64_t)(4 + h->tsize()) +
+                     (int64_t)h->prb_G * ((int64_t)h->d + h->n_batches()) * 4;
+    return SPFM_OK;
+}
+
 int spfm_debug_branch_counts(spfm_handle h, unsigned* out8, int reset) {
     GUARD(h);
     if (!out8) return SPFM_ERR_INVALID;

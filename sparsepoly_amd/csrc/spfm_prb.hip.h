@@ -1540,6 +1540,29 @@ __global__ __launch_bounds__(kWave) void peer_probe_kernel(double* const* slabs,
     if (threadIdx.x == 0) ok[0] = all ? 1 : 0;
 }
 
+// ---- diagnostic: the entry stream of the persistent pass and nothing else --------------
+// What a worker thread of pcd_prb_kernel loads per step (slot bounds, then its 4-byte row ids
+// and values: lane = 4 lanes per slot, PRB_PF entries each, the reload loop for longer slots),
+// folded into a checksum so that nothing is optimised away.  Counter calibration: its
+// FETCH_SIZE under rocprofv3 against the known byte count.
+template <typename T>
+__global__ __launch_bounds__(kPrbThreads) void prb_stream_probe_kernel(PrbArgs a,
+                                                                      const T* __restrict__ eval,
+                                                                      double* __restrict__ sink) {
+    const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    const bool worker = wave >= 1 && wave <= 4;
+    const int wt = tid - 64, slot = worker ? (wt >> 2) : 64, sub = wt & 3;
+    double acc = 0.0;
+    for (int b = 0; b < a.nb; ++b) {
+        const int ncols = a.bptr[b + 1] - a.bptr[b];
+        int e0, e1;
+        unsigned long long lm;
+        prb_load_sp(a, g, b, slot, ncols, e0, e1, lm);
+        for (int e = e0 + sub; e < e1; e += 4) acc += (double)a.erow[e] + (double)eval[e];
+    }
+    sink[(size_t)g * kPrbThreads + tid] = acc;
+}
+
 // out[pos] = v[desc[pos].j]
 __global__ void gather_sched_kernel(int d, const ColDesc* __restrict__ desc,
                                     const double* __restrict__ v, double* __restrict__ out) {

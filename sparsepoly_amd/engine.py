@@ -334,6 +334,13 @@ class HipEngine(object):
         return dict(omegati_clip=buf[0], omegacs_dcache=buf[1], omegacs_cache=buf[2],
                     squaredl21_resum=buf[3])
 
+    def debug_stream_probe(self):
+        """One launch that reads the persistent pass's entry stream and nothing else; returns
+        the bytes it requested (counter calibration, see spfm.h)."""
+        nb = C.c_int64()
+        self._check(self._lib.spfm_debug_stream_probe(self._h, C.byref(nb)))
+        return nb.value
+
     def get_option(self, key):
         v = C.c_int()
         self._check(self._lib.spfm_get_option(self._h, key.encode(), C.byref(v)))

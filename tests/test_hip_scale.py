@@ -179,6 +179,52 @@ def test_fullsize_vs_oracle(oracle, config2_matrix, solver, reg):
     np.testing.assert_allclose(yp, ypo, rtol=0, atol=2e-4 * max(1.0, np.abs(ypo).max()))
 
 
+def test_fullsize_reference_order_merged_steps_vs_oracle(oracle, config2_matrix):
+    """Full BASELINE config-2 size in the REFERENCE's own column order (schedule='exact', the
+    estimators' default): the degree-2 pcd passes run it as merged steps whose shared rows the
+    chains replay (38 284 strict steps -> ~5 500), cd_linear keeps the strict steps.
+    One cd_linear epoch + 2 component passes against the oracle in natural order, f32 storage,
+    and against the strict engine (relax=0)."""
+    Xc, y = config2_matrix
+    n, d = Xc.shape
+    k = 30
+    ic = np.arange(2, dtype=np.int32)
+    runs = {}
+    for relax in (1, 0):
+        eng, order, P0 = _engine(Xc, y, k, 2, "pcd", "squaredl12", "f32", "exact",
+                                 options={"relax": relax})
+        np.testing.assert_array_equal(order, np.arange(d))
+        y0 = eng.get_y_pred()
+        v_lin = eng.cd_linear_epoch(1.0)
+        v = eng.pcd_epoch(0, 2, 10.0, 1e-4, 1.0, ic)
+        P, w = eng.get_params()
+        runs[relax] = dict(v_lin=v_lin, v=v, P=P, w=w, yp=eng.get_y_pred(), strict=eng.n_batches,
+                           merged=eng.get_option("relax_steps"),
+                           fallbacks=eng.get_option("persistent_fallbacks"))
+        eng.close()
+    a, b = runs[1], runs[0]
+    assert a["strict"] > 30_000 and 3_000 < a["merged"] < 0.25 * a["strict"], (a["strict"], a["merged"])
+    assert b["merged"] == 0 and a["fallbacks"] == 0 and b["fallbacks"] == 0
+    np.testing.assert_allclose(a["v"], b["v"], rtol=2e-6)
+    np.testing.assert_allclose(a["P"], b["P"], rtol=0, atol=5e-6)
+    ds = oracle.CSC(Xc)
+    regc = oracle.Regularizer("squaredl12")
+    wo = np.zeros(d)
+    ypo = np.ascontiguousarray(y0.copy())
+    cn = np.asarray(Xc.multiply(Xc).sum(axis=0)).ravel()
+    jf = np.arange(d, dtype=np.int32)
+    vo_lin = oracle.cd_linear_epoch(wo, ds, y, ypo, cn, 1.0, "squared", jf)
+    regc.init_cache_pcd(2, d, k)
+    Po = np.ascontiguousarray(P0[0].copy())
+    A = np.zeros((n, 3))
+    vo = oracle.pcd_epoch(Po, ds, y, ypo, np.ones(k), 2, 10.0, 1e-4, 1.0, regc, "squared", A, ic, jf)
+    np.testing.assert_allclose(a["v_lin"], vo_lin, rtol=1e-5)
+    np.testing.assert_allclose(a["v"], vo, rtol=1e-5)
+    np.testing.assert_allclose(a["w"], wo, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(a["P"][0], Po, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(a["yp"], ypo, rtol=0, atol=2e-4 * max(1.0, np.abs(ypo).max()))
+
+
 def test_estimator_augment_and_warm_start(oracle):
     """fit_lower='augment' (dummy columns, sparse_factorization_machines.py:86-92) and
     warm_start=True (P_, w_, lams_ reused, y_pred recomputed: :380-391,408)."""

@@ -1530,7 +1530,7 @@ struct spfm_engine {
         HIPC(r_cfptr.alloc(sizeof(int32_t) * cf_ptr.size()));
         HIPC(r_cf.alloc(sizeof(PrbConf<T>) * hcf.size()));
         HIPC(r_clist.alloc(sizeof(int16_t) * clist.size() + 16));
-        HIPC(r_cslab.alloc(sizeof(double) * 2 * 64 * 4));
+        HIPC(r_cslab.alloc(sizeof(double) * 2 * 64 * 8));
         HIPC(hipMemcpyAsync(r_bptr.p, r_batch_ptr.data(), sizeof(int32_t) * r_batch_ptr.size(),
                             hipMemcpyHostToDevice, stream));
         HIPC(hipMemcpyAsync(r_sp.p, sp.data(), sizeof(int32_t) * sp.size(), hipMemcpyHostToDevice,
@@ -1595,7 +1595,7 @@ struct spfm_engine {
         // relaxed runs: a schedule of tiny steps -- the reference order -- is run
         // as merged steps of ~20 columns by the CR instantiation (degree 2, one GPU)
         bool relaxed = false;
-        if constexpr (M == 2) {
+        if constexpr (M == 2 || M == 3) {
             if (relax_candidate() && !prb_stamp_on) {
                 rc = ensure_relax<T>();
                 if (rc) return rc;
@@ -1676,17 +1676,17 @@ struct spfm_engine {
         using std::integral_constant;
         int lrc = SPFM_OK;
         bool launched = false;
-        if constexpr (M == 2) {
+        if constexpr (M == 2 || M == 3) {
             if (relaxed) {
                 auto launch_cr = [&](auto lr_tag) -> int {
                     constexpr int LRc = decltype(lr_tag)::value;
-                    const size_t lds = LRc != 0 ? lds_bytes : kPrbLds;
-                    auto* fn = pcd_prb_kernel<T, 2, LOSS, LRc, false, -1, false, true>;
+                    const size_t lds = (LRc == 1 || LRc == 2) ? lds_bytes : kPrbLds;
+                    auto* fn = pcd_prb_kernel<T, M, LOSS, LRc, false, -1, false, true>;
                     HIPC(hipFuncSetAttribute((const void*)fn,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     if (!resident_ok((const void*)fn, kPrbThreads, lds, prb_G)) return kNotResident;
                     hipLaunchKernelGGL(fn, dim3(launch_groups(prb_G)), dim3(kPrbThreads), lds, stream,
-                                       c, pa, r_eval.as<T>(), A.as<T>(), (size_t)n * Kind<2>::AS,
+                                       c, pa, r_eval.as<T>(), A.as<T>(), (size_t)n * Kind<M>::AS,
                                        yy.as<T>(), prow_old.as<double>(), Po, d, reg, cb, mu, beta,
                                        gamma, eta, prb_viol.as<double>());
                     return SPFM_OK;
@@ -1696,6 +1696,12 @@ struct spfm_engine {
                 if constexpr (can_lr) {
                     if (use_lr) {
                         lrc = launch_cr(integral_constant<int, LRV>{});
+                        done = true;
+                    }
+                }
+                if constexpr (can_pk) {
+                    if (!done && packed) {
+                        lrc = launch_cr(integral_constant<int, 3>{});
                         done = true;
                     }
                 }
@@ -3248,6 +3254,7 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         }
         h->prb_long = value;
         h->prb_ready = false;
+        h->relax_state = 0;
     } else if (k == "prb_pack") {  // packed row records for degree-3 passes (rows in global memory)
         h->prb_pack = value != 0;
     } else if (k == "relax") {  // merged steps for schedules of tiny steps
@@ -3333,6 +3340,7 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         }
         h->prb_G = value;
         h->prb_ready = false;
+        h->relax_state = 0;
     } else if (k == "max_batch") {
         if (value < 1) {
             h->err = "max_batch must be >= 1";

@@ -443,11 +443,13 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
     static_assert(!LDSR || (Kind<M>::AS <= 2 && sizeof(T) == 4 &&
                             (LR == 2 || LOSS == LOSS_SQUARED)),
                   "LDS-resident rows: float storage, one or two cache values per row");
-    static_assert(!PK || (sizeof(T) == 4 && Kind<M>::AS == 2 && !CR),
+    static_assert(!PK || (sizeof(T) == 4 && Kind<M>::AS == 2),
                   "packed row records: float storage, two cache values per row");
     float4* __restrict__ rec = reinterpret_cast<float4*>(a.rec);
     constexpr int AS = Kind<M>::AS;
-    static_assert(!CR || (M == 2 && !MG && !STAMP), "relaxed runs: degree 2, single GPU");
+    static_assert(!CR || (M >= 2 && !MG && !STAMP), "relaxed runs: degree >= 2, single GPU");
+    constexpr int CSN = 2 + Kind<M>::AS;  // CR: published state of a conflict row (yhat, y, A[i,1..])
+    constexpr int CSS = 8;                // ... stride of a conflict row's granules in the slab
     const int row0 = LDSR ? g * a.rows_per : 0;
     // CR: per-conflict contributions of the step, behind the fixed block
     double* sh_ce = dyn_lds + kPrbLdsFixed;  // [64][2] of a row's EARLIER column (constant)
@@ -551,7 +553,9 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
         double yh[PRB_PF], yt[PRB_PF], dlast[PRB_PF];
         double pl = 0.0;
         int jl = 0;
-        double cst[3] = {0.0, 0.0, 0.0};  // CR, control wave: state of conflict row `lane`
+        double cst[CSN];  // CR, control wave: state of conflict row `lane` (yhat, y, A[i,1..AS])
+#pragma unroll
+        for (int t = 0; t < CSN; ++t) cst[t] = 0.0;
         if (control) {
             if (lane < ncols) {
                 pl = pold_sched[c0 + lane];
@@ -563,29 +567,35 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                 // with zeros (stale tags, as for the column slots)
                 const int nc = cp1 - cp0, ncw = max(nc, cp3 - cp2);
                 const unsigned long long ctag = prb_tag(b);
-                double* cs = a.cslab + (size_t)(b & 1) * 64 * 4 + (size_t)lane * 4;
+                double* cs = a.cslab + ((size_t)(b & 1) * 64 + lane) * CSS;
                 if (lane < nc) {
                     const int i = cfc.row;
                     if (i / a.rows_per == g) {
-                        double y0, y1, a1;
+                        double st[CSN];
                         if constexpr (LDSR) {
-                            y0 = (double)lds_r[i - row0];
-                            y1 = (LR == 1) ? 0.0 : (lds_s[i - row0] ? 1.0 : -1.0);
-                            a1 = (double)lds_a[i - row0];
+                            st[0] = (double)lds_r[i - row0];
+                            st[1] = (LR == 1) ? 0.0 : (lds_s[i - row0] ? 1.0 : -1.0);
+#pragma unroll
+                            for (int t = 0; t < AS; ++t) st[2 + t] = (double)lds_a[(i - row0) * AS + t];
+                        } else if constexpr (PK) {
+                            const float4 r = rec[(size_t)i];
+                            st[0] = (double)r.x;
+                            st[1] = (double)r.y;
+                            st[2] = (double)r.z;
+                            st[2 + AS - 1] = (double)r.w;
                         } else {
                             const typename Vec2<T>::type yv = yy2[(size_t)i];
-                            y0 = (double)yv.x;
-                            y1 = (double)yv.y;
-                            a1 = (double)A[(size_t)i];
+                            st[0] = (double)yv.x;
+                            st[1] = (double)yv.y;
+#pragma unroll
+                            for (int t = 0; t < AS; ++t) st[2 + t] = (double)A[(size_t)i * AS + t];
                         }
-                        prb_store_granule(cs, y0, ctag);
-                        prb_store_granule(cs + 1, y1, ctag);
-                        prb_store_granule(cs + 2, a1, ctag);
+#pragma unroll
+                        for (int t = 0; t < CSN; ++t) prb_store_granule(cs + t, st[t], ctag);
                     }
                 } else if (lane < ncw && (lane % a.G) == g) {
-                    prb_store_granule(cs, 0.0, ctag);
-                    prb_store_granule(cs + 1, 0.0, ctag);
-                    prb_store_granule(cs + 2, 0.0, ctag);
+#pragma unroll
+                    for (int t = 0; t < CSN; ++t) prb_store_granule(cs + t, 0.0, ctag);
                 }
             }
         } else if (worker) {
@@ -781,8 +791,8 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
             if constexpr (CR) {
                 if (control) {
                     if (lane < cp1 - cp0) {  // the published state of "my" conflict row
-                        if (!prb_poll<3>(a, a.cslab + (size_t)(b & 1) * 64 * 4 + (size_t)lane * 4,
-                                         prb_tag(b), cst))
+                        if (!prb_poll<CSN>(a, a.cslab + ((size_t)(b & 1) * 64 + lane) * CSS,
+                                           prb_tag(b), cst))
                             *sh_ok = 0;
                     }
                     // tables of step b+1 (consumed at its start)
@@ -848,15 +858,27 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                     sh_delta[lane] = 0.0;
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
-                    double c2 = 0.0, pb = 0.0;
+                    // of "my" conflict row: the earlier column's dA chain on the published state
+                    // (da[t] = dA_t of pcd._grad_anova, da[0] = x) -- its term of that column's
+                    // sums, and what its update will subtract from the row (pcd.py:124-133)
+                    double da[AS + 1], pb = 0.0;
+#pragma unroll
+                    for (int t = 0; t <= AS; ++t) da[t] = 0.0;
                     if (lane < nc) {
                         const double pa = sh_pold[qa];
                         pb = sh_pold[qb];
-                        const double dAa = xa * (cst[2] - pa * xa);
-                        c2 = lam * dAa;
-                        sh_ce[lane * 2] = dloss_dev(LOSS, cst[0], cst[1]) * dAa;
-                        sh_ce[lane * 2 + 1] = dAa * dAa;
+                        da[0] = xa;
+#pragma unroll
+                        for (int t = 1; t <= AS; ++t) da[t] = xa * (cst[1 + t] - pa * da[t - 1]);
+                        sh_ce[lane * 2] = dloss_dev(LOSS, cst[0], cst[1]) * da[AS];
+                        sh_ce[lane * 2 + 1] = da[AS] * da[AS];
                     }
+                    // the row as the earlier column leaves it for a given delta (stored as T)
+                    auto after_a = [&](double Da, double* a1, double& y0n) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int t = 0; t < AS; ++t) a1[t] = (double)(T)(cst[2 + t] - Da * da[t]);
+                        y0n = (double)(T)(cst[0] - lam * Da * da[AS]);
+                    };
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
                     // my column's conflict list (8 entries: index | role << 8, -1 = none)
@@ -879,10 +901,9 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                     double dl = 0.0, res = pl;
                     for (int round = 0; round <= ncols + 1; ++round) {
                         if (lane < nc) {  // the later column's term of "my" row
-                            const double Da = sh_delta[qa];
-                            const double a1 = (double)(T)(cst[2] - Da * xa);
-                            const double y0n = (double)(T)(cst[0] - Da * c2);
-                            const double dAb = xb * (a1 - pb * xb);
+                            double a1[AS], y0n;
+                            after_a(sh_delta[qa], a1, y0n);
+                            const double dAb = grad_factor<M>(a1, xb, pb);
                             sh_cv[lane * 2] = dloss_dev(LOSS, y0n, cst[1]) * dAb;
                             sh_cv[lane * 2 + 1] = dAb * dAb;
                         }
@@ -914,17 +935,32 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                     // the conflict rows' final state, by their owner: both updates in order
                     if (lane < nc && cfc.row / a.rows_per == g) {
                         const int i = cfc.row;
-                        const double Da = sh_delta[qa], Db = sh_delta[qb];
-                        const double a1 = (double)(T)(cst[2] - Da * xa);
-                        const double y0n = (double)(T)(cst[0] - Da * c2);
-                        const double dAb = xb * (a1 - pb * xb);
-                        const T a2 = (T)(a1 - Db * xb);
-                        const T y0f = (T)(y0n - lam * Db * dAb);
+                        const double Db = sh_delta[qb];
+                        double a1[AS], y0n;
+                        after_a(sh_delta[qa], a1, y0n);
+                        T a2[AS];
+                        double db = xb;  // dA chain of the later column on the updated row
+#pragma unroll
+                        for (int t = 0; t < AS; ++t) {
+                            const double dn = xb * (a1[t] - pb * db);
+                            a2[t] = (T)(a1[t] - Db * db);
+                            db = dn;
+                        }
+                        const T y0f = (T)(y0n - lam * Db * db);
                         if constexpr (LDSR) {
-                            lds_a[i - row0] = a2;
+#pragma unroll
+                            for (int t = 0; t < AS; ++t) lds_a[(i - row0) * AS + t] = a2[t];
                             lds_r[i - row0] = y0f;
+                        } else if constexpr (PK) {
+                            float4 o;
+                            o.x = (float)y0f;
+                            o.y = (float)cst[1];
+                            o.z = (float)a2[0];
+                            o.w = (float)a2[AS - 1];
+                            rec[(size_t)i] = o;
                         } else {
-                            A[(size_t)i] = a2;
+#pragma unroll
+                            for (int t = 0; t < AS; ++t) A[(size_t)i * AS + t] = a2[t];
                             yy[2 * (size_t)i] = y0f;
                         }
                     }

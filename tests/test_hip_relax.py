@@ -146,3 +146,57 @@ def test_estimator_default_schedule_uses_relaxed_runs(oracle):
     fm.fit(X, y)
     np.testing.assert_allclose(est.P_, fm.P_, rtol=0, atol=1e-9)
     np.testing.assert_allclose(est.w_, fm.w_, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("precision,options", [("f64", {}), ("f32", {}), ("f32", {"prb_lds": 0}),
+                                               ("f32", {"prb_lds": 0, "prb_pack": 0}),
+                                               ("f64", {"prb_groups": 7})])
+@pytest.mark.parametrize("loss", ["squared", "logistic"])
+def test_relaxed_runs_degree3_explicit_lower_order(oracle, loss, precision, options):
+    """Degree 3 with fit_lower='explicit' (BASELINE configs[2]'s shape): the degree-2 epoch on
+    P_[1] and the degree-3 epoch on P_[0] both run the reference order as merged steps -- the
+    conflict rows carry two cache values, rows in LDS, in packed 16-byte records or in plain
+    arrays -- against the oracle in natural order."""
+    from sparsepoly_amd.engine import HipEngine
+
+    X, y = _problem(loss, n=8_000, d=1_200, per_row=8, seed=12)
+    d, k = X.shape[1], 3
+    order = np.arange(d, dtype=np.int32)
+    eng = HipEngine(0, precision)
+    for key, val in options.items():
+        eng.set_option(key, val)
+    eng.set_data(X, y)
+    P0 = 0.05 * np.random.RandomState(1).randn(2, k, d)
+    lams = np.ones(k)
+    eng.set_params(P0, np.zeros(d), lams)
+    eng.configure("pcd", loss, "omegati", 3)
+    eng.init_pred(3, True, True)
+    eng.set_schedule("exact", order)
+    ic = np.arange(k, dtype=np.int32)
+    viol = []
+    for _ in range(2):
+        v = eng.cd_linear_epoch(0.5)
+        v += eng.pcd_epoch(1, 2, 50.0, 1e-3, 1.0, ic)
+        v += eng.pcd_epoch(0, 3, 50.0, 1e-3, 1.0, ic)
+        viol.append(v)
+    P, w = eng.get_params()
+    strict, merged = eng.n_batches, eng.get_option("relax_steps")
+    packed = eng.get_option("prb_pack_active")
+    assert eng.get_option("persistent_fallbacks") == 0
+    eng.close()
+    assert 0 < merged < 0.4 * strict, (strict, merged)
+    if precision == "f32" and options.get("prb_lds", 1) == 0:
+        assert packed == (0 if options.get("prb_pack", 1) == 0 else 1)
+    fm = oracle.OracleFM(degree=3, loss=loss, n_components=k, solver="pcd", regularizer="omegati",
+                         alpha=0.5, beta=50.0, gamma=1e-3, tol=0, max_iter=2, fit_linear=True,
+                         fit_lower="explicit", feature_order=order)
+    fm.fit(X, y, P_init=P0, lams_init=lams)
+    ref = [h[0] for h in fm.history]
+    if precision == "f64":
+        np.testing.assert_allclose(viol, ref, rtol=1e-9)
+        np.testing.assert_allclose(P, fm.P_, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(w, fm.w_, rtol=0, atol=1e-9)
+    else:
+        np.testing.assert_allclose(viol, ref, rtol=5e-5)
+        np.testing.assert_allclose(P, fm.P_, rtol=0, atol=2e-4)
+        np.testing.assert_allclose(w, fm.w_, rtol=0, atol=2e-4)

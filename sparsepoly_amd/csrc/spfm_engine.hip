@@ -1150,10 +1150,18 @@ struct spfm_engine {
         // row block resident in LDS (4-5 bytes per row: residual, or prediction + label sign)
         constexpr bool can_lr = std::is_same<T, float>::value;
         constexpr int LRV = (LOSS == LOSS_SQUARED) ? 1 : 2;
-        const PrbArgs pa = prb_args();
+        // relaxed runs: the merged steps of the reference order, as the pcd passes
+        bool relaxed = false;
+        if (relax_candidate()) {
+            rc = ensure_relax<T>();
+            if (rc) return rc;
+            relaxed = relax_state == 1;
+        }
+        const PrbArgs pa = relaxed ? relax_args() : prb_args();
         int lds_max = 0;
         HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
-        const size_t lds_lr = sizeof(double) * kPrbLdsFixed + (size_t)pa.rows_per * 5 + 16;
+        const size_t lds_lr = sizeof(double) * (kPrbLdsFixed + (relaxed ? kPrbLdsCR : 0)) +
+                              (size_t)pa.rows_per * 5 + 16;
         const bool use_lr = can_lr && prb_lds && lds_lr <= (size_t)lds_max && (LRV == 1 || y_pm1);
         const size_t lds_bytes = use_lr ? std::max(lds_lr, kPrbLds) : kPrbLds;
         if constexpr (can_lr) {
@@ -1167,12 +1175,25 @@ struct spfm_engine {
         hipLaunchKernelGGL(gather_sched_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
                            d_desc.as<ColDesc>(), w.as<double>(), prow_old.as<double>());
         HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));
+        if (relaxed) HIPC(hipMemsetAsync(r_cslab.p, 0, r_cslab.bytes, stream));
         {
             int prc = peer_clear(kPeerPcdOff, kPeerPbOff);
             if (prc) return prc;
         }
         prof_begin(4, nnz);
         bool launched = false;
+        auto launch_cr = [&](auto lr_tag, size_t lds) -> int {
+            constexpr int LRc = decltype(lr_tag)::value;
+            auto* fn = lin_prb_kernel<T, LOSS, LRc, false, true>;
+            HIPC(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+            if (!resident_ok((const void*)fn, kPrbThreads, lds, prb_G)) return kNotResident;
+            hipLaunchKernelGGL(fn, dim3(launch_groups(prb_G)), dim3(kPrbThreads), lds, stream, pa,
+                               r_eval.as<T>(), yy.as<T>(), prow_old.as<double>(),
+                               prb_cn.as<double>(), w.as<double>(), alpha, mu,
+                               prb_viol.as<double>());
+            return SPFM_OK;
+        };
         auto launch = [&](auto lr_tag, auto mg_tag, size_t lds) -> int {
             constexpr int LRc = decltype(lr_tag)::value;
             constexpr bool MGc = decltype(mg_tag)::value;
@@ -1188,8 +1209,19 @@ struct spfm_engine {
             return SPFM_OK;
         };
         int lrc = SPFM_OK;
+        if (relaxed) {
+            launched = true;
+            bool done = false;
+            if constexpr (can_lr) {
+                if (use_lr) {
+                    lrc = launch_cr(std::integral_constant<int, LRV>{}, lds_bytes);
+                    done = true;
+                }
+            }
+            if (!done) lrc = launch_cr(std::integral_constant<int, 0>{}, kPrbLds);
+        }
         if constexpr (can_lr) {
-            if (use_lr) {
+            if (use_lr && !launched) {
                 lrc = pa.n_ranks > 1
                           ? launch(std::integral_constant<int, LRV>{}, std::true_type{}, lds_bytes)
                           : launch(std::integral_constant<int, LRV>{}, std::false_type{}, lds_bytes);

@@ -1128,7 +1128,10 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
 // epoch start: workgroup 0 writes the new w[j] while others may still read the old one).
 // LR as in pcd_prb_kernel: 1 = residual word per row in LDS (squared loss), 2 = prediction
 // word + label sign (+-1 targets); float storage.  4-5 bytes per row: it always fits.
-template <typename T, int LOSS, int LR, bool MG = false>
+// CR = true: relaxed runs as in pcd_prb_kernel -- the conflict rows' state is (yhat or residual, y),
+// a row's later column sees yhat - u_a x_a (cd_linear.py:28-31); there is no regularizer chain, so
+// the rounds stop after the depth of the row dependencies.
+template <typename T, int LOSS, int LR, bool MG = false, bool CR = false>
 __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
     PrbArgs a, const T* __restrict__ eval, T* __restrict__ yy,
     const double* __restrict__ w_sched, const double* __restrict__ cn_sched,
@@ -1150,7 +1153,10 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
     static_assert(LR == 0 || (sizeof(T) == 4 && (LR == 2 || LOSS == LOSS_SQUARED)),
                   "LDS-resident rows: float storage");
     const int row0 = LR ? g * a.rows_per : 0;
-    T* lds_r = reinterpret_cast<T*>(dyn_lds + kPrbLdsFixed);  // [rows_per] residual or yhat
+    static_assert(!CR || !MG, "relaxed runs: single GPU");
+    double* sh_ce = dyn_lds + kPrbLdsFixed;  // CR: [64] term of a conflict row's EARLIER column
+    double* sh_cv = sh_ce + 64;              // CR: [64] ... of its LATER column (per round)
+    T* lds_r = reinterpret_cast<T*>(dyn_lds + kPrbLdsFixed + (CR ? kPrbLdsCR : 0));  // [rows_per] residual or yhat
     unsigned char* lds_s = reinterpret_cast<unsigned char*>(lds_r + a.rows_per);  // y > 0
     if constexpr (LR != 0) {
         const int nr = min(a.rows_per, a.n_rows - row0);
@@ -1196,12 +1202,31 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
         *sh_ok = 1;
         *sh_go = 0;
     }
+    // CR: see pcd_prb_kernel
+    int cp0 = 0, cp1 = 0, cp2 = 0, cp3 = 0;
+    PrbConf<T> cfc, cfn;
+    cfc.row = cfn.row = 0;
+    cfc.qq = cfn.qq = 0;
+    cfc.xa = cfc.xb = cfn.xa = cfn.xb = (T)0;
+    prb_u4 clq = {~0u, ~0u, ~0u, ~0u}, clqn = {~0u, ~0u, ~0u, ~0u};
+    if constexpr (CR) {
+        if (control) {
+            const PrbConf<T>* cfa = reinterpret_cast<const PrbConf<T>*>(a.cf);
+            cp0 = a.cf_ptr[0];
+            cp1 = a.cf_ptr[min(1, a.nb)];
+            cp2 = a.cf_ptr[min(2, a.nb)];
+            cp3 = a.cf_ptr[min(3, a.nb)];
+            if (lane < cp1 - cp0) cfc = cfa[cp0 + lane];
+            if (lane < c1 - c0) clq = reinterpret_cast<const prb_u4*>(a.clist)[c0 + lane];
+        }
+    }
     for (int b = 0; b < a.nb; ++b) {
         const int ncols = c1 - c0;
         const int c4 = (b + 4 <= a.nb) ? a.bptr[b + 4] : c3;
         double yh[PRB_PF];
         double wl = 0.0, cnl = 0.0;
         int jl = 0;
+        double cst[2] = {0.0, 0.0};  // CR, control wave: (yhat or residual, y) of conflict row `lane`
         int n2e0 = 0, n2e1 = 0;
         unsigned long long lm2 = 0ull;
         const unsigned long long lmu =
@@ -1238,6 +1263,22 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 wl = w_sched[c0 + lane];
                 cnl = cn_sched[c0 + lane];
                 if (g == 0) jl = a.desc[c0 + lane].j;
+            }
+            if constexpr (CR) {  // the owners publish the conflict rows' state
+                const int nc = cp1 - cp0, ncw = max(nc, cp3 - cp2);
+                const unsigned long long ctag = prb_tag(b);
+                double* cs = a.cslab + ((size_t)(b & 1) * 64 + lane) * 8;
+                if (lane < nc) {
+                    if (cfc.row / a.rows_per == g) {
+                        double y0, y1;
+                        row_state(cfc.row, y0, y1);
+                        prb_store_granule(cs, y0, ctag);
+                        prb_store_granule(cs + 1, y1, ctag);
+                    }
+                } else if (lane < ncw && (lane % a.G) == g) {
+                    prb_store_granule(cs, 0.0, ctag);
+                    prb_store_granule(cs + 1, 0.0, ctag);
+                }
             }
         } else if (worker) {
             double yt[PRB_PF];
@@ -1293,6 +1334,16 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                     prb_collect_quarter<1>(a, b, part, lane, ncols, sh_quart, kPrbParts);
                 if (!ok) *sh_ok = 0;
             }
+            if constexpr (CR) {
+                if (lane < cp1 - cp0) {
+                    if (!prb_poll<2>(a, a.cslab + ((size_t)(b & 1) * 64 + lane) * 8, prb_tag(b), cst))
+                        *sh_ok = 0;
+                }
+                const PrbConf<T>* cfa = reinterpret_cast<const PrbConf<T>*>(a.cf);
+                if (lane < cp2 - cp1) cfn = cfa[cp1 + lane];
+                clqn = prb_u4{~0u, ~0u, ~0u, ~0u};
+                if (lane < c2 - c1) clqn = reinterpret_cast<const prb_u4*>(a.clist)[c1 + lane];
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // part sums in LDS
         if (!*sh_ok) break;
@@ -1304,12 +1355,68 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
                 if (!prb_cross_gpu<1>(a, g, b, lane, &tot)) *sh_ok = 0;
             }
             const bool valid = lane < ncols;
-            double upd = tot;           // cd_linear.py:19-24
-            upd += alpha * wl;
+            bool relaxed_step = false;
+            if constexpr (CR) relaxed_step = (cp1 - cp0) > 0;
             const double inv = mu * cnl + alpha;
-            upd /= inv;
-            if (!valid) upd = 0.0;
-            sh_delta[lane] = upd;
+            double upd = 0.0;
+            if (!relaxed_step) {
+                upd = tot;  // cd_linear.py:19-24
+                upd += alpha * wl;
+                upd /= inv;
+                if (!valid) upd = 0.0;
+                sh_delta[lane] = upd;
+            }
+            if constexpr (CR) {
+                if (relaxed_step) {
+                    // the conflict rows' terms in rounds (lane c <-> conflict row c, lane q <->
+                    // column q): a row's later column sees the prediction after the earlier
+                    // column's update (stored as T); no chain couples the columns, so the rounds
+                    // end with the depth of the row dependencies
+                    const int nc = cp1 - cp0;
+                    const int qa = cfc.qq & 0xff, qb = cfc.qq >> 8;
+                    const double xa = (double)cfc.xa, xb = (double)cfc.xb;
+                    sh_delta[lane] = 0.0;
+                    if (lane < nc) sh_ce[lane] = dloss_dev(LOSS, cst[0], cst[1]) * xa;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    int le[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const unsigned wv = clq[t >> 1];
+                        le[t] = (int)(short)((t & 1) ? (wv >> 16) : (wv & 0xffffu));
+                    }
+                    double g0 = tot;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (le[t] >= 0 && (le[t] >> 8) == 0) g0 += sh_ce[le[t] & 0xff];
+                    for (int round = 0; round <= ncols + 1; ++round) {
+                        if (lane < nc) {
+                            const double y0n = (double)(T)(cst[0] - sh_delta[qa] * xa);
+                            sh_cv[lane] = dloss_dev(LOSS, y0n, cst[1]) * xb;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        double gq = g0;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (le[t] >= 0 && (le[t] >> 8) != 0) gq += sh_cv[le[t] & 0xff];
+                        double un = gq;
+                        un += alpha * wl;
+                        un /= inv;
+                        if (!valid) un = 0.0;
+                        const bool same = __double_as_longlong(un) == __double_as_longlong(upd);
+                        upd = un;
+                        sh_delta[lane] = upd;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        if (__ballot(!same) == 0ull) break;
+                    }
+                    if (lane < nc && cfc.row / a.rows_per == g) {  // the row's final prediction
+                        const double y0n = (double)(T)(cst[0] - sh_delta[qa] * xa);
+                        row_update(cfc.row, y0n, sh_delta[qb] * xb);
+                    }
+                }
+            }
             if (g == 0 && valid) {
                 w[jl] = wl - upd;
                 viol_pos[c0 + lane] = fabs(upd);
@@ -1350,6 +1457,16 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
         ne1 = n2e1;
         lm0 = lm1;
         lm1 = lm2;
+        if constexpr (CR) {
+            if (control) {
+                cp0 = cp1;
+                cp1 = cp2;
+                cp2 = cp3;
+                cp3 = a.cf_ptr[min(b + 4, a.nb)];
+                cfc = cfn;
+                clq = clqn;
+            }
+        }
         c0 = c1;
         c1 = c2;
         c2 = c3;

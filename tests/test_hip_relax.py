@@ -1,6 +1,6 @@
 """Relaxed runs: a schedule of tiny steps -- the reference's own visiting order,
 `schedule='exact'`, the estimators' default: 2.6 row-disjoint columns per step on BASELINE config 2
--- is run by the degree-2 pcd pass as merged steps of ~20 consecutive columns.  The few rows two
+-- is run by cd_linear and the degree-2 / degree-3 pcd passes as merged steps of ~20 consecutive columns.  The few rows two
 columns of a merged step share are taken out of the row blocks' parallel sums and replayed, in
 column order and with their intermediate state, by every workgroup's chain.  The result is the
 sequential sweep's (pcd.py:97-135): checked against the oracle in the SAME order and against the

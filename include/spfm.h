@@ -179,6 +179,29 @@ int spfm_pcd_epoch(spfm_handle h, int order_idx, int degree, double beta, double
 int spfm_pbcd_epoch(spfm_handle h, int order_idx, int degree, double beta, double gamma,
                     double eta, double* viol);
 
+/* -- host-stepped epochs: user-defined regularizer objects ---------------------------------
+ * The reference's regularizers are duck-typed plug-ins (regularizer/__init__.py:8-15,
+ * base.py:27-34): any object with init_cache_* / compute_cache_* / prox_cd | prox_bcd /
+ * update_cache_* can be registered.  The six built-ins run inside the device chains; for any
+ * other object the epoch is stepped from the host.  Between spfm_host_epoch_begin and
+ * spfm_host_epoch_end (one reference epoch call; the schedule's dependent steps b = 0 ..
+ * n_batches-1 in order, for pcd once per component after spfm_host_pass_begin(s)):
+ *   spfm_host_step_sums   the step's column sums: pcd sums_out[ncols][2] = (sum dloss dA,
+ *                         sum dA^2) (pcd.py:54-59); pbcd sums_out[ncols][k+1] = grad[0..k),
+ *                         sum_s inv_step_sizes[s] (pbcd.py:60-70); all-reduced over the ranks
+ *   (caller)              pcd.py:61-68 / pbcd.py:68-79 with the object's prox and cache hooks,
+ *                         column by column in the step's visiting order
+ *   spfm_host_step_apply  p_new[ncols] (pcd) / p_new, p_old [ncols][k] (pbcd): parameters
+ *                         written, rows scatter-updated (pcd.py:119-133 / pbcd.py:135-146)
+ * Two host round trips per dependent step: the plug-in surface honoured, not accelerated.
+ * sparsepoly_amd.engine.HipEngine.{pcd,pbcd}_epoch_host drive it; the estimators take this path
+ * for any registered regularizer that is not one of the six built-in classes. */
+int spfm_host_epoch_begin(spfm_handle h, int order_idx, int degree);
+int spfm_host_pass_begin(spfm_handle h, int component);
+int spfm_host_step_sums(spfm_handle h, int step, double* sums_out);
+int spfm_host_step_apply(spfm_handle h, int step, const double* p_new, const double* p_old);
+int spfm_host_epoch_end(spfm_handle h, double* viol);
+
 /* psgd.psgd_epoch (optimizer/psgd.py:125-199): one pass over indices_samples (a
  * permutation of 0..n_samples-1; sparse_factorization_machines.py:98,124-125) in
  * minibatches of batch_size rows (the last one may be shorter, psgd.py:177).  Updates

@@ -186,6 +186,23 @@ __global__ void begin_pass_kernel(Ctl* ctl, const int32_t* comp_order, const dou
     }
 }
 
+// host-stepped epochs (user-defined regularizer objects): the caller computed the step's new
+// coordinates; pnew_delta[q] holds p_new on entry and p_old - p_new on return (what
+// pcd_sync_kernel consumes), P[s, j] and sum_viol are updated (pcd.py:119-121)
+__global__ void host_apply_pcd_kernel(const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc,
+                                      int ncols, double* __restrict__ P, int d,
+                                      const double* __restrict__ pold,
+                                      double* __restrict__ pnew_delta,
+                                      double* __restrict__ viol_col) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ncols) return;
+    const double pn = pnew_delta[q], dl = pold[q] - pn;
+    const int j = desc[q].j;
+    P[(size_t)ctl->s * d + j] = pn;
+    pnew_delta[q] = dl;
+    viol_col[j] += fabs(dl);
+}
+
 // undo of begin_pass_kernel's counter step for a pass that was announced but not launched
 __global__ void unbegin_pass_kernel(Ctl* ctl) {
     if (threadIdx.x == 0 && blockIdx.x == 0) ctl->pass -= 1;

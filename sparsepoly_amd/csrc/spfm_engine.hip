@@ -44,6 +44,16 @@ void schedule_relax(int64_t, int32_t, const int64_t*, const int32_t*, const int3
                     std::vector<int32_t>&, std::vector<int32_t>&, std::vector<int32_t>&,
                     std::vector<int32_t>&, std::vector<int64_t>&, std::vector<int64_t>&,
                     std::vector<int16_t>&, std::vector<uint8_t>&);
+// spfm_ingest.hip: device-side CSR -> CSC (one stable radix sort by column id)
+template <typename T>
+hipError_t device_csr_to_csc(int64_t, int32_t, int64_t, const int64_t*, const int32_t*, const T*,
+                             int64_t*, int32_t*, T*, int*, hipStream_t);
+extern template hipError_t device_csr_to_csc<float>(int64_t, int32_t, int64_t, const int64_t*,
+                                                    const int32_t*, const float*, int64_t*,
+                                                    int32_t*, float*, int*, hipStream_t);
+extern template hipError_t device_csr_to_csc<double>(int64_t, int32_t, int64_t, const int64_t*,
+                                                     const int32_t*, const double*, int64_t*,
+                                                     int32_t*, double*, int*, hipStream_t);
 }  // namespace spfm
 
 using namespace spfm;
@@ -617,8 +627,83 @@ struct spfm_engine {
         return SPFM_OK;
     }
 
+    // CSR ingest on the DEVICE (round 3; SURVEY.md 8f N4 as written): the CSR arrays go up once
+    // (they are the engine's row-major image anyway), the CSC image is their stable radix sort
+    // by column id (spfm_ingest.hip); the host keeps only the CSC *structure* (indptr, row ids),
+    // copied back for the schedule and stream builders.  Returns kIngestFallback when the device
+    // path cannot be used (the host-thread transposition then takes over).
+    bool ingest_device = true;
+    int ingest_device_used = 0;
+    static constexpr int kIngestFallback = 2;
+    template <typename T>
+    int set_data_csr_device(const int64_t* indptr, const int32_t* indices, const double* data,
+                            const double* y) {
+        std::vector<T> rv((size_t)(nnz > 0 ? nnz : 1));
+        const int T_ = (nnz >= (1 << 20)) ? schedule_threads() : 1;
+        {
+            std::vector<std::thread> pool;
+            auto work = [&](int tid) {
+                const int64_t per = (nnz + T_ - 1) / T_;
+                const int64_t lo = per * tid, hi = std::min<int64_t>(nnz, lo + per);
+                for (int64_t ii = lo; ii < hi; ++ii) rv[(size_t)ii] = (T)data[ii];
+            };
+            for (int t = 1; t < T_; ++t) pool.emplace_back(work, t);
+            work(0);
+            for (auto& th : pool) th.join();
+        }
+        std::vector<T> hy((size_t)n * 2 + 2);
+        for (int64_t i = 0; i < n; ++i) {
+            hy[(size_t)2 * i] = (T)0;
+            hy[(size_t)2 * i + 1] = (T)y[i];
+        }
+        const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
+        HIPC(cptr.alloc(sizeof(int64_t) * ((size_t)d + 1)));
+        HIPC(cidx.alloc(sizeof(int32_t) * nz));
+        HIPC(cval.alloc(sizeof(T) * nz));
+        HIPC(rptr.alloc(sizeof(int64_t) * ((size_t)n + 1)));
+        HIPC(ridx.alloc(sizeof(int32_t) * nz));
+        HIPC(rval.alloc(sizeof(T) * nz));
+        HIPC(yy.alloc(sizeof(T) * 2 * (size_t)(n > 0 ? n : 1)));
+        HIPC(col_norm.alloc(sizeof(double) * (size_t)d));
+        HIPC(hipMemcpyAsync(rptr.p, indptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice,
+                            stream));
+        if (nnz > 0) {
+            HIPC(hipMemcpyAsync(ridx.p, indices, sizeof(int32_t) * (size_t)nnz,
+                                hipMemcpyHostToDevice, stream));
+            HIPC(hipMemcpyAsync(rval.p, rv.data(), sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice,
+                                stream));
+        }
+        if (n > 0)
+            HIPC(hipMemcpyAsync(yy.p, hy.data(), sizeof(T) * 2 * (size_t)n, hipMemcpyHostToDevice,
+                                stream));
+        HIPC(hipStreamSynchronize(stream));
+        int invalid = 0;
+        hipError_t e = device_csr_to_csc<T>(n, d, nnz, rptr.as<int64_t>(), ridx.as<int32_t>(),
+                                            rval.as<T>(), cptr.as<int64_t>(), cidx.as<int32_t>(),
+                                            cval.as<T>(), &invalid, stream);
+        if (e != hipSuccess) {  // e.g. no room for the sort's scratch: the host path takes over
+            (void)hipGetLastError();
+            return kIngestFallback;
+        }
+        if (invalid)
+            FAIL(SPFM_ERR_INVALID,
+                 "set_data: CSR must have sorted, duplicate-free column indices in [0, d)");
+        h_cptr.resize((size_t)d + 1);
+        h_cidx.resize((size_t)nnz);
+        HIPC(hipMemcpyAsync(h_cptr.data(), cptr.p, sizeof(int64_t) * ((size_t)d + 1),
+                            hipMemcpyDeviceToHost, stream));
+        if (nnz > 0)
+            HIPC(hipMemcpyAsync(h_cidx.data(), cidx.p, sizeof(int32_t) * (size_t)nnz,
+                                hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL((col_norm_kernel<T>), dim3(cdiv((int64_t)d * 64, kBlock)), dim3(kBlock), 0,
+                           stream, d, cptr.as<int64_t>(), cval.as<T>(), col_norm.as<double>());
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(stream));
+        return SPFM_OK;
+    }
+
     // CSR ingest (replaces get_dataset's X.tocsc(), dataset.py:119-123, too): the CSC image
-    // is built by host threads, the CSR image is the input itself
+    // is built on the device (above) or by host threads; the CSR image is the input itself
     int set_data_csr(int64_t n_, int32_t d_, const int64_t* indptr, const int32_t* indices,
                      const double* data, const double* y) {
         if (n_ < 0 || d_ <= 0 || !indptr || !y) FAIL(SPFM_ERR_INVALID, "set_data: bad arguments");
@@ -626,6 +711,23 @@ struct spfm_engine {
         if (indptr[0] != 0) FAIL(SPFM_ERR_INVALID, "set_data: indptr[0] != 0");
         for (int64_t i = 0; i < n_; ++i)
             if (indptr[i + 1] < indptr[i]) FAIL(SPFM_ERR_INVALID, "set_data: indptr not monotone");
+        ingest_device_used = 0;
+        if (ingest_device && indptr[n_] < ((int64_t)1 << 31)) {
+            if (have_params && d_ != d) have_params = false;
+            n = n_;
+            d = d_;
+            nnz = indptr[n_];
+            int rc = dtype == SPFM_F32 ? set_data_csr_device<float>(indptr, indices, data, y)
+                                       : set_data_csr_device<double>(indptr, indices, data, y);
+            if (rc == SPFM_OK) {
+                ingest_device_used = 1;
+                return data_installed(y);
+            }
+            if (rc != kIngestFallback) {
+                have_data = false;
+                return rc;
+            }
+        }
         std::vector<int64_t> cp, perm;
         std::vector<int32_t> ci;
         if (!csr_to_csc(n_, d_, indptr, indices, cp, ci, perm))
@@ -2536,6 +2638,207 @@ struct spfm_engine {
         return epoch_epilogue(viol);
     }
 
+    // ================================================= host-stepped epochs
+    // User-defined regularizer objects (regularizer/__init__.py:8-15, base.py:27-34: the
+    // reference's duck-typed plug-in protocol) cannot run inside the device chains.  For them the
+    // epoch is stepped from the host: per dependent step the device forms the column sums
+    // (pcd.py:54-59 / pbcd.py:60-67), the caller applies the update rule with its own
+    // prox_cd / prox_bcd and cache hooks in visiting order, the device scatter-updates
+    // (pcd.py:124-133 / pbcd.py:135-144).  Two host round trips per step: a path that honours
+    // the plug-in surface, not a fast one.  Multi-kernel kernels; with several ranks the sums are
+    // all-reduced like any other step.
+    int host_order = -1, host_degree = 0;
+    std::vector<double> host_stage;
+
+    int host_epoch_begin(int order_idx, int degree) {
+        int rc = epoch_prologue();
+        if (rc) return rc;
+        if (solver != SPFM_SOLVER_PCD && solver != SPFM_SOLVER_PBCD)
+            FAIL(SPFM_ERR_INVALID, "host-stepped epochs: configure for pcd or pbcd");
+        if (order_idx < 0 || order_idx >= n_orders) FAIL(SPFM_ERR_INVALID, "bad order index");
+        if (!degree_ok(degree)) FAIL(SPFM_ERR_INVALID, "bad degree");
+        const int M = kind_of(degree);
+        if (solver == SPFM_SOLVER_PCD) {
+            rc = ensure_p();
+            if (rc) return rc;
+            pt_valid = false;
+            HIPC(hipMemsetAsync(ctl.p, 0, sizeof(Ctl), stream));
+            rc = dtype == SPFM_F32 ? pcd_precompute_all_dispatch<float>(M, order_idx)
+                                   : pcd_precompute_all_dispatch<double>(M, order_idx);
+            if (rc) return rc;
+            pt_valid = false;
+        } else {
+            rc = ensure_pt();
+            if (rc) return rc;
+            p_valid = false;
+            rc = dtype == SPFM_F32 ? host_pbcd_precompute<float>(M, order_idx)
+                                   : host_pbcd_precompute<double>(M, order_idx);
+            if (rc) return rc;
+        }
+        host_order = order_idx;
+        host_degree = degree;
+        return sync();
+    }
+    template <typename T>
+    int host_pbcd_precompute(int M, int order_idx) {
+        if (n == 0) return SPFM_OK;
+        double* Po = Pt.as<double>() + (size_t)order_idx * k * d;
+#define SPFM_HPRE(MM)                                                                        \
+    hipLaunchKernelGGL((pbcd_precompute_kernel<T, MM>), dim3(cdiv(n * k, kBlock)), dim3(kBlock), \
+                       0, stream, n, k, rptr.as<int64_t>(), ridx.as<int32_t>(), rval.as<T>(), Po, \
+                       A.as<T>())
+        switch (M) {
+            case 0: SPFM_HPRE(0); break;
+            case 2: SPFM_HPRE(2); break;
+            case 3: SPFM_HPRE(3); break;
+            case 4: SPFM_HPRE(4); break;
+            case 5: SPFM_HPRE(5); break;
+            case 6: SPFM_HPRE(6); break;
+            default: FAIL(SPFM_ERR_UNSUPPORTED, "degree outside 2..6");
+        }
+#undef SPFM_HPRE
+        HIPC(hipGetLastError());
+        return SPFM_OK;
+    }
+    int host_pass_begin(int s) {  // pcd: the component of the following steps (pcd.py:92)
+        if (host_order < 0 || solver != SPFM_SOLVER_PCD)
+            FAIL(SPFM_ERR_INVALID, "host_pass_begin: call spfm_host_epoch_begin (pcd) first");
+        if (s < 0 || s >= k) FAIL(SPFM_ERR_INVALID, "component out of range");
+        Ctl hc;
+        std::memset(&hc, 0, sizeof hc);
+        hc.s = s;
+        hc.lam = h_lams[(size_t)s];
+        HIPC(hipMemcpyAsync(ctl.p, &hc, sizeof hc, hipMemcpyHostToDevice, stream));
+        return sync();
+    }
+    int host_step_check(int b) {
+        if (host_order < 0) FAIL(SPFM_ERR_INVALID, "host step: call spfm_host_epoch_begin first");
+        if (b < 0 || b >= n_batches()) FAIL(SPFM_ERR_INVALID, "host step: step index out of range");
+        return SPFM_OK;
+    }
+
+    template <typename T, int M>
+    int host_sums_pcd(int b, double* out) {
+        const int c0 = batch_ptr[b], nc = batch_ptr[b + 1] - c0;
+        if (nc == 0) return SPFM_OK;
+        double* Po = P.as<double>() + (size_t)host_order * k * d;
+        hipLaunchKernelGGL((pcd_grad_kernel<T, M>), dim3(nc), dim3(kBlock), 0, stream, ctl.as<Ctl>(),
+                           d_desc.as<ColDesc>() + c0, cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
+                           (size_t)n * Kind<M>::AS, yy.as<typename Vec2<T>::type>(), Po, d, loss,
+                           part.as<double>(), pold.as<double>());
+        HIPC(hipGetLastError());
+        int rc = allreduce(part.as<double>(), (size_t)2 * nc);
+        if (rc) return rc;
+        HIPC(hipMemcpyAsync(out, part.p, sizeof(double) * 2 * (size_t)nc, hipMemcpyDeviceToHost,
+                            stream));
+        return sync();
+    }
+    template <typename T, int M>
+    int host_apply_pcd(int b, const double* p_new) {
+        const int c0 = batch_ptr[b], nc = batch_ptr[b + 1] - c0;
+        if (nc == 0) return SPFM_OK;
+        double* Po = P.as<double>() + (size_t)host_order * k * d;
+        HIPC(hipMemcpyAsync(delta.p, p_new, sizeof(double) * (size_t)nc, hipMemcpyHostToDevice,
+                            stream));
+        hipLaunchKernelGGL(host_apply_pcd_kernel, dim3(cdiv(nc, 64)), dim3(64), 0, stream,
+                           ctl.as<Ctl>(), d_desc.as<ColDesc>() + c0, nc, Po, d, pold.as<double>(),
+                           delta.as<double>(), viol_col.as<double>());
+        hipLaunchKernelGGL((pcd_sync_kernel<T, M>), dim3(nc), dim3(kBlock), 0, stream, ctl.as<Ctl>(),
+                           d_desc.as<ColDesc>() + c0, cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
+                           (size_t)n * Kind<M>::AS, yy.as<T>(), delta.as<double>(),
+                           pold.as<double>());
+        HIPC(hipGetLastError());
+        return sync();  // the caller's p_new buffer is free again
+    }
+    template <typename T, int M, int L, int C>
+    int host_sums_pbcd(int b, double* out) {
+        const int c0 = batch_ptr[b], nc = batch_ptr[b + 1] - c0;
+        if (nc == 0) return SPFM_OK;
+        double* Po = Pt.as<double>() + (size_t)host_order * k * d;
+        const size_t shm = sizeof(double) * ((size_t)(kBlock / L) * k + 16);
+        hipLaunchKernelGGL((pbcd_grad_kernel<T, M, L, C>), dim3(nc * kPbW), dim3(kBlock), shm, stream,
+                           d_desc.as<ColDesc>() + c0, cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
+                           yy.as<typename Vec2<T>::type>(), Po, k, loss, part.as<double>());
+        HIPC(hipGetLastError());
+        const size_t np = (size_t)nc * kPbW * (k + 1);
+        int rc = allreduce(part.as<double>(), np);
+        if (rc) return rc;
+        host_stage.resize(np);
+        HIPC(hipMemcpyAsync(host_stage.data(), part.p, sizeof(double) * np, hipMemcpyDeviceToHost,
+                            stream));
+        rc = sync();
+        if (rc) return rc;
+        for (int q = 0; q < nc; ++q)  // the column's kPbW partial vectors in fixed order
+            for (int s = 0; s <= k; ++s) {
+                double acc = 0.0;
+                for (int w = 0; w < kPbW; ++w)
+                    acc += host_stage[((size_t)q * kPbW + w) * (k + 1) + s];
+                out[(size_t)q * (k + 1) + s] = acc;
+            }
+        return SPFM_OK;
+    }
+    template <typename T, int M, int L, int C>
+    int host_apply_pbcd(int b, const double* p_new, const double* p_old) {
+        const int c0 = batch_ptr[b], nc = batch_ptr[b + 1] - c0;
+        if (nc == 0) return SPFM_OK;
+        if (!p_old) FAIL(SPFM_ERR_INVALID, "host step (pbcd): p_old is required");
+        double* Po = Pt.as<double>() + (size_t)host_order * k * d;
+        host_stage.assign((size_t)4 * nc, 0.0);
+        for (int q = 0; q < nc; ++q) host_stage[(size_t)4 * q + 2] = 1.0;  // shrink factor f = 1
+        HIPC(hipMemcpyAsync(delta.p, p_new, sizeof(double) * (size_t)nc * k, hipMemcpyHostToDevice,
+                            stream));
+        HIPC(hipMemcpyAsync(pold.p, p_old, sizeof(double) * (size_t)nc * k, hipMemcpyHostToDevice,
+                            stream));
+        HIPC(hipMemcpyAsync(pb_scal.p, host_stage.data(), sizeof(double) * 4 * (size_t)nc,
+                            hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL((pbcd_sync_kernel<T, M, L, C>), dim3(nc * kPbW), dim3(kBlock), 0, stream,
+                           d_desc.as<ColDesc>() + c0, cidx.as<int32_t>(), cval.as<T>(), A.as<T>(),
+                           yy.as<T>(), lams.as<double>(), k, Po, delta.as<double>(),
+                           pold.as<double>(), pb_scal.as<double>(), viol_col.as<double>());
+        HIPC(hipGetLastError());
+        return sync();
+    }
+    // dispatch on (storage type, degree, component lanes) as the multi-kernel engine does
+    template <typename T, int M>
+    int host_step_tm(bool sums, int b, double* out, const double* p_new, const double* p_old) {
+        if (solver == SPFM_SOLVER_PCD)
+            return sums ? host_sums_pcd<T, M>(b, out) : host_apply_pcd<T, M>(b, p_new);
+#define SPFM_HPB(LL, CC) \
+    return sums ? host_sums_pbcd<T, M, LL, CC>(b, out) : host_apply_pbcd<T, M, LL, CC>(b, p_new, p_old)
+        if (k <= 8) SPFM_HPB(8, 1);
+        if (k <= 16) SPFM_HPB(16, 1);
+        if (k <= 32) SPFM_HPB(32, 1);
+        if (k <= 64) SPFM_HPB(64, 1);
+        if (k <= 128) SPFM_HPB(64, 2);
+        SPFM_HPB(64, 4);
+#undef SPFM_HPB
+    }
+    template <typename T>
+    int host_step_t(bool sums, int b, double* out, const double* p_new, const double* p_old) {
+        switch (kind_of(host_degree)) {
+            case 0: return host_step_tm<T, 0>(sums, b, out, p_new, p_old);
+            case 2: return host_step_tm<T, 2>(sums, b, out, p_new, p_old);
+            case 3: return host_step_tm<T, 3>(sums, b, out, p_new, p_old);
+            case 4: return host_step_tm<T, 4>(sums, b, out, p_new, p_old);
+            case 5: return host_step_tm<T, 5>(sums, b, out, p_new, p_old);
+            case 6: return host_step_tm<T, 6>(sums, b, out, p_new, p_old);
+        }
+        FAIL(SPFM_ERR_UNSUPPORTED, "degree outside 2..6");
+    }
+    int host_step(bool sums, int b, double* out, const double* p_new, const double* p_old) {
+        int rc = host_step_check(b);
+        if (rc) return rc;
+        if ((sums && !out) || (!sums && !p_new)) FAIL(SPFM_ERR_INVALID, "host step: NULL buffer");
+        return dtype == SPFM_F32 ? host_step_t<float>(sums, b, out, p_new, p_old)
+                                 : host_step_t<double>(sums, b, out, p_new, p_old);
+    }
+    int host_epoch_end(double* viol) {
+        if (host_order < 0) FAIL(SPFM_ERR_INVALID, "host_epoch_end: no host-stepped epoch open");
+        host_order = -1;
+        if (solver == SPFM_SOLVER_PCD) pt_valid = false;
+        return epoch_epilogue(viol);
+    }
+
     // ================================================================== psgd
     // regularizer.init_cache_psgd exists for l1 / l21 / squaredl12 / squaredl21 only
     // (reference regularizer/*.py); psgd has no all-subsets variant.
@@ -3045,6 +3348,27 @@ int spfm_pbcd_epoch(spfm_handle h, int order_idx, int degree, double beta, doubl
     return h->pbcd_epoch(order_idx, degree, beta, gamma, eta, viol);
 }
 
+int spfm_host_epoch_begin(spfm_handle h, int order_idx, int degree) {
+    GUARD(h);
+    return h->host_epoch_begin(order_idx, degree);
+}
+int spfm_host_pass_begin(spfm_handle h, int component) {
+    GUARD(h);
+    return h->host_pass_begin(component);
+}
+int spfm_host_step_sums(spfm_handle h, int step, double* sums_out) {
+    GUARD(h);
+    return h->host_step(true, step, sums_out, nullptr, nullptr);
+}
+int spfm_host_step_apply(spfm_handle h, int step, const double* p_new, const double* p_old) {
+    GUARD(h);
+    return h->host_step(false, step, nullptr, p_new, p_old);
+}
+int spfm_host_epoch_end(spfm_handle h, double* viol) {
+    GUARD(h);
+    return h->host_epoch_end(viol);
+}
+
 int spfm_psgd_epoch(spfm_handle h, int degree, double alpha, double beta, double gamma,
                     double eta0, int learning_rate, double power_t, int64_t batch_size,
                     const int32_t* indices_samples, int64_t n_samples, int fit_linear,
@@ -3289,6 +3613,8 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->relax_state = 0;
     } else if (k == "prb_pack") {  // packed row records for degree-3 passes (rows in global memory)
         h->prb_pack = value != 0;
+    } else if (k == "ingest_device") {  // CSR -> CSC on the device (default) or by host threads
+        h->ingest_device = value != 0;
     } else if (k == "relax") {  // merged steps for schedules of tiny steps
         h->relax_on = value != 0;
         h->relax_state = 0;
@@ -3408,6 +3734,8 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "persistent_active")
         *value = h->have_schedule && (h->prb_usable() || h->wide_usable());
     else if (k == "relax") *value = h->relax_on;
+    else if (k == "ingest_device") *value = h->ingest_device;
+    else if (k == "ingest_device_used") *value = h->ingest_device_used;
     else if (k == "prb_pack_active") *value = h->prb_pack_active;
     else if (k == "relax_steps")
         *value = h->relax_state == 1 ? (int)h->r_batch_ptr.size() - 1 : 0;

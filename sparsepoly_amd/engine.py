@@ -239,6 +239,92 @@ class HipEngine(object):
             C.byref(v)))
         return v.value
 
+    # ---------------------------------------- host-stepped epochs (plug-in regularizers)
+    _MU = {"squared": 1.0, "logistic": 0.25, "squared_hinge": 2.0}  # loss.py:18,32,59
+
+    def _host_steps(self):
+        sched = self.get_schedule()
+        return sched.order, sched.batch_ptr
+
+    def pcd_epoch_host(self, reg, P, lams, loss, order_idx, degree, beta, gamma, eta,
+                       indices_component):
+        """``pcd.pcd_epoch`` (optimizer/pcd.py:71-137) for a regularizer OBJECT that is not one
+        of the device built-ins: the device forms every dependent step's column sums and
+        scatter-updates, the object's ``compute_cache_pcd_all / compute_cache_pcd / prox_cd /
+        update_cache_pcd`` run here, column by column in visiting order (include/spfm.h
+        "host-stepped epochs").  ``P``: the (n_components, n_features) host array of this order,
+        updated in place (it mirrors the device copy).  Returns sum_viol."""
+        mu = self._MU[loss]
+        order, bp = self._host_steps()
+        self._check(self._lib.spfm_host_epoch_begin(self._h, int(order_idx), int(degree)))
+        reg.compute_cache_pcd_all(P, degree)                                   # pcd.py:91
+        viol = 0.0
+        sums = np.empty((int(np.diff(bp).max()), 2))
+        for s in indices_component:                                            # :92
+            s = int(s)
+            self._check(self._lib.spfm_host_pass_begin(self._h, s))
+            reg.compute_cache_pcd(P, degree, s)                                # :96
+            for b in range(len(bp) - 1):
+                cols = order[bp[b]:bp[b + 1]]
+                nc = len(cols)
+                if nc == 0:
+                    continue
+                self._check(self._lib.spfm_host_step_sums(self._h, b,
+                                                          sums.ctypes.data_as(_capi._dp)))
+                p_new = np.empty(nc)
+                for q in range(nc):                                            # :97, in order
+                    j = int(cols[q])
+                    p_old = float(P[s, j])
+                    inv = mu * sums[q, 1] + beta                               # :61-62
+                    upd = (lams[s] * sums[q, 0] + beta * p_old) / inv          # :64-66
+                    pn = float(reg.prox_cd(p_old - eta * upd, eta * gamma / inv, degree, j))
+                    viol += abs(p_old - pn)                                    # :119-121
+                    P[s, j] = pn
+                    p_new[q] = pn
+                    reg.update_cache_pcd(P, degree, s, j)                      # :135
+                self._check(self._lib.spfm_host_step_apply(
+                    self._h, b, p_new.ctypes.data_as(_capi._dp), None))
+        dv = C.c_double()
+        self._check(self._lib.spfm_host_epoch_end(self._h, C.byref(dv)))
+        return viol
+
+    def pbcd_epoch_host(self, reg, Pt, lams, loss, order_idx, degree, beta, gamma, eta):
+        """``pbcd.pbcd_epoch`` (optimizer/pbcd.py:82-148) for a regularizer object:
+        ``compute_cache_pbcd / prox_bcd (in place) / update_cache_pbcd`` run here.  ``Pt``: the
+        (n_features, n_components) host array of this order, updated in place."""
+        mu = self._MU[loss]
+        order, bp = self._host_steps()
+        k = Pt.shape[1]
+        lams = np.asarray(lams, dtype=np.float64)
+        self._check(self._lib.spfm_host_epoch_begin(self._h, int(order_idx), int(degree)))
+        reg.compute_cache_pbcd(Pt, degree)                                     # pbcd.py:109
+        viol = 0.0
+        sums = np.empty((int(np.diff(bp).max()), k + 1))
+        for b in range(len(bp) - 1):
+            cols = order[bp[b]:bp[b + 1]]
+            nc = len(cols)
+            if nc == 0:
+                continue
+            self._check(self._lib.spfm_host_step_sums(self._h, b, sums.ctypes.data_as(_capi._dp)))
+            p_new = np.empty((nc, k))
+            p_old = np.empty((nc, k))
+            for q in range(nc):                                                # :110, in order
+                j = int(cols[q])
+                p_old[q] = Pt[j]
+                inv = mu * sums[q, k] + beta                                   # :68-72
+                grad = (sums[q, :k] * lams + beta * Pt[j]) / inv               # :74-77
+                pj = Pt[j] - eta * grad                                        # :78
+                reg.prox_bcd(pj, eta * gamma / inv, degree, j)                 # :79 (in place)
+                viol += float(np.abs(p_old[q] - pj).sum())                     # :146
+                Pt[j] = pj
+                p_new[q] = pj
+                reg.update_cache_pbcd(Pt, degree, j)                           # :145
+            self._check(self._lib.spfm_host_step_apply(
+                self._h, b, p_new.ctypes.data_as(_capi._dp), p_old.ctypes.data_as(_capi._dp)))
+        dv = C.c_double()
+        self._check(self._lib.spfm_host_epoch_end(self._h, C.byref(dv)))
+        return viol
+
     def psgd_epoch(self, degree, alpha, beta, gamma, eta0, learning_rate, power_t, batch_size,
                    indices_samples, fit_linear, it):
         """``psgd.psgd_epoch`` (optimizer/psgd.py:125-199).  Returns (sum_loss, it)."""

@@ -11,8 +11,12 @@ gives a user of the reference: ``eval``, the pcd protocol (``init_cache_pcd``,
 (``init_cache_pbcd``, ``compute_cache_pbcd``, ``prox_bcd``, ``update_cache_pbcd``) and the
 full-matrix ``prox`` of the psgd solver, with the reference's state attributes (``_cache``,
 ``_dcache``, ``_abs_p``, ``_norms``) readable and writable.  They are checked call by call against
-traces recorded from the reference (``tests/golden/g5_reg_traces.npz``).  A user-defined Python
-regularizer cannot run on the device; the estimators reject it with ``ValueError``.
+traces recorded from the reference (``tests/golden/g5_reg_traces.npz``).  A user-defined
+regularizer -- any object with this protocol registered under a name in an estimator's
+``_REGULARIZERS``, as in the reference (``base.py:27-34``) -- cannot run on the device; the
+estimators honour it through host-stepped epochs (``HipEngine.pcd_epoch_host`` /
+``pbcd_epoch_host``: the device forms every step's column sums and scatter-updates, the object's
+prox and cache hooks run on the host; ``include/spfm.h``).
 
 Conventions as in the reference: pcd works on ``P`` of shape (n_components, n_features), pbcd and
 psgd on (n_features, n_components); ``eval`` takes (..., n_features, n_components) (stacks allowed)
@@ -321,7 +325,10 @@ class OmegaTI(_Regularizer):
             for v in self._abs_p:
                 self._cache_all_subsets *= 1.0 + v
             return
-        self._cache[:] = _esp_table(self._abs_p, degree)
+        # the caches are sized for the top degree; a lower-order epoch (fit_lower='explicit')
+        # fills entries 0..degree and leaves the rest at 0 (omegati.py:62-74)
+        self._cache[:] = 0.0
+        self._cache[:degree + 1] = _esp_table(self._abs_p, degree)
         self._dcache[:] = 0.0
         self._dcache[1] = 1.0
 

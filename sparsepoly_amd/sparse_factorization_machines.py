@@ -194,6 +194,26 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         """Copy the live device parameters into P_ / w_ (in place)."""
         engine.get_params(self.P_, self.w_, skip_P=not with_P)
 
+    @staticmethod
+    def _is_builtin_regularizer(obj):
+        from . import regularizer as _r
+
+        return type(obj) in (_r.L1, _r.L21, _r.SquaredL12, _r.SquaredL21, _r.OmegaTI, _r.OmegaCS)
+
+    def _pcd_epoch(self, engine, order_idx, degree, beta, gamma, indices_component):
+        """one ``pcd.pcd_epoch`` call: the device epoch, or -- plug-in regularizer -- the
+        host-stepped one on the live ``self.P_[order_idx]`` (as the reference's view, :227-228)"""
+        if self._plugin_reg is None:
+            return engine.pcd_epoch(order_idx, degree, beta, gamma, self.eta0, indices_component)
+        return engine.pcd_epoch_host(self._plugin_reg, self.P_[order_idx], self.lams_, self.loss,
+                                     order_idx, degree, beta, gamma, self.eta0, indices_component)
+
+    def _pbcd_epoch(self, engine, order_idx, degree, beta, gamma):
+        if self._plugin_reg is None:
+            return engine.pbcd_epoch(order_idx, degree, beta, gamma, self.eta0)
+        return engine.pbcd_epoch_host(self._plugin_reg, self._Pt_host[order_idx], self.lams_,
+                                      self.loss, order_idx, degree, beta, gamma, self.eta0)
+
     # ------------------------------------------------------------ epoch drivers
     def _fit_pcd(self, engine, n_samples, n_features, rng, conflict_csc):
         """Restates _fit_pcd, sparse_factorization_machines.py:175-258."""
@@ -201,6 +221,8 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         indices_component = np.arange(self.n_components, dtype=np.int32)
         converged = False
         alpha, beta, gamma = self._scaled(n_samples)
+        if self._plugin_reg is not None:  # regularizer.init_cache_pcd(...) (:194)
+            self._plugin_reg.init_cache_pcd(self.degree, n_features, self.n_components)
         if not self.shuffle:
             self._set_schedule(engine, indices_feature, conflict_csc)
         it = 0
@@ -214,9 +236,9 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 viol += engine.cd_linear_epoch(alpha)
             if self.fit_lower == "explicit":
                 for deg in range(2, self.degree):
-                    viol += engine.pcd_epoch(self.degree - deg, deg, beta, gamma, self.eta0,
-                                             indices_component)
-            viol += engine.pcd_epoch(0, self.degree, beta, gamma, self.eta0, indices_component)
+                    viol += self._pcd_epoch(engine, self.degree - deg, deg, beta, gamma,
+                                            indices_component)
+            viol += self._pcd_epoch(engine, 0, self.degree, beta, gamma, indices_component)
 
             if (self.callback is not None) and it % self.n_calls == 0:
                 self._sync_params(engine)  # pcd writes through self.P_[0] (:227-228)
@@ -239,6 +261,10 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         indices_feature = np.arange(n_features, dtype=np.int32)
         converged = False
         alpha, beta, gamma = self._scaled(n_samples)
+        if self._plugin_reg is not None:
+            # regularizer.init_cache_pbcd(...) (:282) and the transposed working copy (:285)
+            self._plugin_reg.init_cache_pbcd(self.degree, n_features, self.n_components)
+            self._Pt_host = np.array(self.P_.swapaxes(1, 2))
         if not self.shuffle:
             self._set_schedule(engine, indices_feature, conflict_csc)
         it = 0
@@ -251,8 +277,8 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 viol += engine.cd_linear_epoch(alpha)
             if self.fit_lower == "explicit":
                 for deg in range(2, self.degree):
-                    viol += engine.pbcd_epoch(self.degree - deg, deg, beta, gamma, self.eta0)
-            viol += engine.pbcd_epoch(0, self.degree, beta, gamma, self.eta0)
+                    viol += self._pbcd_epoch(engine, self.degree - deg, deg, beta, gamma)
+            viol += self._pbcd_epoch(engine, 0, self.degree, beta, gamma)
 
             if (self.callback is not None) and it % self.n_calls == 0:
                 self._sync_params(engine, with_P=False)
@@ -327,7 +353,11 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         n_samples, n_features = X.shape
         rng = check_random_state(self.random_state)
         self._get_loss(self.loss)
-        self._get_regularizer(self.regularizer)
+        reg_obj = self._get_regularizer(self.regularizer)
+        # a registered regularizer that is not one of the six built-in classes cannot run in the
+        # device chains: its epochs are stepped from the host, calling the object's own prox and
+        # cache hooks (include/spfm.h "host-stepped epochs")
+        self._plugin_reg = None if self._is_builtin_regularizer(reg_obj) else reg_obj
 
         if not (self.warm_start and hasattr(self, "w_")):
             self.w_ = np.zeros(n_features, dtype=np.double)
@@ -410,7 +440,18 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
             self.w_ = np.ascontiguousarray(self.w_, dtype=np.double)
             engine.set_params(self.P_, self.w_, self.lams_)
             # regularizer.init_cache_pcd / init_cache_pbcd (:194, :282), incl. their errors
-            engine.configure(self.solver, self.loss, self.regularizer, self.degree)
+            if self._plugin_reg is not None:
+                if self.solver == "psgd":
+                    raise ValueError("solver='psgd' needs one of the built-in regularizers "
+                                     "(its full-matrix prox runs on the device).")
+                if self.distributed:
+                    raise ValueError("a user-defined regularizer object runs on one GPU "
+                                     "(distributed=False).")
+                # the device-side regularizer is never called on this path; 'l1' only satisfies
+                # the solver / regularizer pairing check of spfm_configure
+                engine.configure(self.solver, self.loss, "l1", self.degree)
+            else:
+                engine.configure(self.solver, self.loss, self.regularizer, self.degree)
             if self.solver == "psgd":
                 # X.count_nonzero() (dataset.py:32,84): stored entries, n*d when dense
                 nnz = X.nnz if sp.issparse(X) else n_samples * n_features
@@ -427,6 +468,7 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 converged, self.n_iter_ = self._fit_pbcd(engine, n_samples, n_features, rng,
                                                          conflict_csc)
             self.n_steps_per_sweep_ = engine.n_batches
+            self.__dict__.pop("_Pt_host", None)
             if self.schedule_ is None:
                 self.schedule_ = engine.get_schedule(self.schedule)
             keep = key is not None
@@ -447,6 +489,8 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
     def __getstate__(self):
         state = dict(super().__getstate__())
         state.pop("_device_session", None)  # a device handle is not picklable
+        state.pop("_plugin_reg", None)      # a user's regularizer object may not be either
+        state.pop("_Pt_host", None)
         return state
 
     def _finish_fit(self, converged):

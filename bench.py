@@ -28,6 +28,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
   exact_schedule  the estimators' default schedule (reference order, parity at fit() level):
                   dependent steps per sweep and ms per iteration from 3 component passes
   f64             ms per iteration with float64 storage (the reference's own arithmetic)
+  concurrent_fits four independent fits of the workload at once on the one GPU (a regularisation
+                  path; sparsepoly_amd/concurrent.py): aggregate epochs/s and bytes/s.  `value`
+                  stays the rate of ONE fit
 N > 1: rows are sharded over the ranks; the persistent passes exchange their per-step totals
 through peer-mapped slabs inside the kernels (no per-step collective).  Default is WEAK scaling:
 N times the rows and columns (the family that ends in BASELINE configs[4]: 10M x 1M on 8 GPUs),
@@ -435,7 +438,9 @@ def main():
 
     # ---- the estimators' default schedule ('exact': the reference's own order) and f64 storage
     extras = {}
-    if rank == 0 and world == 1 and not args.no_extras and cfg["solver"] == "pcd":
+    skip = os.environ.get("SPFM_BENCH_SKIP", "").split(",")  # diagnostics: leave extras out
+    if rank == 0 and world == 1 and not args.no_extras and cfg["solver"] == "pcd" \
+            and "exact" not in skip:
         e2, _, ts = make_engine(args.precision, "exact")
         nb2 = e2.n_batches
         iteration(e2, comps=1)  # builds the entry stream, warms up
@@ -459,7 +464,8 @@ def main():
             "measured": "1 cd_linear epoch (%.0f ms) + 3 top-order component passes (%.0f ms "
                         "each), extrapolated to %d passes per order" % (1e3 * t_lin, 1e3 * t_pass, K),
             "is_estimator_default": True}
-    if rank == 0 and world == 1 and not args.no_extras and args.precision == "f32":
+    if rank == 0 and world == 1 and not args.no_extras and args.precision == "f32" \
+            and "f64" not in skip:
         e3, _, _ = make_engine("f64", args.schedule)
         iteration(e3)
         torch.cuda.synchronize()
@@ -469,6 +475,51 @@ def main():
         extras["f64"] = {"ms_per_iteration": round(1e3 * (time.perf_counter() - t1), 2),
                          "schedule": args.schedule}
         e3.close()
+
+    # ---- four independent fits of the same workload at once (a regularisation path): one handle,
+    # stream and host thread per fit, their persistent passes side by side on disjoint CUs
+    if rank == 0 and world == 1 and not args.no_extras and cfg["solver"] == "pcd":
+        import threading
+
+        from sparsepoly_amd.engine import co_tenancy
+
+        F, its = 4, 3
+        with co_tenancy(F):
+            engs = [make_engine(args.precision, args.schedule)[0] for _ in range(F)]
+        for e in engs:
+            iteration(e)  # builds the entry streams, warms up
+        torch.cuda.synchronize()
+        bar = threading.Barrier(F + 1)
+        spent = [0.0] * F
+
+        def fit_loop(f):
+            bar.wait()
+            t = time.perf_counter()
+            for _ in range(its):
+                iteration(engs[f])
+            spent[f] = time.perf_counter() - t
+
+        th = [threading.Thread(target=fit_loop, args=(f,)) for f in range(F)]
+        for t in th:
+            t.start()
+        bar.wait()
+        t1 = time.perf_counter()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t1
+        fb = [int(e.get_option("persistent_fallbacks")) for e in engs]
+        for e in engs:
+            e.close()
+        extras["concurrent_fits"] = {
+            "fits": F, "iterations_each": its,
+            "ms_per_iteration_per_fit": [round(1e3 * t / its, 1) for t in spent],
+            "aggregate_epochs_per_s": round(F * its / wall, 3),
+            "aggregate_GBps": round(F * its * b_alg / wall / 1e9, 1),
+            "aggregate_frac_of_hbm_peak": round(F * its * b_alg / wall / 1e9 / HBM_PEAK_GBS, 4),
+            "persistent_fallbacks": fb,
+            "note": "independent fits (different models, same matrix); each equals its solo run "
+                    "bit for bit (tests/test_hip_concurrent.py); `value` above is ONE fit"}
 
     # ---- CPU baseline: the oracle on one full iteration of the same workload
     cpu = None

@@ -9,6 +9,15 @@ import os
 
 import numpy as np
 
+# Concurrent fits (sparsepoly_amd/concurrent.py) give every fit its own HIP stream.  The HIP
+# runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and, once
+# those are taken, doubles streams up on a queue -- two persistent passes on one queue run one
+# after the other.  Four fits plus the null stream (PyTorch's default stream, any synchronous
+# hipMemcpy) are five streams.  The variable is read when the HIP runtime initialises, i.e. at the
+# first HIP call of the process: setting it here is early enough unless the host program has
+# already touched the GPU -- it can export the variable itself then.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPFM_HIP_LIB") or os.path.join(_HERE, "lib", "libspfm_hip.so")
 

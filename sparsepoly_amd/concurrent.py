@@ -1,0 +1,94 @@
+"""Independent fits side by side on ONE GPU.
+
+A regularisation path, a cross-validation grid, a bag of restarts: F estimators over the same
+(or different) data whose fits do not depend on each other.  One fit's coordinate-descent pass is
+a chain of dependent steps on 64 of the 256 CUs; the other CUs idle.  Here every
+fit gets its own engine handle, HIP stream and host thread, and the persistent passes of up to
+four fits run at the same time on disjoint CUs: each fit is the same kernels on the same inputs
+as its solo ``fit`` (bit-identical results), the aggregate throughput is ~3.8x at F = 4
+(tools/concurrent_fits.py).
+
+The reference's answer to the same use-case is ``warm_start`` -- one fit after the other
+(sparse_factorization_machines.py:380-391 of the reference); this is the MI355X-side
+complement, not a replacement: ``warm_start`` chains keep working as before.
+"""
+import threading
+
+from . import engine as _engine
+
+# HIP spreads a process's streams over four hardware queues, and a persistent pass of the
+# default 64 row blocks takes a quarter of the CUs: more fits at once would only queue up
+MAX_CONCURRENT = 4
+
+
+def fit_concurrently(estimators, X, y, max_concurrent=MAX_CONCURRENT):
+    """Fit every estimator of ``estimators`` on ``(X, y)``, up to ``max_concurrent`` at a time on
+    the GPU.  ``X`` / ``y`` may be one data set for all of them or sequences with one entry per
+    estimator (cross-validation folds).  Returns the list of fitted estimators (the same
+    objects); the first exception raised by a fit is re-raised after all fits have ended."""
+    ests = list(estimators)
+    if not ests:
+        return ests
+    if int(max_concurrent) < 1:
+        raise ValueError("max_concurrent must be >= 1.")
+    per_fit_data = isinstance(X, (list, tuple))
+    if per_fit_data:
+        if not isinstance(y, (list, tuple)) or len(X) != len(ests) or len(y) != len(ests):
+            raise ValueError("X and y must hold one entry per estimator.")
+    for e in ests:
+        if getattr(e, "distributed", False):
+            raise ValueError("concurrent fits run on one GPU (distributed=False).")
+        if getattr(e, "warm_start", False) and getattr(e, "_device_session", None) is not None:
+            # a kept device session was sized for a solo fit (all CUs): start it afresh
+            e.release_device()
+    n_threads = min(int(max_concurrent), len(ests))
+    todo = list(enumerate(ests))[::-1]
+    lock = threading.Lock()
+    errors = []
+
+    def work():
+        while True:
+            with lock:
+                if not todo or errors:
+                    return
+                i, est = todo.pop()
+            try:
+                est.fit(X[i] if per_fit_data else X, y[i] if per_fit_data else y)
+            except BaseException as exc:  # re-raised by the caller's thread
+                with lock:
+                    errors.append(exc)
+                return
+
+    _engine._capi.load()  # once, before the threads race for it
+    with _engine.co_tenancy(n_threads):
+        threads = [threading.Thread(target=work, name="spfm-fit-%d" % t) for t in range(n_threads)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
+    return ests
+
+
+def fit_path(estimator, X, y, max_concurrent=MAX_CONCURRENT, **grid):
+    """Clones of ``estimator`` with the parameter values of ``grid`` (keyword -> sequence, all of
+    one length; e.g. ``gamma=[1e-3, 1e-4, 1e-5]``), fitted side by side.  Returns the fitted
+    clones in grid order; ``estimator`` itself is not touched."""
+    from sklearn.base import clone
+
+    if not grid:
+        raise ValueError("fit_path needs at least one parameter sequence (e.g. gamma=[...]).")
+    lengths = {len(v) for v in grid.values()}
+    if len(lengths) != 1:
+        raise ValueError("all parameter sequences must have the same length.")
+    valid = estimator.get_params()
+    for name in grid:
+        if name not in valid:
+            raise ValueError("%r is not a parameter of %s." % (name, type(estimator).__name__))
+    ests = []
+    for i in range(lengths.pop()):
+        e = clone(estimator)
+        e.set_params(**{name: values[i] for name, values in grid.items()})
+        ests.append(e)
+    return fit_concurrently(ests, X, y, max_concurrent=max_concurrent)

@@ -634,6 +634,7 @@ struct spfm_engine {
     // path cannot be used (the host-thread transposition then takes over).
     bool ingest_device = true;
     int ingest_device_used = 0;
+    int co_tenants = 1;  // persistent passes of other handles expected on the device at the same time
     static constexpr int kIngestFallback = 2;
     template <typename T>
     int set_data_csr_device(const int64_t* indptr, const int32_t* indices, const double* data,
@@ -1475,7 +1476,9 @@ struct spfm_engine {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
             return true;
-        const int64_t sharers = shm.hdr ? n_ranks : 1;  // host-shm communicator: ranks on one GPU
+        // host-shm communicator: ranks on one GPU; co_tenants: handles of this process whose
+        // persistent passes run side by side (concurrent fits, one stream each)
+        const int64_t sharers = (int64_t)(shm.hdr ? n_ranks : 1) * co_tenants;
         return (int64_t)per_cu * ncu >= (int64_t)G * sharers;
     }
     static constexpr int kNotResident = 1;  // internal: the launch was not made, nothing changed
@@ -1646,7 +1649,12 @@ struct spfm_engine {
         std::vector<PrbConf<T>> hcf(ncf ? ncf : 1);
         {
             std::vector<T> hv((size_t)(nnz > 0 ? nnz : 1));
-            HIPC(hipMemcpy(hv.data(), cval.p, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToHost));
+            // (on the handle's own stream: a copy on the null stream would create that stream,
+            // which then holds one of the process's few hardware queues for good -- and
+            // concurrent fits, one stream each, end up two to a queue)
+            HIPC(hipMemcpyAsync(hv.data(), cval.p, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToHost,
+                                stream));
+            HIPC(hipStreamSynchronize(stream));
             for (size_t c = 0; c < ncf; ++c) {
                 hcf[c].row = cf_row[c];
                 hcf[c].qq = cf_qq[c];
@@ -3469,7 +3477,8 @@ int spfm_peer_alloc(spfm_handle h, char* handle64) {
                      hipGetErrorString(ae) + "); use the per-step collective";
             return SPFM_ERR_RUNTIME;
         }
-        if (hipMemset(p, 0, sizeof(double) * spfm_engine::kPeerDoubles) != hipSuccess) {
+        if (hipMemsetAsync(p, 0, sizeof(double) * spfm_engine::kPeerDoubles, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) {
             (void)hipFree(p);
             h->err = "peer slab memset failed";
             return SPFM_ERR_RUNTIME;
@@ -3523,10 +3532,11 @@ int spfm_peer_connect(spfm_handle h, int n_ranks, int rank, const char* handles)
     }
     if (h->peer_tab_pcd.alloc(sizeof(double*) * 8) != hipSuccess ||
         h->peer_tab_pb.alloc(sizeof(double*) * 8) != hipSuccess ||
-        hipMemcpy(h->peer_tab_pcd.p, t1.data(), sizeof(double*) * (size_t)n_ranks,
-                  hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(h->peer_tab_pb.p, t2.data(), sizeof(double*) * (size_t)n_ranks,
-                  hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpyAsync(h->peer_tab_pcd.p, t1.data(), sizeof(double*) * (size_t)n_ranks,
+                       hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(h->peer_tab_pb.p, t2.data(), sizeof(double*) * (size_t)n_ranks,
+                       hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) {
         h->err = "peer table upload failed";
         return SPFM_ERR_RUNTIME;
     }
@@ -3613,6 +3623,29 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->relax_state = 0;
     } else if (k == "prb_pack") {  // packed row records for degree-3 passes (rows in global memory)
         h->prb_pack = value != 0;
+    } else if (k == "co_tenants") {  // concurrent fits: handles sharing the device's CUs
+        if (value < 1 || value > 64) {
+            h->err = "co_tenants must be in [1, 64]";
+            return SPFM_ERR_INVALID;
+        }
+        h->co_tenants = value;
+        // every tenant keeps to its share of the CUs (one persistent workgroup per CU)
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+        const int share = std::max(1, ncu / value);
+        if (h->prb_G > share) {
+            h->prb_G = share;
+            h->prb_ready = false;
+            h->relax_state = 0;
+        }
+        if (h->pbprb_G > share) {
+            h->pbprb_G = share;
+            h->pb_stream_ready = false;
+        }
+        if (h->pcdw_G > share) {
+            h->pcdw_G = share;
+            h->wide_ready = false;
+        }
     } else if (k == "ingest_device") {  // CSR -> CSC on the device (default) or by host threads
         h->ingest_device = value != 0;
     } else if (k == "relax") {  // merged steps for schedules of tiny steps
@@ -3735,6 +3768,7 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
         *value = h->have_schedule && (h->prb_usable() || h->wide_usable());
     else if (k == "relax") *value = h->relax_on;
     else if (k == "ingest_device") *value = h->ingest_device;
+    else if (k == "co_tenants") *value = h->co_tenants;
     else if (k == "ingest_device_used") *value = h->ingest_device_used;
     else if (k == "prb_pack_active") *value = h->prb_pack_active;
     else if (k == "relax_steps")

@@ -38,6 +38,27 @@ def canonical_csc(X):
     return Xc
 
 
+# handles created inside `co_tenancy(n)` announce that n of them train side by side on one GPU
+# (sparsepoly_amd/concurrent.py): every persistent pass keeps to 1/n of the CUs
+_CO_TENANTS = 1
+
+
+class co_tenancy(object):
+    def __init__(self, n):
+        self.n = max(1, int(n))
+
+    def __enter__(self):
+        global _CO_TENANTS
+        self._old = _CO_TENANTS
+        _CO_TENANTS = self.n
+        return self
+
+    def __exit__(self, *exc):
+        global _CO_TENANTS
+        _CO_TENANTS = self._old
+        return False
+
+
 class HipEngine(object):
     def __init__(self, device=0, precision="f32"):
         if precision not in _capi.DTYPES:
@@ -53,6 +74,8 @@ class HipEngine(object):
         self.n = self.d = self.k = self.n_orders = None
         self.order = None
         self.n_batches = None
+        if _CO_TENANTS > 1:
+            self.set_option("co_tenants", _CO_TENANTS)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -479,6 +479,14 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 engine.close()
         return self._finish_fit(converged)
 
+    def fit_path(self, X, y, max_concurrent=4, **grid):
+        """Clones of this estimator over a parameter grid (``gamma=[...]``, ``beta=[...]``, ... all
+        of one length), fitted side by side on the GPU; see sparsepoly_amd/concurrent.py.  Each
+        clone equals its own solo ``fit`` bit for bit."""
+        from .concurrent import fit_path
+
+        return fit_path(self, X, y, max_concurrent=max_concurrent, **grid)
+
     def release_device(self):
         """Free the device session kept by ``warm_start=True`` (data, schedule, stream)."""
         cached = getattr(self, "_device_session", None)

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""F independent fits of BASELINE config 2 on ONE GPU at the same time (a regularisation path:
+same matrix and schedule, different gamma): one engine handle, stream and host thread per fit; the
+persistent passes of the fits run side by side on disjoint CUs (64 workgroups each).  Prints one
+JSON line per F: wall time per iteration (cd_linear epoch + one pcd epoch over 30 components) of
+the slowest fit, aggregate epochs per second, and whether every fit equals its solo run bitwise.
+
+    python tools/concurrent_fits.py [F ...]      (default 1 2 3 4)
+"""
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sparsepoly_amd.engine import HipEngine  # noqa: E402
+from sparsepoly_amd.synth import make_problem  # noqa: E402
+
+K, BETA, ALPHA = 30, 10.0, 1.0
+GAMMAS = [1e-4, 2e-4, 5e-5, 1e-3, 3e-4, 7e-5, 2e-3, 4e-4]
+ITERS = int(os.environ.get("ITERS", "3"))
+
+
+def make_engine(X, y, P0, F, sched="colored"):
+    d = X.shape[1]
+    eng = HipEngine(0, "f32")
+    if F > 1:
+        eng.set_option("co_tenants", F)
+    eng.set_data(X, y)
+    eng.set_params(P0, np.zeros(d), np.ones(K))
+    eng.configure("pcd", "squared", "squaredl12", 2)
+    eng.init_pred(2, True, False)
+    eng.set_schedule(sched, np.arange(d, dtype=np.int32))
+    return eng
+
+
+def iterate(eng, gamma, iters, out, idx, barrier=None):
+    ic = np.arange(K, dtype=np.int32)
+    if barrier is not None:
+        barrier.wait()
+    t0 = time.perf_counter()
+    v = []
+    for _ in range(iters):
+        v.append(eng.cd_linear_epoch(ALPHA) + eng.pcd_epoch(0, 2, BETA, gamma, 1.0, ic))
+    out[idx] = (time.perf_counter() - t0, v)
+
+
+def main():
+    Fs = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
+    if os.environ.get("WITH_TORCH"):   # as in bench.py: torch's HIP runtime loaded first
+        import torch
+
+        print("torch sum on its default (null) stream:",
+              float(torch.ones(1000, device="cuda").sum().item()))
+        torch.cuda.synchronize()
+        print("torch", torch.__version__, torch.version.hip, flush=True)
+    X, y = make_problem(1_000_000, 100_000, 50, 0)
+    d = X.shape[1]
+    nnz = X.nnz
+    P0 = 0.01 * np.random.RandomState(0).randn(1, K, d)
+    solo = {}
+    for _ in range(int(os.environ.get("PRE", "0"))):   # handles created and closed beforehand
+        e = make_engine(X, y, P0, 1, os.environ.get("PRE_SCHED", "colored"))
+        o = [None]
+        if os.environ.get("PRE_RUN", "1") == "1":
+            iterate(e, GAMMAS[0], 1, o, 0)
+        e.close()
+    for F in Fs:
+        engs = [make_engine(X, y, P0, F) for _ in range(F)]
+        out = [None] * F
+        for f, e in enumerate(engs):          # warm-up: builds the entry streams
+            iterate(e, GAMMAS[f], 1, out, f)
+        barrier = threading.Barrier(F)
+        th = [threading.Thread(target=iterate, args=(engs[f], GAMMAS[f], ITERS, out, f, barrier))
+              for f in range(F)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        wall = time.perf_counter() - t0
+        res = []
+        for f, e in enumerate(engs):
+            P, w = e.get_params()
+            res.append((P, w, e.get_y_pred()))
+        fallbacks = [e.get_option("persistent_fallbacks") for e in engs]
+        for e in engs:
+            e.close()
+        same = None
+        if F == 1:
+            solo[0] = res[0]
+        if F > 1 and not os.environ.get("NO_CHECK"):
+            if 0 not in solo:
+                solo[0] = None
+            # every fit against its own solo run (fit 0: the F = 1 run above; the others: now)
+            same = []
+            for f in range(F):
+                if f == 0 and solo.get(0) is not None:
+                    ref = solo[0]
+                else:
+                    e = make_engine(X, y, P0, 1)
+                    o = [None]
+                    iterate(e, GAMMAS[f], 1 + ITERS, o, 0)
+                    Pq, wq = e.get_params()
+                    ref = (Pq, wq, e.get_y_pred())
+                    e.close()
+                same.append(bool(all(np.array_equal(a, b) for a, b in zip(res[f], ref))))
+        ms_iter = 1e3 * wall / ITERS
+        agg = F * ITERS / wall
+        print(json.dumps({
+            "fits": F, "iterations": ITERS, "ms_per_iteration_wall": round(ms_iter, 1),
+            "ms_per_iteration_per_fit": [round(1e3 * o[0] / ITERS, 1) for o in out],
+            "aggregate_epochs_per_s": round(agg, 3),
+            "aggregate_GBps_pcd": round(F * 30 * 28.0 * nnz / (wall / ITERS) / 1e9, 1),
+            "equals_solo_bitwise": same, "persistent_fallbacks": fallbacks}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

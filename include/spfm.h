@@ -294,7 +294,20 @@ int spfm_set_option(spfm_handle h, const char* key, int value);
  * rows in global memory work on packed 16-byte row records), "persistent_failed" (0: try the
  * persistent passes again after a recorded fall-back), test hooks "debug_spin_max" (polls of one
  * in-kernel wait before a persistent pass gives up, default 2^21) and "debug_drop_group" (the next
- * N persistent launches lack their last workgroup, i.e. time out).
+ * N persistent launches lack their last workgroup, i.e. time out), "ingest_device" (0/1, default 1:
+ * spfm_set_data_csr transposes on the device -- one stable radix sort of the entries by column id;
+ * 0, or no room for the sort's scratch: host threads), "co_tenants" (1..64, default 1: the number
+ * of handles of this process whose persistent passes run at the same time on this device --
+ * independent fits, one handle and one host thread each; the handle then sizes its passes to
+ * 1/co_tenants of the CUs and its residency check to the shared device.  Set it before the
+ * schedule.  Handles are independent objects: calls on DIFFERENT handles may be made from
+ * different threads at the same time, calls on one handle must not overlap).
+ *
+ * The library never issues work on the null stream (every handle owns a non-blocking stream):
+ * concurrent handles do not serialise on each other or on the host program's default stream.
+ * The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); a host program
+ * that wants more than three concurrent handles next to its own streams should raise it (the
+ * Python package defaults it to 8).
  *
  * Failure semantics of the persistent passes (all-or-nothing epochs, as the reference's epoch
  * functions): if a pass cannot run to its end -- its workgroups are not all resident, a peer GPU
@@ -309,7 +322,8 @@ int spfm_set_option(spfm_handle h, const char* key, int value);
  * 2 LDS prediction + label sign), "pbprb_active", "wide_active", "wide_lds_active",
  * "prb_pack_active", "relax_steps" (merged steps per degree-2 pcd sweep, 0 = strict steps),
  * "persistent_fallbacks", "persistent_failed", "n_ranks" (ranks of the attached communicator),
- * "peer_ready" (in-kernel cross-GPU exchange connected and verified) */
+ * "peer_ready" (in-kernel cross-GPU exchange connected and verified), "ingest_device_used"
+ * (1 if the last spfm_set_data_csr transposed on the device), "co_tenants" */
 int spfm_get_option(spfm_handle h, const char* key, int* value);
 
 /* diagnostic ("prb_stamps" option): accumulated shader cycles per phase of the last

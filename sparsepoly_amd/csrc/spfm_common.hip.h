@@ -46,6 +46,8 @@ enum {
     BR_OMEGACS_DCACHE = 1,   // omegacs.py:90-96   negative _dcache: recompute with degree-1
     BR_OMEGACS_CACHE = 2,    // omegacs.py:75-76   negative _cache after the update: recompute
     BR_SQL21_RESUM = 3,      // squaredl21.py:48-49 _cache < _norms[j]: re-sum the norms
+    BR_RELAX_STEPS = 4,      // relaxed runs: merged steps that had conflict rows ...
+    BR_RELAX_ROUNDS = 5,     // ... and the rounds their chains took (diagnostic, not a branch)
     BR_COUNT = 8
 };
 __device__ unsigned g_branch_count[BR_COUNT];

@@ -921,12 +921,21 @@ __global__ __launch_bounds__(kPrbThreads) void pcd_prb_kernel(
                         res = pcd_chain_lanes<M>(reg, lane, ncols - 1, valid, pl, gq, hq, lam, mu,
                                                  beta, gamma, eta, cache, sh_chain);
                         const double dn = valid ? (pl - res) : 0.0;
+                        // (a relative threshold instead of the bitwise test buys nothing: the
+                        // rounds end with the DEPTH of the dependencies -- 2^-36 and bitwise both
+                        // take 5.2 rounds on config 2, 2^-20 takes 4.2; tools/relax_probe.py)
                         const bool same = __double_as_longlong(dn) == __double_as_longlong(dl);
                         dl = dn;
                         sh_delta[lane] = dl;
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_wave_barrier();
-                        if (__ballot(!same) == 0ull) break;
+                        if (__ballot(!same) == 0ull) {
+                            if (lane == 0 && g == a.G - 1) {
+                                atomicAdd(&g_branch_count[BR_RELAX_STEPS], 1u);
+                                atomicAdd(&g_branch_count[BR_RELAX_ROUNDS], (unsigned)(round + 1));
+                            }
+                            break;
+                        }
                     }
                     if (g == 0 && valid) {
                         ps[jl] = res;

@@ -441,7 +441,7 @@ class HipEngine(object):
         buf = (C.c_uint32 * 8)()
         self._check(self._lib.spfm_debug_branch_counts(self._h, buf, int(bool(reset))))
         return dict(omegati_clip=buf[0], omegacs_dcache=buf[1], omegacs_cache=buf[2],
-                    squaredl21_resum=buf[3])
+                    squaredl21_resum=buf[3], relax_steps=buf[4], relax_rounds=buf[5])
 
     def debug_stream_probe(self):
         """One launch that reads the persistent pass's entry stream and nothing else; returns

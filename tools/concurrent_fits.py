@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""F independent fits of BASELINE config 2 on ONE GPU at the same time (a regularisation path:
-same matrix and schedule, different gamma): one engine handle, stream and host thread per fit; the
-persistent passes of the fits run side by side on disjoint CUs (64 workgroups each).  Prints one
-JSON line per F: wall time per iteration (cd_linear epoch + one pcd epoch over 30 components) of
-the slowest fit, aggregate epochs per second, and whether every fit equals its solo run bitwise.
+"""F independent fits of a BASELINE configuration (CONFIG=2|3|4, default 2) on ONE GPU at the same
+time (a regularisation path: same matrix and schedule, different gamma): one engine handle, stream
+and host thread per fit; the persistent passes of the fits run side by side on disjoint CUs.
+Prints one JSON line per F: wall time per iteration (the reference's iteration body) of every fit,
+aggregate iterations per second, and whether every fit equals its solo run bitwise.
 
-    python tools/concurrent_fits.py [F ...]      (default 1 2 3 4)
+    [CONFIG=3] [ITERS=3] [NO_CHECK=1] python tools/concurrent_fits.py [F ...]      (default 1 2 3 4)
+
+Diagnostics: WITH_TORCH=1 (a torch kernel on the null stream first), PRE=n PRE_SCHED=exact
+(handles created, run and closed beforehand), GPU_MAX_HW_QUEUES=4 (the runtime's own default).
 """
 import json
 import os
@@ -20,8 +23,13 @@ sys.path.insert(0, ROOT)
 from sparsepoly_amd.engine import HipEngine  # noqa: E402
 from sparsepoly_amd.synth import make_problem  # noqa: E402
 
-K, BETA, ALPHA = 30, 10.0, 1.0
-GAMMAS = [1e-4, 2e-4, 5e-5, 1e-3, 3e-4, 7e-5, 2e-3, 4e-4]
+CONFIG = int(os.environ.get("CONFIG", "2"))      # BASELINE configs[1..3], as in bench.py
+SOLVER, REG, DEGREE, K, BETA, G0 = {
+    2: ("pcd", "squaredl12", 2, 30, 10.0, 1e-4),
+    3: ("pcd", "omegati", 3, 16, 10.0, 1e-6),
+    4: ("pbcd", "omegacs", 2, 30, 1.0, 1e-3)}[CONFIG]
+ALPHA = 1.0
+GAMMAS = [G0 * f for f in (1.0, 2.0, 0.5, 10.0, 3.0, 0.7, 20.0, 4.0)]
 ITERS = int(os.environ.get("ITERS", "3"))
 
 
@@ -32,8 +40,8 @@ def make_engine(X, y, P0, F, sched="colored"):
         eng.set_option("co_tenants", F)
     eng.set_data(X, y)
     eng.set_params(P0, np.zeros(d), np.ones(K))
-    eng.configure("pcd", "squared", "squaredl12", 2)
-    eng.init_pred(2, True, False)
+    eng.configure(SOLVER, "squared", REG, DEGREE)
+    eng.init_pred(DEGREE, True, DEGREE == 3)
     eng.set_schedule(sched, np.arange(d, dtype=np.int32))
     return eng
 
@@ -45,7 +53,14 @@ def iterate(eng, gamma, iters, out, idx, barrier=None):
     t0 = time.perf_counter()
     v = []
     for _ in range(iters):
-        v.append(eng.cd_linear_epoch(ALPHA) + eng.pcd_epoch(0, 2, BETA, gamma, 1.0, ic))
+        a = eng.cd_linear_epoch(ALPHA)
+        for deg in list(range(2, DEGREE)) + [DEGREE]:   # the reference's iteration body
+            o = DEGREE - deg if deg != DEGREE else 0
+            if SOLVER == "pcd":
+                a += eng.pcd_epoch(o, deg, BETA, gamma, 1.0, ic)
+            else:
+                a += eng.pbcd_epoch(o, deg, BETA, gamma, 1.0)
+        v.append(a)
     out[idx] = (time.perf_counter() - t0, v)
 
 
@@ -61,7 +76,7 @@ def main():
     X, y = make_problem(1_000_000, 100_000, 50, 0)
     d = X.shape[1]
     nnz = X.nnz
-    P0 = 0.01 * np.random.RandomState(0).randn(1, K, d)
+    P0 = 0.01 * np.random.RandomState(0).randn(DEGREE - 1, K, d)
     solo = {}
     for _ in range(int(os.environ.get("PRE", "0"))):   # handles created and closed beforehand
         e = make_engine(X, y, P0, 1, os.environ.get("PRE_SCHED", "colored"))
@@ -112,10 +127,9 @@ def main():
         ms_iter = 1e3 * wall / ITERS
         agg = F * ITERS / wall
         print(json.dumps({
-            "fits": F, "iterations": ITERS, "ms_per_iteration_wall": round(ms_iter, 1),
+            "config": CONFIG, "fits": F, "iterations": ITERS, "ms_per_iteration_wall": round(ms_iter, 1),
             "ms_per_iteration_per_fit": [round(1e3 * o[0] / ITERS, 1) for o in out],
             "aggregate_epochs_per_s": round(agg, 3),
-            "aggregate_GBps_pcd": round(F * 30 * 28.0 * nnz / (wall / ITERS) / 1e9, 1),
             "equals_solo_bitwise": same, "persistent_fallbacks": fallbacks}), flush=True)
 
 

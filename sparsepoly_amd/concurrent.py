@@ -66,6 +66,11 @@ def fit_concurrently(estimators, X, y, max_concurrent=MAX_CONCURRENT):
             t.start()
         for t in threads:
             t.join()
+    for e in ests:
+        # a device session kept by warm_start was sized for a share of the CUs: the next solo fit
+        # starts a full-size one (fitted attributes stay)
+        if getattr(e, "_device_session", None) is not None:
+            e.release_device()
     if errors:
         raise errors[0]
     return ests

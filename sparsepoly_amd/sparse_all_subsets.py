@@ -140,6 +140,13 @@ class _BaseSparseAllSubsets(BaseSparsePoly, metaclass=ABCMeta):
             warnings.warn("Objective did not converge. Increase max_iter.")
         return self
 
+    def fit_path(self, X, y, max_concurrent=4, **grid):
+        """Clones of this estimator over a parameter grid (``gamma=[...]``, ...), fitted side by
+        side on the GPU (sparsepoly_amd/concurrent.py); each equals its solo ``fit``."""
+        from .concurrent import fit_path
+
+        return fit_path(self, X, y, max_concurrent=max_concurrent, **grid)
+
     def _get_output(self, X):
         """sparse_all_subsets.py:260-263 (poly_predict(..., 'all-subsets')), on the device."""
         engine = self._new_engine()

@@ -169,3 +169,22 @@ def test_errors_of_a_fit_reach_the_caller():
     with pytest.raises(ValueError):
         fit_concurrently([good], [X, X], [y, y])
     assert fit_concurrently([], X, y) == []
+
+
+def test_all_subsets_path_equals_solo_fits():
+    import warnings
+
+    from sklearn.base import clone
+
+    from sparsepoly_amd import SparseAllSubsetsRegressor
+
+    X, y = _problem(2500, 150, 6, seed=6)
+    base = SparseAllSubsetsRegressor(n_components=3, max_iter=3, tol=0, beta=1.0, random_state=0,
+                                     schedule="colored")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        path = base.fit_path(X, y, gamma=[1e-2, 1e-3, 1e-4])
+        for e in path:
+            s = clone(base).set_params(gamma=e.gamma).fit(X, y)
+            assert np.array_equal(s.P_, e.P_)
+            assert np.array_equal(s.predict(X), e.predict(X))

@@ -60,7 +60,9 @@ def fit_concurrently(estimators, X, y, max_concurrent=MAX_CONCURRENT):
                 return
 
     _engine._capi.load()  # once, before the threads race for it
-    with _engine.co_tenancy(n_threads):
+    # one data set for all: the first fit to reach the colouring computes it, the others install
+    # the result (same order, same steps -- what their own colouring would have produced)
+    with _engine.co_tenancy(n_threads, share_schedules=not per_fit_data):
         threads = [threading.Thread(target=work, name="spfm-fit-%d" % t) for t in range(n_threads)]
         for t in threads:
             t.start()

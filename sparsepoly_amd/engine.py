@@ -13,6 +13,7 @@ The methods map one-to-one onto the reference calls they replace
 =====================  =====================================================
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import scipy.sparse as sp
@@ -43,20 +44,52 @@ def canonical_csc(X):
 _CO_TENANTS = 1
 
 
+# ... and, when they all train on ONE data set, share the colouring: the first fit that asks for
+# a (mode, visiting order) computes the schedule, the others install its result
+_SHARED_SCHEDULES = None
+_SHARED_LOCK = threading.Lock()
+
+
 class co_tenancy(object):
-    def __init__(self, n):
+    def __init__(self, n, share_schedules=False):
         self.n = max(1, int(n))
+        self.share = bool(share_schedules)
 
     def __enter__(self):
-        global _CO_TENANTS
-        self._old = _CO_TENANTS
+        global _CO_TENANTS, _SHARED_SCHEDULES
+        self._old = (_CO_TENANTS, _SHARED_SCHEDULES)
         _CO_TENANTS = self.n
+        _SHARED_SCHEDULES = {} if self.share else None
         return self
 
     def __exit__(self, *exc):
-        global _CO_TENANTS
-        _CO_TENANTS = self._old
+        global _CO_TENANTS, _SHARED_SCHEDULES
+        _CO_TENANTS, _SHARED_SCHEDULES = self._old
         return False
+
+
+def shared_schedule(key, compute, install):
+    """Inside ``co_tenancy(..., share_schedules=True)``: ``compute()`` (-> order, Schedule) runs
+    in the first thread that asks for ``key``; every other thread waits for it and calls
+    ``install(schedule)`` (-> order).  Outside such a context: ``compute()[0]``."""
+    cache = _SHARED_SCHEDULES
+    if cache is None:
+        return compute()[0]
+    with _SHARED_LOCK:
+        entry = cache.get(key)
+        leader = entry is None
+        if leader:
+            entry = cache[key] = {"done": threading.Event(), "sched": None}
+    if leader:
+        try:
+            order, entry["sched"] = compute()
+        finally:
+            entry["done"].set()     # on an error the followers compute for themselves
+        return order
+    entry["done"].wait()
+    if entry["sched"] is None:
+        return compute()[0]
+    return install(entry["sched"])
 
 
 class HipEngine(object):

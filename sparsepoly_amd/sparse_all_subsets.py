@@ -161,7 +161,7 @@ class _BaseSparseAllSubsets(BaseSparsePoly, metaclass=ABCMeta):
         """sparse_all_subsets.py:265-269"""
         if not hasattr(self, "P_"):
             raise NotFittedError("Estimator not fitted.")
-        X = check_array(X, accept_sparse="csc", dtype=np.double)
+        X = check_array(X, accept_sparse=("csr", "csc"), dtype=np.double)  # row-major on the device
         return self._get_output(X)
 
 

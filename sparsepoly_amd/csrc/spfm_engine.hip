@@ -261,7 +261,7 @@ struct spfm_engine {
     // wide persistent passes (spfm_pcdw.hip.h): steps of up to 512 columns, degree-2 pcd and
     // cd_linear; chosen when the schedule has a step of more than 64 columns
     bool wide_on = true;
-    int pcdw_G = 256;
+    int pcdw_G = 0;  // workgroups of the wide pass; 0 = chosen from the rows (wide_groups)
     bool wide_ready = false;
     int wide_G = 0, wide_tot = 0;
     int wide_lr_active = 0;
@@ -1957,11 +1957,29 @@ struct spfm_engine {
                max_batch_cols > 64 && max_batch_cols <= 512 && nnz < ((int64_t)1 << 31) && n > 0;
     }
 
+    // Workgroups of the wide pass.  Its exchange (reduce-scatter to slot owners + all-gather)
+    // grows with the workgroup count, the entry loops shrink with it: one workgroup per CU for a
+    // big row block; half of them when the rows still fit LDS then (<= 2.2 M rows: the shard of
+    // a multi-GPU run -- 1.25 M rows of the 10M x 1M problem: 23.7 instead of 27.3 ms per
+    // component pass, tools/shard_rehearsal.py).  An explicit "pcdw_groups" wins; concurrent
+    // tenants keep to their share of the CUs.
+    int wide_groups(int ncu, size_t lds_max) const {
+        int g = pcdw_G;
+        if (g <= 0) {
+            const size_t half = (size_t)std::max(1, ncu / 2);
+            const size_t rows_per = ((size_t)n + half - 1) / half;
+            g = (kPcdwLdsFixed + rows_per * 8 + 16 <= lds_max) ? (int)half : ncu;
+        }
+        g = std::min(g, std::max(1, ncu / co_tenants));
+        return std::max(1, std::min(g, ncu));
+    }
+
     template <typename T>
     int ensure_wide() {
-        int ncu = 0;
+        int ncu = 0, lds_max = 0;
         HIPC(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
-        const int G = std::max(1, std::min(pcdw_G, ncu));
+        HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+        const int G = wide_groups(ncu, (size_t)lds_max);
         if (wide_ready && wide_G == G) return SPFM_OK;
         std::vector<int32_t> wbase, wsp, src;
         std::vector<uint8_t> hz;
@@ -3642,10 +3660,7 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
             h->pbprb_G = share;
             h->pb_stream_ready = false;
         }
-        if (h->pcdw_G > share) {
-            h->pcdw_G = share;
-            h->wide_ready = false;
-        }
+        h->wide_ready = false;  // the wide pass caps itself (wide_groups)
     } else if (k == "ingest_device") {  // CSR -> CSC on the device (default) or by host threads
         h->ingest_device = value != 0;
     } else if (k == "relax") {  // merged steps for schedules of tiny steps
@@ -3762,6 +3777,7 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "wide_active") *value = h->have_schedule && h->wide_usable();
     else if (k == "wide_lds_active") *value = h->wide_lr_active;
     else if (k == "pbprb_groups") *value = h->pbprb_G;
+    else if (k == "pcdw_groups") *value = h->wide_ready ? h->wide_G : h->pcdw_G;  // 0 = not chosen yet
     else if (k == "pbprb_owners") *value = h->pb_GO;
     else if (k == "pbprb_active") *value = h->pbprb_active;
     else if (k == "persistent_active")

@@ -584,6 +584,126 @@ __device__ __forceinline__ double pcd_chain_lanes(int reg, int lane, int last, b
     }
 }
 
+
+// The same chain for a WIDE step: up to 8 x 64 columns, one per thread of a 512-thread workgroup,
+// wave w holding columns 64 w .. 64 w + 63 (degree 2; pcdw_kernel).  pcd_chain_lanes called once
+// per 64 columns by one wave costs a full scan per call, six in a row for a step of 364 columns
+// while seven waves wait.  Here all waves scan their columns at once:
+//   1. every wave guesses its columns' branches at the step's input cache c0 (the cache moves by
+//      ~1e-7 per column), scans, and publishes its total map c -> A c + B;
+//   2. barrier; a wave's true input is the maps of the waves in front of it applied to c0 in
+//      order -- the expression the sequential rounds evaluate (cache = A * cache + B);
+//   3. the wave checks its branches against that input and re-scans until they agree; if any wave
+//      changed a branch (hence its map), the changed maps are published again and 2-3 repeat.
+// The inclusive scans depend on the branches only, so with the same (unique, sequentially
+// consistent) branches every value is the bit pattern the one-wave form produces.  All eight
+// waves must call (barriers inside).  sh_map: LDS [8][2] doubles, sh_bad: LDS 3 ints.
+template <int M>
+__device__ __forceinline__ double pcd_chain_waves(int reg, int lane, int wave, int ncols, bool valid,
+                                                  double p_old, double g, double h, double lam,
+                                                  double mu, double beta, double gamma, double eta,
+                                                  double (&cache)[M + 1], double* sh_map,
+                                                  int* sh_bad) {
+    static_assert(M == 2, "wide steps: degree 2");
+    double pin = 0.0, st = 0.0;
+    if (valid) {
+        double inv = h * mu;
+        inv += beta;
+        double upd = g * lam;
+        upd += beta * p_old;
+        const double rinv = recip_nr(inv);
+        upd *= rinv;
+        pin = p_old - eta * upd;
+        st = (eta * gamma) * rinv;
+    }
+    if (reg == REG_L1) {
+        const double sg = (pin > 0) ? 1.0 : ((pin < 0) ? -1.0 : 0.0);
+        const double m = fabs(pin) - st;
+        return sg * (m > 0.0 ? m : 0.0);
+    }
+    const bool sq = reg == REG_SQL12;
+    const int nw = (ncols + 63) >> 6;                   // waves that hold columns
+    const int last = min(64, ncols - 64 * wave) - 1;    // this wave's last column (< 0: none)
+    const bool act = valid && lane <= last;
+    const double ab = fabs(p_old);
+    // lane constants: the column's result is m = app - tt * u with u = c - ab (squaredl12.py:52-57,
+    // pre-scaled as in pcd_chain_lanes) or u = max(c - ab, 0) (omegati.py:82-99 at degree 2)
+    double app, tt, sg;
+    if (sq) {
+        const double rden = recip_nr(1 + 2 * st);
+        const double pp = pin * rden;
+        app = fabs(pp);
+        tt = (2 * st) * rden;
+        sg = (pp > 0) ? 1.0 : -1.0;
+    } else {
+        app = fabs(pin);
+        tt = st;
+        sg = (pin > 0) ? 1.0 : -1.0;
+    }
+    const int ci = sq ? 0 : 1;
+    const double c0 = cache[ci];
+    bool pos = sq ? true : ((c0 - ab) >= 0);
+    bool nz = (app - tt * (pos ? (c0 - ab) : 0.0)) > 0;
+    double al = 1.0, be = 0.0, m = 0.0;
+    auto scan = [&]() __attribute__((always_inline)) {
+        if (!act) {
+            al = 1.0;
+            be = 0.0;
+        } else if (!pos) {  // omegati clip: u = 0, r = p
+            al = 0.0;
+            be = app;
+        } else if (nz) {    // c' = (1 - tt)(c - a) + app
+            al = 1.0 - tt;
+            be = app - al * ab;
+        } else {            // c' = c - a
+            al = 1.0;
+            be = -ab;
+        }
+        affine_scan_inclusive(al, be, lane);
+    };
+    scan();
+    bool dirty = true;
+    for (int gr = 0; gr < 3 * kWave; ++gr) {
+        if (dirty && lane == 0) {
+            sh_map[wave * 2] = last >= 0 ? readlane_d(al, last >= 0 ? last : 0) : 1.0;
+            sh_map[wave * 2 + 1] = last >= 0 ? readlane_d(be, last >= 0 ? last : 0) : 0.0;
+        }
+        if (wave == 0 && lane == 0) {
+            if (gr == 0) sh_bad[0] = sh_bad[1] = sh_bad[2] = 0;
+            else sh_bad[(gr + 1) % 3] = 0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        double c_in = c0;
+        for (int w = 0; w < wave; ++w) c_in = sh_map[w * 2] * c_in + sh_map[w * 2 + 1];
+        bool changed = false;
+        for (int lr = 0; lr <= kWave; ++lr) {
+            const double cb = affine_before(al, be, c_in, lane);
+            const double v = cb - ab;
+            const bool pos2 = sq ? true : !(v < 0);
+            const double u = pos2 ? v : 0.0;
+            m = sq ? fma(-tt, u, app) : (app - tt * u);
+            const bool nz2 = m > 0;
+            const unsigned long long bad =
+                __ballot(act && ((pos2 != pos) || (pos2 && (nz2 != nz))));
+            pos = pos2;
+            nz = nz2;
+            if (bad == 0ull) break;
+            changed = true;
+            scan();
+        }
+        dirty = changed;
+        if (changed && lane == 0) sh_bad[gr % 3] = 1;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (sh_bad[gr % 3] == 0) break;
+    }
+    if (!sq && __ballot(act && !pos) != 0ull) count_branch(BR_OMEGATI_CLIP, lane);
+    double c_end = c0;
+    for (int w = 0; w < nw; ++w) c_end = sh_map[w * 2] * c_end + sh_map[w * 2 + 1];
+    cache[ci] = c_end;
+    const double r = sq ? ((act && nz) ? m : 0.0) : (act ? ((m > 0) ? m : 0.0) : 0.0);
+    return sg * r;
+}
+
 // Stand-alone chain for batches of more than 64 columns (and for the multi-kernel
 // path): one wavefront, 64 columns at a time; writes P[s,j], sum_viol
 // (pcd.py:119-121) and delta = p_old - p_new for the sync kernel.

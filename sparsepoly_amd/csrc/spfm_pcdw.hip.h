@@ -21,9 +21,11 @@ namespace spfm {
 //     32-granule vector ("vslot"); the vslot's OWNER workgroup sums the G partial vectors in
 //     fixed order (and, with several GPUs, adds the ranks' vectors through the peer-mapped
 //     slabs), publishes the totals; every workgroup collects the <= 32 total vectors
-//   * every workgroup's control wave runs the chain (pcd_chain_lanes, 64 columns per round,
-//     the regularizer cache carried through the rounds and steps); cd_linear has no chain --
-//     each thread forms its column's update itself
+//   * every workgroup runs the chain redundantly, its eight waves in parallel on 64 columns each
+//     (pcd_chain_waves: branch guess at the step's input cache, per-wave affine scan, the waves'
+//     total maps composed in order, re-checked until consistent; round 2 ran pcd_chain_lanes
+//     once per 64 columns on one wave); the regularizer cache is carried through the steps in
+//     every thread; cd_linear has no chain -- each thread forms its column's update itself
 //   * thread q scatter-updates its column's rows.
 // Rows (A[i], yhat_i, y_i) stay in global memory, owned by the workgroup (LR = 0), or -- float
 // storage, squared loss, block small enough -- live in LDS for the whole pass as (A[i],
@@ -154,7 +156,9 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
     double* sh_red = dyn_lds;                // [2][NG][L] owner part sums
     double* sh_tot = sh_red + 2 * NG * L;    // [512][2] totals of the step's columns
-    double* sh_delta = sh_tot + 1024;        // [512] p_old - p_new (pcd)
+    double* sh_delta = sh_tot + 1024;        // [512]: [0..16) the waves' chain maps, then 3 flags
+    double* sh_map = sh_delta;
+    int* sh_bad = reinterpret_cast<int*>(sh_delta + 16);
     double* sh_pold = sh_delta + 512;        // [512]
     int* sh_ok = reinterpret_cast<int*>(sh_pold + 512);
     T* lds_a = reinterpret_cast<T*>(sh_ok + 4);  // LR: [rows_per] A[i] (pcd)
@@ -472,28 +476,20 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
         if (!*sh_ok) break;
         PW_STAMP(6)  // barrier
 
-        // ---- phase 4: the update.  pcd: the control wave runs the chain over the step's
-        // columns, 64 per round (pcd.py:61-68 + the regularizer's cache recurrence), every
-        // workgroup redundantly; cd_linear: no chain (cd_linear.py:19-24)
+        // ---- phase 4: the update.  pcd: the chain over the step's columns (pcd.py:61-68 + the
+        // regularizer's cache recurrence), every workgroup redundantly; cd_linear: no chain
+        // (cd_linear.py:19-24)
         double delta = 0.0;
         if constexpr (KIND == 0) {
-            if (wave == 0) {
-                for (int base = 0; base < ncols; base += 64) {
-                    const int qq = base + wlane;
-                    const bool valid = qq < ncols;
-                    const int last = min(64, ncols - base) - 1;
-                    const double pl = valid ? sh_pold[qq] : 0.0;
-                    const double t0 = valid ? sh_tot[(size_t)qq * 2] : 0.0;
-                    const double t1 = valid ? sh_tot[(size_t)qq * 2 + 1] : 0.0;
-                    const double res = pcd_chain_lanes<2>(pp.reg, wlane, last, valid, pl, t0, t1,
-                                                          lam, pp.mu, pp.beta, pp.gamma, pp.eta,
-                                                          cache, nullptr);
-                    if (valid) sh_delta[qq] = pl - res;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (q < ncols) {
-                delta = sh_delta[q];
+            // all eight waves, 64 columns each, in parallel (pcd_chain_waves)
+            const bool valid = q < ncols;
+            const double t0 = valid ? sh_tot[(size_t)q * 2] : 0.0;
+            const double t1 = valid ? sh_tot[(size_t)q * 2 + 1] : 0.0;
+            const double res = pcd_chain_waves<2>(pp.reg, wlane, wave, ncols, valid, s0, t0, t1, lam,
+                                                  pp.mu, pp.beta, pp.gamma, pp.eta, cache, sh_map,
+                                                  sh_bad);
+            if (valid) {
+                delta = s0 - res;
                 if (g == 0) {
                     pp.P[(size_t)s_comp * pp.d + jmine] = s0 - delta;
                     pp.viol_pos[c0 + q] = fabs(delta);

@@ -15,6 +15,7 @@ import warnings
 from abc import ABCMeta, abstractmethod
 
 import numpy as np
+import scipy.sparse as sp
 from sklearn.utils import check_random_state
 from sklearn.utils.validation import NotFittedError, check_array
 
@@ -98,7 +99,9 @@ class _BaseSparseAllSubsets(BaseSparsePoly, metaclass=ABCMeta):
         self.P_ = np.ascontiguousarray(self.P_, dtype=np.double)
         engine = self._new_engine()
         try:
-            engine.set_data(canonical_csc(X), y)
+            # canonical CSR goes to the library as it is (transposed on the device)
+            csr_direct = sp.isspmatrix_csr(X) and X.has_canonical_format
+            engine.set_data(X if csr_direct else canonical_csc(X), y)
             engine.set_params(self.P_[None], np.zeros(n_features), self.lams_)
             engine.configure(self.solver, self.loss, self.regularizer, -1)
             engine.init_pred(-1, False, False)  # y_pred = self._get_output(X) (:241)

@@ -156,3 +156,57 @@ def test_wide_pass_many_entries_per_thread_rows_in_global_memory(oracle, precisi
         np.testing.assert_allclose(r["w"], fm.w_, rtol=0, atol=1e-4)
         scale = max(1.0, float(np.abs(fm.y_pred_).max()))
         np.testing.assert_allclose(r["y_pred"], fm.y_pred_, rtol=0, atol=2e-4 * scale)
+
+
+@pytest.mark.parametrize("pos_a,pos_b", [(10, 150), (3, 40), (70, 71), (127, 128)])
+def test_forced_omegati_clip_inside_a_wide_step(oracle, pos_a, pos_b):
+    """omegati.py:97-98 (the clip of _dcache at 0) FORCED inside one wide step whose columns are
+    spread over several waves of the chain (pcd_chain_waves): the construction of
+    tests/test_hip_branches.py -- two empty columns a, b whose magnitudes make the running cache
+    minus |p_b| negative at column b -- placed at chosen positions of a step of 200 pairwise
+    row-disjoint columns (a and b in different 64-column chunks, in one chunk, or adjacent across
+    a chunk boundary).  The device's clip counter must tick and the result must equal the
+    oracle's."""
+    from sparsepoly_amd.engine import HipEngine
+
+    ta, tb = 6206275.0, 0.0013605052372440696
+    na, nb = 5 * ta, 5 * tb
+    assert (na + nb) - na < nb
+    d = 200
+    rng = np.random.RandomState(5)
+    data_cols = [j for j in range(d) if j not in (pos_a, pos_b)]
+    n = len(data_cols)
+    X = sp.csc_matrix((rng.randn(n), (np.arange(n), np.array(data_cols))), shape=(n, d))
+    y = rng.randn(n)
+    P0 = np.zeros((1, 1, d))
+    P0[0, 0, pos_a], P0[0, 0, pos_b] = na, -nb
+    eng = HipEngine(0, "f64")
+    eng.set_option("wide_min_cols", 0)
+    eng.set_data(X, y)
+    eng.set_params(P0, np.zeros(d), np.ones(1))
+    eng.configure("pcd", "squared", "omegati", 2)
+    eng.init_pred(2, False, False)
+    y0 = eng.get_y_pred()
+    eng.set_schedule("colored", np.arange(d, dtype=np.int32))
+    sched = eng.get_schedule()
+    assert eng.get_option("wide_active") == 1 and eng.n_batches == 1
+    assert np.array_equal(sched.order, np.arange(d))       # one step, the natural order
+    eng.debug_branch_counts(reset=True)
+    v = eng.pcd_epoch(0, 2, 1.0, 0.05, 1.0, np.arange(1, dtype=np.int32))
+    counts = eng.debug_branch_counts(reset=True)
+    P, _ = eng.get_params()
+    yp = eng.get_y_pred()
+    eng.close()
+    assert counts["omegati_clip"] > 0
+    ds = oracle.CSC(X)
+    regc = oracle.Regularizer("omegati")
+    regc.init_cache_pcd(2, d, 1)
+    Po = np.ascontiguousarray(P0[0].copy())
+    ypo = np.ascontiguousarray(y0.copy())
+    A = np.zeros((n, 3))
+    vo = oracle.pcd_epoch(Po, ds, y, ypo, np.ones(1), 2, 1.0, 0.05, 1.0, regc, "squared", A,
+                          np.arange(1, dtype=np.int32), np.arange(d, dtype=np.int32))
+    np.testing.assert_allclose(v, vo, rtol=1e-12)
+    np.testing.assert_allclose(P[0], Po, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(yp, ypo, rtol=0, atol=1e-12)
+    assert P[0, 0, pos_a] == 0.0 and P[0, 0, pos_b] == 0.0

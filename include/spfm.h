@@ -277,7 +277,7 @@ int spfm_set_use_graph(spfm_handle h, int on);
  * a snapshot -- spfm_get_option("psgd_redone") counts those).  Round 2: "pbcd_persistent"
  * (0/1: the persistent pbcd pass), "pbprb_groups" (its workgroups, default 256), "wide" (0/1:
  * the wide passes for degree-2 pcd / cd_linear, steps of up to 512 columns), "pcdw_groups"
- * (their workgroups; default 0 = one per CU, half as many when the rows then still fit LDS),
+ * (their workgroups; default 0 = about 160 entries per workgroup and step, at most one per CU),
  * "wide_min_cols" (mean colour-class width below which the schedule is coloured again with 64 columns per class and the 64-column passes run, default
  * 110; 0 = always wide), "peer_exchange" (only 0 can be set: give the in-kernel cross-GPU
  * exchange up after spfm_peer_connect and use the per-step collective), diagnostics

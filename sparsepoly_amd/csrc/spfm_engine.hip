@@ -1958,17 +1958,24 @@ struct spfm_engine {
     }
 
     // Workgroups of the wide pass.  Its exchange (reduce-scatter to slot owners + all-gather)
-    // grows with the workgroup count, the entry loops shrink with it: one workgroup per CU for a
-    // big row block; half of them when the rows still fit LDS then (<= 2.2 M rows: the shard of
-    // a multi-GPU run -- 1.25 M rows of the 10M x 1M problem: 23.7 instead of 27.3 ms per
-    // component pass, tools/shard_rehearsal.py).  An explicit "pcdw_groups" wins; concurrent
-    // tenants keep to their share of the CUs.
+    // grows with the workgroup count, the entry loops shrink with it; measured optimum: about 160
+    // entries per workgroup and step (the shard of a multi-GPU run -- 1.25 M rows of the
+    // 10M x 1M problem, 22.7 k entries per step: 23.9 ms per component pass at 128 workgroups,
+    // 27.3 at 256; 2M x 200k, 36.5 k entries per step: 7.5 us per step at 256, 8.7 at 128).  More
+    // workgroups than that when the rows fit LDS only then.  An explicit "pcdw_groups" wins;
+    // concurrent tenants keep to their share of the CUs.
     int wide_groups(int ncu, size_t lds_max) const {
         int g = pcdw_G;
         if (g <= 0) {
-            const size_t half = (size_t)std::max(1, ncu / 2);
-            const size_t rows_per = ((size_t)n + half - 1) / half;
-            g = (kPcdwLdsFixed + rows_per * 8 + 16 <= lds_max) ? (int)half : ncu;
+            const int64_t steps = std::max<int64_t>(1, (int64_t)batch_ptr.size() - 1);
+            const int64_t per_step = nnz / steps;
+            g = (int)std::min<int64_t>(ncu, std::max<int64_t>(64, ((per_step / 160 + 15) / 16) * 16));
+            auto fits = [&](int gg) {
+                const size_t rows_per = ((size_t)n + (size_t)gg - 1) / (size_t)gg;
+                return kPcdwLdsFixed + rows_per * 8 + 16 <= lds_max;
+            };
+            if (!fits(g) && fits(ncu))
+                while (g < ncu && !fits(g)) g = std::min(ncu, g + 16);
         }
         g = std::min(g, std::max(1, ncu / co_tenants));
         return std::max(1, std::min(g, ncu));

@@ -663,6 +663,12 @@ __device__ __forceinline__ double pcd_chain_waves(int reg, int lane, int wave, i
     };
     scan();
     bool dirty = true;
+    double mA[8], mB[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        mA[w] = 1.0;
+        mB[w] = 0.0;
+    }
     for (int gr = 0; gr < 3 * kWave; ++gr) {
         if (dirty && lane == 0) {
             sh_map[wave * 2] = last >= 0 ? readlane_d(al, last >= 0 ? last : 0) : 1.0;
@@ -673,8 +679,17 @@ __device__ __forceinline__ double pcd_chain_waves(int reg, int lane, int wave, i
             else sh_bad[(gr + 1) % 3] = 0;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // all eight maps in flight at once (a dependent LDS round trip per wave in front would
+        // cost more than the scan); maps of waves without columns are never applied
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            mA[w] = sh_map[w * 2];
+            mB[w] = sh_map[w * 2 + 1];
+        }
         double c_in = c0;
-        for (int w = 0; w < wave; ++w) c_in = sh_map[w * 2] * c_in + sh_map[w * 2 + 1];
+#pragma unroll
+        for (int w = 0; w < 7; ++w)
+            if (w < wave) c_in = mA[w] * c_in + mB[w];
         bool changed = false;
         for (int lr = 0; lr <= kWave; ++lr) {
             const double cb = affine_before(al, be, c_in, lane);
@@ -697,8 +712,10 @@ __device__ __forceinline__ double pcd_chain_waves(int reg, int lane, int wave, i
         if (sh_bad[gr % 3] == 0) break;
     }
     if (!sq && __ballot(act && !pos) != 0ull) count_branch(BR_OMEGATI_CLIP, lane);
-    double c_end = c0;
-    for (int w = 0; w < nw; ++w) c_end = sh_map[w * 2] * c_end + sh_map[w * 2 + 1];
+    double c_end = c0;  // the maps read in the last round are the final ones (nobody changed)
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+        if (w < nw) c_end = mA[w] * c_end + mB[w];
     cache[ci] = c_end;
     const double r = sq ? ((act && nz) ? m : 0.0) : (act ? ((m > 0) ? m : 0.0) : 0.0);
     return sg * r;

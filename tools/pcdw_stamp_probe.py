@@ -35,7 +35,7 @@ for stamps in (0, 1):
                  "prefetch issue", "collect poll", "barrier", "chain rounds", "scatter",
                  "rotate+end barrier"]
         print("   cycles/step:           WG0      min     mean      max")
-        for k in range(10):
+        for k in range(len(names)):
             print("   %-20s %8.0f %8.0f %8.0f %8.0f" % (names[k], st[0, k] / nb, st[:, k].min() / nb,
                                                       st[:, k].mean() / nb, st[:, k].max() / nb))
         print("   total WG0 %.0f" % (st[0, :10].sum() / nb))

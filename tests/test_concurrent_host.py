@@ -51,3 +51,75 @@ def test_hardware_queue_default_is_set_before_the_runtime_starts():
     import sparsepoly_amd._capi  # noqa: F401
 
     assert int(os.environ["GPU_MAX_HW_QUEUES"]) >= 4
+
+
+def test_shared_schedule_is_computed_once_and_installed_by_the_others():
+    import threading
+
+    from sparsepoly_amd import engine as E
+
+    calls = {"compute": 0, "install": 0}
+    lock = threading.Lock()
+
+    def compute():
+        with lock:
+            calls["compute"] += 1
+        return "order", "schedule"
+
+    def install(s):
+        assert s == "schedule"
+        with lock:
+            calls["install"] += 1
+        return "order"
+
+    # outside a sharing context: everybody computes
+    assert E.shared_schedule(("k",), compute, install) == "order"
+    assert calls == {"compute": 1, "install": 0}
+    out = []
+    with E.co_tenancy(4, share_schedules=True):
+        th = [threading.Thread(target=lambda: out.append(E.shared_schedule(("k",), compute, install)))
+              for _ in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert E.shared_schedule(("other",), compute, install) == "order"   # another key: computed
+    assert out == ["order"] * 4
+    assert calls == {"compute": 3, "install": 3}
+    assert E._SHARED_SCHEDULES is None
+
+
+def test_shared_schedule_leader_failure_lets_the_followers_compute():
+    import threading
+
+    from sparsepoly_amd import engine as E
+
+    state = {"n": 0}
+    gate = threading.Event()
+
+    def compute():
+        state["n"] += 1
+        if state["n"] == 1:
+            gate.wait(1.0)
+            raise RuntimeError("leader fails")
+        return "order", "schedule"
+
+    res = []
+
+    def run():
+        try:
+            res.append(E.shared_schedule(("k",), compute, lambda s: "installed"))
+        except RuntimeError:
+            res.append("error")
+
+    with E.co_tenancy(2, share_schedules=True):
+        a = threading.Thread(target=run)
+        a.start()
+        import time
+        time.sleep(0.1)
+        b = threading.Thread(target=run)
+        b.start()
+        gate.set()
+        a.join()
+        b.join()
+    assert sorted(res) == ["error", "order"]

@@ -185,12 +185,15 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         if isinstance(self.schedule, Schedule):
             order = engine.install_schedule(self.schedule, conflict_csc)
             self.schedule_ = self.schedule
-        elif conflict_csc is None:
-            # concurrent fits on one data set (sparsepoly_amd/concurrent.py) colour it once
+        elif conflict_csc is None and self.schedule == "colored" and \
+                getattr(self, "_struct_key", None) is not None:
+            # a colouring is a function of the matrix structure and the visiting order (and of
+            # what decides the step width): concurrent fits on one data set
+            # (sparsepoly_amd/concurrent.py) compute it once, and so do later fits of this process
             mode = self.schedule
             jf = np.ascontiguousarray(indices_feature, dtype=np.int32)
-            key = (mode, engine.n, engine.d, hash(jf.tobytes()), self.solver, self.loss,
-                   self.precision, self.degree)
+            key = (self._struct_key, mode, hash(jf.tobytes()), self.solver, self.loss,
+                   self.precision, self.degree, self.fit_lower, self.fit_linear)
 
             def compute():
                 o = engine.set_schedule(mode, jf, None)
@@ -416,6 +419,9 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         # else -- and the paths that need the CSC on the host -- through scipy
         csr_direct = sp.isspmatrix_csr(X) and X.has_canonical_format and not self.distributed
         Xc = None if csr_direct else canonical_csc(X)
+        self._struct_key = None
+        if self.schedule == "colored" and not self.distributed and not self.shuffle:
+            self._struct_key = _engine_mod.structure_key(X if csr_direct else Xc)
         conflict_csc = None
         # warm_start keeps the device session: same data => no re-upload,
         # no re-colouring, no new row-block stream

@@ -188,3 +188,37 @@ def test_all_subsets_path_equals_solo_fits():
             s = clone(base).set_params(gamma=e.gamma).fit(X, y)
             assert np.array_equal(s.P_, e.P_)
             assert np.array_equal(s.predict(X), e.predict(X))
+
+
+def test_a_second_fit_on_the_same_matrix_reuses_the_colouring():
+    """The process-wide memory of coloured schedules (engine.shared_schedule): same structure,
+    same visiting order -> installed instead of computed; another matrix, another order or
+    shuffle=True -> computed.  The fits equal those of a process that never remembered anything."""
+    import warnings
+
+    from sparsepoly_amd import SparseFactorizationMachineRegressor
+    from sparsepoly_amd import engine as E
+
+    X, y = _problem(3000, 250, 8, seed=9)
+    kw = dict(n_components=3, max_iter=3, tol=0, beta=1.0, random_state=0, schedule="colored")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        E._SCHEDULE_LRU.clear()
+        E._SCHEDULE_STATS.update(hits=0, misses=0)
+        a = SparseFactorizationMachineRegressor(gamma=1e-3, **kw).fit(X, y)
+        assert E._SCHEDULE_STATS == {"hits": 0, "misses": 1}
+        b = SparseFactorizationMachineRegressor(gamma=1e-4, **kw).fit(X, y)        # same matrix
+        assert E._SCHEDULE_STATS == {"hits": 1, "misses": 1}
+        Xv = X.copy()
+        Xv.data = Xv.data * 2.0                                    # same structure, other values
+        SparseFactorizationMachineRegressor(gamma=1e-4, **kw).fit(Xv, y)
+        assert E._SCHEDULE_STATS == {"hits": 2, "misses": 1}
+        SparseFactorizationMachineRegressor(gamma=1e-4, **kw).fit(X[:2000], y[:2000])  # another one
+        assert E._SCHEDULE_STATS == {"hits": 2, "misses": 2}
+        SparseFactorizationMachineRegressor(gamma=1e-4, shuffle=True, **kw).fit(X, y)
+        assert E._SCHEDULE_STATS == {"hits": 2, "misses": 2}       # shuffled orders are not kept
+        E._SCHEDULE_LRU.clear()
+        b2 = SparseFactorizationMachineRegressor(gamma=1e-4, **kw).fit(X, y)       # computed afresh
+    assert np.array_equal(b.P_, b2.P_) and np.array_equal(b.w_, b2.w_)
+    assert np.array_equal(a.feature_order_, b.feature_order_)
+    assert b.n_steps_per_sweep_ == b2.n_steps_per_sweep_

@@ -31,6 +31,10 @@ for sched in ("colored", "exact"):
     est.predict(X)
     out["predict_%s_s" % sched] = round(time.perf_counter() - t0, 2)
     est.release_device()
+# a second estimator on the same matrix (no warm start): the colouring is remembered
+t0 = time.perf_counter()
+SparseFactorizationMachineRegressor(schedule="colored", **dict(kw, gamma=3e-4)).fit(X, y)
+out["fit_colored_second_estimator_s"] = round(time.perf_counter() - t0, 2)
 base = SparseFactorizationMachineRegressor(schedule="colored", **kw)
 t0 = time.perf_counter()
 base.fit_path(X, y, gamma=[1e-3, 3e-4, 1e-4, 3e-5])

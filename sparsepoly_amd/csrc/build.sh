@@ -13,9 +13,12 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-u
 p1=$!
 "$HIPCC" $FLAGS -c "$HERE/spfm_ingest.hip" -o "$OUT/spfm_ingest.o" &
 p2=$!
+"$HIPCC" $FLAGS -c "$HERE/spfm_colour.hip" -o "$OUT/spfm_colour.o" &
+p3=$!
 wait $p1
 wait $p2
+wait $p3
 g++ -O2 -std=c++17 -fPIC -Wall -pthread -c "$HERE/spfm_schedule.cpp" -o "$OUT/spfm_schedule.o"
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libspfm_hip.so" "$OUT/spfm_engine.o" "$OUT/spfm_ingest.o" "$OUT/spfm_schedule.o" -ldl -lpthread
-rm -f "$OUT/spfm_engine.o" "$OUT/spfm_ingest.o" "$OUT/spfm_schedule.o"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libspfm_hip.so" "$OUT/spfm_engine.o" "$OUT/spfm_ingest.o" "$OUT/spfm_colour.o" "$OUT/spfm_schedule.o" -ldl -lpthread
+rm -f "$OUT/spfm_engine.o" "$OUT/spfm_ingest.o" "$OUT/spfm_colour.o" "$OUT/spfm_schedule.o"
 echo "built $OUT/libspfm_hip.so (engine tag $TAG)"

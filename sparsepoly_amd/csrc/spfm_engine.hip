@@ -54,6 +54,9 @@ extern template hipError_t device_csr_to_csc<float>(int64_t, int32_t, int64_t, c
 extern template hipError_t device_csr_to_csc<double>(int64_t, int32_t, int64_t, const int64_t*,
                                                      const int32_t*, const double*, int64_t*,
                                                      int32_t*, double*, int*, hipStream_t);
+// spfm_colour.hip: the first-fit colouring on the device (same result as schedule_colored)
+hipError_t device_first_fit(int64_t, int32_t, int64_t, const int64_t*, const int32_t*, const int64_t*,
+                            const int32_t*, int, int32_t*, int*, int*, hipStream_t);
 }  // namespace spfm
 
 using namespace spfm;
@@ -901,6 +904,40 @@ struct spfm_engine {
     }
 
     // =============================================================== schedule
+    // First-fit colouring of the conflict graph in the visiting order `jf` into order / batch_ptr:
+    // on the device when the conflict structure is the handle's own matrix (spfm_colour.hip; the
+    // same classes as the host form, tests/test_hip_colour.py), else -- global structure of a
+    // sharded run, small problems, more than 4096 colours -- by the host threads.
+    bool colour_device = true;
+    int colour_device_used = 0;
+    int colour_columns(int64_t rows, const int64_t* cp, const int32_t* ci, bool own,
+                       const int32_t* jf, int max_batch) {
+        colour_device_used = 0;
+        if (own && colour_device && d >= 4096 && nnz >= (1 << 20) && nnz < ((int64_t)1 << 31) &&
+            (int64_t)d / std::max(1, max_batch) < 3500 && rptr.p && cptr.p) {
+            std::vector<int32_t> col((size_t)d);
+            int nc = 0, ovf = 0;
+            const hipError_t e = device_first_fit(n, d, nnz, cptr.as<int64_t>(), cidx.as<int32_t>(),
+                                                  rptr.as<int64_t>(), jf, max_batch, col.data(), &nc,
+                                                  &ovf, stream);
+            if (e == hipSuccess && !ovf && nc > 0) {
+                // classes in colour order, their columns in visiting order (stable counting sort)
+                std::vector<int32_t> bp((size_t)nc + 1, 0);
+                for (int q = 0; q < d; ++q) bp[(size_t)col[(size_t)q] + 1]++;
+                for (int c = 0; c < nc; ++c) bp[(size_t)c + 1] += bp[(size_t)c];
+                std::vector<int32_t> pos(bp.begin(), bp.end() - 1);
+                order.assign((size_t)d, 0);
+                for (int q = 0; q < d; ++q) order[(size_t)pos[(size_t)col[(size_t)q]]++] = jf[q];
+                batch_ptr = std::move(bp);
+                colour_device_used = 1;
+                return SPFM_OK;
+            }
+            (void)hipGetLastError();
+        }
+        schedule_colored(rows, d, cp, ci, jf, max_batch, order, batch_ptr);
+        return SPFM_OK;
+    }
+
     int set_schedule(int mode, const int32_t* indices_feature, const int64_t* cf_indptr,
                      const int32_t* cf_indices, int64_t cf_rows, int32_t* order_out,
                      int32_t* n_batches_out) {
@@ -927,7 +964,7 @@ struct spfm_engine {
             order.assign(indices_feature, indices_feature + d);
             schedule_exact(rows, d, cp, ci, indices_feature, max_batch, batch_ptr);
         } else if (mode == SPFM_SCHED_COLORED) {
-            schedule_colored(rows, d, cp, ci, indices_feature, max_batch, order, batch_ptr);
+            colour_columns(rows, cp, ci, !cf_indptr, indices_feature, max_batch);
             if (pers && max_batch > 64 && batch_ptr.size() > 1) {
                 // A wide step costs about twice a 64-column step (two fabric hops, 7.0 vs 3.2 us
                 // on one GPU): classes of moderate width are cheaper as more, narrower steps.
@@ -961,7 +998,7 @@ struct spfm_engine {
                 const bool rows_fit = dtype == SPFM_F32 && prb_lds && lds_lr <= (size_t)lds_max;
                 const double limit = rows_fit ? (double)wide_min_cols : 0.72 * (double)wide_min_cols;
                 if (widest > 64 && mean_cols < limit)
-                    schedule_colored(rows, d, cp, ci, indices_feature, 64, order, batch_ptr);
+                    colour_columns(rows, cp, ci, !cf_indptr, indices_feature, 64);
             }
         } else {
             FAIL(SPFM_ERR_INVALID, "set_schedule: unknown mode");
@@ -3668,6 +3705,8 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
             h->pb_stream_ready = false;
         }
         h->wide_ready = false;  // the wide pass caps itself (wide_groups)
+    } else if (k == "colour_device") {  // first-fit colouring on the device (default) or by host threads
+        h->colour_device = value != 0;
     } else if (k == "ingest_device") {  // CSR -> CSC on the device (default) or by host threads
         h->ingest_device = value != 0;
     } else if (k == "relax") {  // merged steps for schedules of tiny steps
@@ -3791,6 +3830,8 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
         *value = h->have_schedule && (h->prb_usable() || h->wide_usable());
     else if (k == "relax") *value = h->relax_on;
     else if (k == "ingest_device") *value = h->ingest_device;
+    else if (k == "colour_device") *value = h->colour_device;
+    else if (k == "colour_device_used") *value = h->colour_device_used;
     else if (k == "co_tenants") *value = h->co_tenants;
     else if (k == "ingest_device_used") *value = h->ingest_device_used;
     else if (k == "prb_pack_active") *value = h->prb_pack_active;

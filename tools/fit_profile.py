@@ -16,7 +16,11 @@ for dev in (0, 1, 1):   # host-thread transposition, then the device one (cold, 
 for e in engs[:-1]: e.close()
 d = X.shape[1]
 t0 = time.time(); eng.set_params(0.01*np.random.RandomState(0).randn(1,30,d), np.zeros(d), np.ones(30)); eng.configure("pcd","squared","squaredl12",2); eng.init_pred(2, True, False); tick("params+configure+init_pred", t0)
-t0 = time.time(); eng.set_schedule("colored", np.arange(d, dtype=np.int32)); tick("set_schedule (colouring)", t0)
+for dev in (0, 1, 1):   # the colouring by host threads, then on the device (cold, warm)
+    eng.set_option("colour_device", dev)
+    t0 = time.time(); eng.set_schedule("colored", np.arange(d, dtype=np.int32)); tick("set_schedule (colouring, colour_device=%d)" % dev, t0)
+    assert eng.get_option("colour_device_used") == dev
+    print("    steps per sweep:", eng.n_batches)
 ic = np.arange(30, dtype=np.int32)
 t0 = time.time(); eng.cd_linear_epoch(1.0); tick("first cd_linear (stream build)", t0)
 t0 = time.time(); eng.pcd_epoch(0, 2, 10.0, 1e-4, 1.0, ic); tick("first pcd epoch", t0)

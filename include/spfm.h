@@ -296,7 +296,10 @@ int spfm_set_option(spfm_handle h, const char* key, int value);
  * in-kernel wait before a persistent pass gives up, default 2^21) and "debug_drop_group" (the next
  * N persistent launches lack their last workgroup, i.e. time out), "ingest_device" (0/1, default 1:
  * spfm_set_data_csr transposes on the device -- one stable radix sort of the entries by column id;
- * 0, or no room for the sort's scratch: host threads), "co_tenants" (1..64, default 1: the number
+ * 0, or no room for the sort's scratch: host threads), "colour_device" (0/1, default 1: the
+ * first-fit colouring of spfm_set_schedule(SPFM_SCHED_COLORED) runs on the device when the
+ * conflict structure is the handle's own matrix -- the same order and batch boundaries as the
+ * host form; "colour_device_used" tells), "co_tenants" (1..64, default 1: the number
  * of handles of this process whose persistent passes run at the same time on this device --
  * independent fits, one handle and one host thread each; the handle then sizes its passes to
  * 1/co_tenants of the CUs and its residency check to the shared device.  Set it before the

@@ -54,6 +54,10 @@ extern template hipError_t device_csr_to_csc<float>(int64_t, int32_t, int64_t, c
 extern template hipError_t device_csr_to_csc<double>(int64_t, int32_t, int64_t, const int64_t*,
                                                      const int32_t*, const double*, int64_t*,
                                                      int32_t*, double*, int*, hipStream_t);
+// spfm_ingest.hip: the row-block entry stream on the device (same result as build_rowblock_stream)
+hipError_t device_rowblock_stream(int64_t, int32_t, int64_t, int, int, int, const int32_t*,
+                                  const int32_t*, const int64_t*, const int32_t*, int32_t*, int32_t*,
+                                  uint32_t*, int*, hipStream_t);
 // spfm_colour.hip: the first-fit colouring on the device (same result as schedule_colored)
 hipError_t device_first_fit(int64_t, int32_t, int64_t, const int64_t*, const int32_t*, const int64_t*,
                             const int32_t*, int, int32_t*, int*, int*, hipStream_t);
@@ -910,6 +914,8 @@ struct spfm_engine {
     // sharded run, small problems, more than 4096 colours -- by the host threads.
     bool colour_device = true;
     int colour_device_used = 0;
+    bool stream_device = true;   // the 64-column pass's entry stream built on the device
+    int stream_device_used = 0;
     int colour_columns(int64_t rows, const int64_t* cp, const int32_t* ci, bool own,
                        const int32_t* jf, int max_batch) {
         colour_device_used = 0;
@@ -1588,18 +1594,39 @@ struct spfm_engine {
         HIPC(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
         if (prb_G > ncu) prb_G = ncu;
         if (prb_G < 1) prb_G = 1;
-        std::vector<int32_t> sp, src;
-        std::vector<uint32_t> lmask;
-        build_rowblock_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, prb_G, prb_long,
-                              sp, src, lmask, nullptr);
-        prb_has_long = 0;
-        for (uint32_t m : lmask) prb_has_long |= (m != 0u);
-        HIPC(prb_lmask.alloc(sizeof(uint32_t) * lmask.size()));
-        HIPC(hipMemcpyAsync(prb_lmask.p, lmask.data(), sizeof(uint32_t) * lmask.size(),
-                            hipMemcpyHostToDevice, stream));
+        // the entry stream: on the device (spfm_ingest.hip device_rowblock_stream: two binary
+        // searches per (column, row block), a scan, a fill -- the host builder's sp / src / lmask
+        // exactly, tests/test_hip_stream.py), or by the host threads (stream_device=0, no room)
+        const int nb_ = n_batches();
+        const size_t nsp = (size_t)prb_G * nb_ * 65 + 1;
         DevBuf d_src;
         HIPC(d_src.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
-        HIPC(prb_sp.alloc(sizeof(int32_t) * sp.size()));
+        HIPC(prb_sp.alloc(sizeof(int32_t) * nsp));
+        HIPC(prb_lmask.alloc(sizeof(uint32_t) * (size_t)prb_G * nb_ * 2));
+        stream_device_used = 0;
+        if (stream_device && nnz >= (1 << 20)) {
+            int hl = 0;
+            const hipError_t e = device_rowblock_stream(
+                n, d, nnz, prb_G, nb_, prb_long, d_order.as<int32_t>(), d_bptr.as<int32_t>(),
+                cptr.as<int64_t>(), cidx.as<int32_t>(), prb_sp.as<int32_t>(), d_src.as<int32_t>(),
+                prb_lmask.as<uint32_t>(), &hl, stream);
+            if (e == hipSuccess) {
+                prb_has_long = hl;
+                stream_device_used = 1;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        std::vector<int32_t> sp, src;
+        std::vector<uint32_t> lmask;
+        if (!stream_device_used) {
+            build_rowblock_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, prb_G,
+                                  prb_long, sp, src, lmask, nullptr);
+            prb_has_long = 0;
+            for (uint32_t m : lmask) prb_has_long |= (m != 0u);
+            HIPC(hipMemcpyAsync(prb_lmask.p, lmask.data(), sizeof(uint32_t) * lmask.size(),
+                                hipMemcpyHostToDevice, stream));
+        }
         HIPC(prb_erow.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
         HIPC(prb_eval.alloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1)));
         HIPC(prb_slab.alloc(sizeof(double) * 2 * ((size_t)prb_G + 1) * 64 * 2));
@@ -1611,11 +1638,13 @@ struct spfm_engine {
         HIPC(hipMemsetAsync(prb_stamps.p, 0, prb_stamps.bytes, stream));
         HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
         HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));
-        HIPC(hipMemcpyAsync(prb_sp.p, sp.data(), sizeof(int32_t) * sp.size(),
-                            hipMemcpyHostToDevice, stream));
-        if (nnz > 0) {
-            HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * (size_t)nnz,
+        if (!stream_device_used)
+            HIPC(hipMemcpyAsync(prb_sp.p, sp.data(), sizeof(int32_t) * sp.size(),
                                 hipMemcpyHostToDevice, stream));
+        if (nnz > 0) {
+            if (!stream_device_used)
+                HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * (size_t)nnz,
+                                    hipMemcpyHostToDevice, stream));
             hipLaunchKernelGGL((prb_gather_kernel<T>), dim3(cdiv(nnz, 256)), dim3(256), 0, stream,
                                nnz, d_src.as<int32_t>(), cidx.as<int32_t>(), cval.as<T>(),
                                prb_erow.as<int32_t>(), prb_eval.as<T>());
@@ -3705,6 +3734,9 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
             h->pb_stream_ready = false;
         }
         h->wide_ready = false;  // the wide pass caps itself (wide_groups)
+    } else if (k == "stream_device") {  // entry stream of the 64-column passes: device or host threads
+        h->stream_device = value != 0;
+        h->prb_ready = false;
     } else if (k == "colour_device") {  // first-fit colouring on the device (default) or by host threads
         h->colour_device = value != 0;
     } else if (k == "ingest_device") {  // CSR -> CSC on the device (default) or by host threads
@@ -3832,6 +3864,8 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "ingest_device") *value = h->ingest_device;
     else if (k == "colour_device") *value = h->colour_device;
     else if (k == "colour_device_used") *value = h->colour_device_used;
+    else if (k == "stream_device") *value = h->stream_device;
+    else if (k == "stream_device_used") *value = h->stream_device_used;
     else if (k == "co_tenants") *value = h->co_tenants;
     else if (k == "ingest_device_used") *value = h->ingest_device_used;
     else if (k == "prb_pack_active") *value = h->prb_pack_active;

@@ -141,3 +141,137 @@ template hipError_t device_csr_to_csc<double>(int64_t, int32_t, int64_t, const i
                                               double*, int*, hipStream_t);
 
 }  // namespace spfm
+
+// ---------------------------------------------------------------------------------------------
+// Entry stream of the persistent row-block passes on the device (host form:
+// spfm_schedule.cpp build_rowblock_stream): entries sorted by (row block g, step b, slot q, row).
+// A column's rows ascend, so its entries in row block g are one contiguous range of the CSC
+// arrays -- two binary searches per (column, row block) give every count without an atomic and
+// every position deterministically: the same sp / src / lmask as the host builder.
+// ---------------------------------------------------------------------------------------------
+#include <rocprim/device/device_scan.hpp>
+
+namespace spfm {
+
+__device__ __forceinline__ int64_t rbs_lower_bound(const int32_t* __restrict__ a, int64_t lo,
+                                                   int64_t hi, int64_t key) {
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)a[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// thread <-> (visiting position pos, row block g), g fastest
+__global__ void rbs_count_kernel(int32_t d, int G, int nb, int64_t rows_per,
+                                 const int32_t* __restrict__ order, const int32_t* __restrict__ bptr,
+                                 const int64_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
+                                 int32_t* __restrict__ cnt, int32_t* __restrict__ first) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)d * G) return;
+    const int pos = (int)(t / G), g = (int)(t % G);
+    int blo = 0, bhi = nb;  // the step of position pos: largest b with bptr[b] <= pos
+    while (bhi - blo > 1) {
+        const int mid = (blo + bhi) >> 1;
+        if (bptr[mid] <= pos) blo = mid;
+        else bhi = mid;
+    }
+    const int b = blo, q = pos - bptr[b];
+    const int32_t j = order[pos];
+    const int64_t cb = cptr[j], ce = cptr[j + 1];
+    const int64_t lo = rbs_lower_bound(cidx, cb, ce, (int64_t)g * rows_per);
+    const int64_t hi = rbs_lower_bound(cidx, lo, ce, (int64_t)(g + 1) * rows_per);
+    first[t] = (int32_t)lo;
+    cnt[((size_t)g * nb + b) * 65 + q] = (int32_t)(hi - lo);
+}
+
+__global__ void rbs_fill_kernel(int32_t d, int G, int nb, const int32_t* __restrict__ bptr,
+                                const int32_t* __restrict__ cnt, const int32_t* __restrict__ sp,
+                                const int32_t* __restrict__ first, int32_t* __restrict__ src) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)d * G) return;
+    const int pos = (int)(t / G), g = (int)(t % G);
+    int blo = 0, bhi = nb;
+    while (bhi - blo > 1) {
+        const int mid = (blo + bhi) >> 1;
+        if (bptr[mid] <= pos) blo = mid;
+        else bhi = mid;
+    }
+    const size_t at = ((size_t)g * nb + blo) * 65 + (size_t)(pos - bptr[blo]);
+    const int32_t m = cnt[at], dst = sp[at], lo = first[t];
+    for (int32_t u = 0; u < m; ++u) src[(size_t)dst + u] = lo + u;
+}
+
+// thread <-> (g, b): slots with more than long_thresh entries
+__global__ void rbs_lmask_kernel(int G, int nb, int long_thresh, const int32_t* __restrict__ bptr,
+                                 const int32_t* __restrict__ cnt, uint32_t* __restrict__ lmask,
+                                 int* __restrict__ any_long) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)G * nb) return;
+    const int b = (int)(t % nb);
+    const int ncols = bptr[b + 1] - bptr[b];
+    uint32_t m0 = 0u, m1 = 0u;
+    for (int q = 0; q < ncols && q < 64; ++q)
+        if (cnt[(size_t)t * 65 + q] > long_thresh) {
+            if (q < 32) m0 |= 1u << q;
+            else m1 |= 1u << (q - 32);
+        }
+    lmask[(size_t)t * 2] = m0;
+    lmask[(size_t)t * 2 + 1] = m1;
+    if (m0 | m1) atomicOr(any_long, 1);
+}
+
+// Device pointers: order[d] (column of every visiting position), bptr[nb + 1], cptr / cidx.
+// Outputs (device, allocated by the caller): sp[G * nb * 65 + 1], src[nnz], lmask[G * nb * 2];
+// *has_long = any long slot.  Scratch is allocated and freed inside.
+hipError_t device_rowblock_stream(int64_t n, int32_t d, int64_t nnz, int G, int nb, int long_thresh,
+                                  const int32_t* order, const int32_t* bptr, const int64_t* cptr,
+                                  const int32_t* cidx, int32_t* sp, int32_t* src, uint32_t* lmask,
+                                  int* has_long, hipStream_t stream) {
+    *has_long = 0;
+    hipError_t e;
+    int32_t *cnt = nullptr, *first = nullptr;
+    int* flag = nullptr;
+    void* temp = nullptr;
+    auto done = [&](hipError_t rc) {
+        (void)hipFree(cnt);
+        (void)hipFree(first);
+        (void)hipFree(flag);
+        (void)hipFree(temp);
+        return rc;
+    };
+    const int64_t rows_per = (n + G - 1) / G > 0 ? (n + G - 1) / G : 1;
+    const size_t nsp = (size_t)G * nb * 65 + 1;
+    const int64_t pairs = (int64_t)d * G;
+    if ((e = hipMalloc(&cnt, sizeof(int32_t) * nsp)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&first, sizeof(int32_t) * (size_t)(pairs > 0 ? pairs : 1))) != hipSuccess)
+        return done(e);
+    if ((e = hipMalloc(&flag, sizeof(int))) != hipSuccess) return done(e);
+    if ((e = hipMemsetAsync(cnt, 0, sizeof(int32_t) * nsp, stream)) != hipSuccess) return done(e);
+    if ((e = hipMemsetAsync(flag, 0, sizeof(int), stream)) != hipSuccess) return done(e);
+    const unsigned blocks = (unsigned)((pairs + 255) / 256);
+    hipLaunchKernelGGL(rbs_count_kernel, dim3(blocks), dim3(256), 0, stream, d, G, nb, rows_per,
+                       order, bptr, cptr, cidx, cnt, first);
+    size_t temp_bytes = 0;
+    if ((e = rocprim::exclusive_scan(nullptr, temp_bytes, cnt, sp, (int32_t)0, nsp,
+                                     rocprim::plus<int32_t>(), stream)) != hipSuccess)
+        return done(e);
+    if ((e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16)) != hipSuccess) return done(e);
+    if ((e = rocprim::exclusive_scan(temp, temp_bytes, cnt, sp, (int32_t)0, nsp,
+                                     rocprim::plus<int32_t>(), stream)) != hipSuccess)
+        return done(e);
+    hipLaunchKernelGGL(rbs_fill_kernel, dim3(blocks), dim3(256), 0, stream, d, G, nb, bptr, cnt, sp,
+                       first, src);
+    hipLaunchKernelGGL(rbs_lmask_kernel, dim3((unsigned)(((int64_t)G * nb + 255) / 256)), dim3(256),
+                       0, stream, G, nb, long_thresh, bptr, cnt, lmask, flag);
+    if ((e = hipGetLastError()) != hipSuccess) return done(e);
+    if ((e = hipMemcpyAsync(has_long, flag, sizeof(int), hipMemcpyDeviceToHost, stream)) !=
+            hipSuccess ||
+        (e = hipStreamSynchronize(stream)) != hipSuccess)
+        return done(e);
+    (void)nnz;
+    return done(hipSuccess);
+}
+
+}  // namespace spfm

@@ -299,7 +299,8 @@ int spfm_set_option(spfm_handle h, const char* key, int value);
  * 0, or no room for the sort's scratch: host threads), "colour_device" (0/1, default 1: the
  * first-fit colouring of spfm_set_schedule(SPFM_SCHED_COLORED) runs on the device when the
  * conflict structure is the handle's own matrix -- the same order and batch boundaries as the
- * host form; "colour_device_used" tells), "co_tenants" (1..64, default 1: the number
+ * host form; "colour_device_used" tells), "stream_device" (0/1, default 1: the entry stream of
+ * the 64-column passes is built on the device, entry for entry the host builder's), "co_tenants" (1..64, default 1: the number
  * of handles of this process whose persistent passes run at the same time on this device --
  * independent fits, one handle and one host thread each; the handle then sizes its passes to
  * 1/co_tenants of the CUs and its residency check to the shared device.  Set it before the

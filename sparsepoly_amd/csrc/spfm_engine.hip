@@ -56,8 +56,8 @@ extern template hipError_t device_csr_to_csc<double>(int64_t, int32_t, int64_t, 
                                                      int32_t*, double*, int*, hipStream_t);
 // spfm_ingest.hip: the row-block entry stream on the device (same result as build_rowblock_stream)
 hipError_t device_rowblock_stream(int64_t, int32_t, int64_t, int, int, int, const int32_t*,
-                                  const int32_t*, const int64_t*, const int32_t*, int32_t*, int32_t*,
-                                  uint32_t*, int*, hipStream_t);
+                                  const int32_t*, const int64_t*, const int32_t*, const uint8_t*,
+                                  int32_t*, int32_t*, uint32_t*, int*, int64_t*, hipStream_t);
 // spfm_colour.hip: the first-fit colouring on the device (same result as schedule_colored)
 hipError_t device_first_fit(int64_t, int32_t, int64_t, const int64_t*, const int32_t*, const int64_t*,
                             const int32_t*, int, int32_t*, int*, int*, hipStream_t);
@@ -1608,8 +1608,8 @@ struct spfm_engine {
             int hl = 0;
             const hipError_t e = device_rowblock_stream(
                 n, d, nnz, prb_G, nb_, prb_long, d_order.as<int32_t>(), d_bptr.as<int32_t>(),
-                cptr.as<int64_t>(), cidx.as<int32_t>(), prb_sp.as<int32_t>(), d_src.as<int32_t>(),
-                prb_lmask.as<uint32_t>(), &hl, stream);
+                cptr.as<int64_t>(), cidx.as<int32_t>(), nullptr, prb_sp.as<int32_t>(),
+                d_src.as<int32_t>(), prb_lmask.as<uint32_t>(), &hl, nullptr, stream);
             if (e == hipSuccess) {
                 prb_has_long = hl;
                 stream_device_used = 1;
@@ -1706,11 +1706,44 @@ struct spfm_engine {
                        cf_row, cf_qq, cf_ia, cf_ib, clist, skip);
         const int nbr = (int)r_batch_ptr.size() - 1;
         if ((double)nbr > 0.6 * (double)n_batches()) return SPFM_OK;  // not worth a second stream
-        build_rowblock_stream(n, h_cptr.data(), h_cidx.data(), order, r_batch_ptr, prb_G, prb_long, sp,
-                              src, lmask, skip.data());
-        relax_has_long = 0;
-        for (uint32_t m : lmask) relax_has_long |= (m != 0u);
-        const size_t ne = src.size(), ncf = cf_row.size();
+        // the merged steps' entry stream (without the entries on conflict rows): on the device like
+        // the strict one (ensure_prb), or by the host builder
+        DevBuf d_src;
+        HIPC(r_bptr.alloc(sizeof(int32_t) * r_batch_ptr.size()));
+        HIPC(hipMemcpyAsync(r_bptr.p, r_batch_ptr.data(), sizeof(int32_t) * r_batch_ptr.size(),
+                            hipMemcpyHostToDevice, stream));
+        const size_t nsp_r = (size_t)prb_G * nbr * 65 + 1;
+        bool dev_stream = false;
+        size_t ne = 0;
+        if (stream_device && nnz >= (1 << 20)) {
+            DevBuf d_skip;
+            HIPC(d_skip.alloc((size_t)nnz));
+            HIPC(hipMemcpyAsync(d_skip.p, skip.data(), (size_t)nnz, hipMemcpyHostToDevice, stream));
+            HIPC(d_src.alloc(sizeof(int32_t) * (size_t)nnz));
+            HIPC(r_sp.alloc(sizeof(int32_t) * nsp_r));
+            HIPC(r_lmask.alloc(sizeof(uint32_t) * (size_t)prb_G * nbr * 2));
+            int hl = 0;
+            int64_t tot = 0;
+            const hipError_t e = device_rowblock_stream(
+                n, d, nnz, prb_G, nbr, prb_long, d_order.as<int32_t>(), r_bptr.as<int32_t>(),
+                cptr.as<int64_t>(), cidx.as<int32_t>(), d_skip.as<uint8_t>(), r_sp.as<int32_t>(),
+                d_src.as<int32_t>(), r_lmask.as<uint32_t>(), &hl, &tot, stream);
+            if (e == hipSuccess) {
+                relax_has_long = hl;
+                ne = (size_t)tot;
+                dev_stream = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (!dev_stream) {
+            build_rowblock_stream(n, h_cptr.data(), h_cidx.data(), order, r_batch_ptr, prb_G,
+                                  prb_long, sp, src, lmask, skip.data());
+            relax_has_long = 0;
+            for (uint32_t m : lmask) relax_has_long |= (m != 0u);
+            ne = src.size();
+        }
+        const size_t ncf = cf_row.size();
         // the conflict rows' x values, in the storage type
         std::vector<PrbConf<T>> hcf(ncf ? ncf : 1);
         {
@@ -1728,23 +1761,23 @@ struct spfm_engine {
                 hcf[c].xb = hv[(size_t)cf_ib[c]];
             }
         }
-        DevBuf d_src;
-        HIPC(d_src.alloc(sizeof(int32_t) * (ne ? ne : 1)));
-        HIPC(r_bptr.alloc(sizeof(int32_t) * r_batch_ptr.size()));
-        HIPC(r_sp.alloc(sizeof(int32_t) * sp.size()));
-        HIPC(r_lmask.alloc(sizeof(uint32_t) * lmask.size()));
+        if (!dev_stream) {
+            HIPC(d_src.alloc(sizeof(int32_t) * (ne ? ne : 1)));
+            HIPC(r_sp.alloc(sizeof(int32_t) * sp.size()));
+            HIPC(r_lmask.alloc(sizeof(uint32_t) * lmask.size()));
+        }
         HIPC(r_erow.alloc(sizeof(int32_t) * (ne ? ne : 1)));
         HIPC(r_eval.alloc(sizeof(T) * (ne ? ne : 1)));
         HIPC(r_cfptr.alloc(sizeof(int32_t) * cf_ptr.size()));
         HIPC(r_cf.alloc(sizeof(PrbConf<T>) * hcf.size()));
         HIPC(r_clist.alloc(sizeof(int16_t) * clist.size() + 16));
         HIPC(r_cslab.alloc(sizeof(double) * 2 * 64 * 8));
-        HIPC(hipMemcpyAsync(r_bptr.p, r_batch_ptr.data(), sizeof(int32_t) * r_batch_ptr.size(),
-                            hipMemcpyHostToDevice, stream));
-        HIPC(hipMemcpyAsync(r_sp.p, sp.data(), sizeof(int32_t) * sp.size(), hipMemcpyHostToDevice,
-                            stream));
-        HIPC(hipMemcpyAsync(r_lmask.p, lmask.data(), sizeof(uint32_t) * lmask.size(),
-                            hipMemcpyHostToDevice, stream));
+        if (!dev_stream) {
+            HIPC(hipMemcpyAsync(r_sp.p, sp.data(), sizeof(int32_t) * sp.size(), hipMemcpyHostToDevice,
+                                stream));
+            HIPC(hipMemcpyAsync(r_lmask.p, lmask.data(), sizeof(uint32_t) * lmask.size(),
+                                hipMemcpyHostToDevice, stream));
+        }
         HIPC(hipMemcpyAsync(r_cfptr.p, cf_ptr.data(), sizeof(int32_t) * cf_ptr.size(),
                             hipMemcpyHostToDevice, stream));
         HIPC(hipMemcpyAsync(r_cf.p, hcf.data(), sizeof(PrbConf<T>) * hcf.size(),
@@ -1752,8 +1785,9 @@ struct spfm_engine {
         HIPC(hipMemcpyAsync(r_clist.p, clist.data(), sizeof(int16_t) * clist.size(),
                             hipMemcpyHostToDevice, stream));
         if (ne > 0) {
-            HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * ne, hipMemcpyHostToDevice,
-                                stream));
+            if (!dev_stream)
+                HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * ne, hipMemcpyHostToDevice,
+                                    stream));
             hipLaunchKernelGGL((prb_gather_kernel<T>), dim3(cdiv((int64_t)ne, 256)), dim3(256), 0,
                                stream, (int64_t)ne, d_src.as<int32_t>(), cidx.as<int32_t>(),
                                cval.as<T>(), r_erow.as<int32_t>(), r_eval.as<T>());

@@ -167,7 +167,8 @@ __device__ __forceinline__ int64_t rbs_lower_bound(const int32_t* __restrict__ a
 __global__ void rbs_count_kernel(int32_t d, int G, int nb, int64_t rows_per,
                                  const int32_t* __restrict__ order, const int32_t* __restrict__ bptr,
                                  const int64_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
-                                 int32_t* __restrict__ cnt, int32_t* __restrict__ first) {
+                                 const uint8_t* __restrict__ skip, int32_t* __restrict__ cnt,
+                                 int32_t* __restrict__ first) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)d * G) return;
     const int pos = (int)(t / G), g = (int)(t % G);
@@ -183,10 +184,16 @@ __global__ void rbs_count_kernel(int32_t d, int G, int nb, int64_t rows_per,
     const int64_t lo = rbs_lower_bound(cidx, cb, ce, (int64_t)g * rows_per);
     const int64_t hi = rbs_lower_bound(cidx, lo, ce, (int64_t)(g + 1) * rows_per);
     first[t] = (int32_t)lo;
-    cnt[((size_t)g * nb + b) * 65 + q] = (int32_t)(hi - lo);
+    int32_t m = (int32_t)(hi - lo);
+    if (skip)  // entries left out of the stream (relaxed runs: those on conflict rows)
+        for (int64_t ii = lo; ii < hi; ++ii) m -= skip[ii] ? 1 : 0;
+    cnt[((size_t)g * nb + b) * 65 + q] = m;
 }
 
 __global__ void rbs_fill_kernel(int32_t d, int G, int nb, const int32_t* __restrict__ bptr,
+                                const int64_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
+                                const int32_t* __restrict__ order, int64_t rows_per,
+                                const uint8_t* __restrict__ skip,
                                 const int32_t* __restrict__ cnt, const int32_t* __restrict__ sp,
                                 const int32_t* __restrict__ first, int32_t* __restrict__ src) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -200,7 +207,15 @@ __global__ void rbs_fill_kernel(int32_t d, int G, int nb, const int32_t* __restr
     }
     const size_t at = ((size_t)g * nb + blo) * 65 + (size_t)(pos - bptr[blo]);
     const int32_t m = cnt[at], dst = sp[at], lo = first[t];
-    for (int32_t u = 0; u < m; ++u) src[(size_t)dst + u] = lo + u;
+    if (!skip) {
+        for (int32_t u = 0; u < m; ++u) src[(size_t)dst + u] = lo + u;
+    } else {  // the range's end again, then its entries that stay
+        const int32_t j = order[pos];
+        const int64_t hi = rbs_lower_bound(cidx, lo, cptr[j + 1], (int64_t)(g + 1) * rows_per);
+        int32_t u = 0;
+        for (int64_t ii = lo; ii < hi; ++ii)
+            if (!skip[ii]) src[(size_t)dst + u++] = (int32_t)ii;
+    }
 }
 
 // thread <-> (g, b): slots with more than long_thresh entries
@@ -222,13 +237,16 @@ __global__ void rbs_lmask_kernel(int G, int nb, int long_thresh, const int32_t* 
     if (m0 | m1) atomicOr(any_long, 1);
 }
 
-// Device pointers: order[d] (column of every visiting position), bptr[nb + 1], cptr / cidx.
+// Device pointers: order[d] (column of every visiting position), bptr[nb + 1], cptr / cidx,
+// skip[nnz] or nullptr (CSC entries that are not part of the stream).
 // Outputs (device, allocated by the caller): sp[G * nb * 65 + 1], src[nnz], lmask[G * nb * 2];
-// *has_long = any long slot.  Scratch is allocated and freed inside.
+// *has_long = any long slot, *n_entries = entries in the stream.  Scratch is allocated and freed
+// inside.
 hipError_t device_rowblock_stream(int64_t n, int32_t d, int64_t nnz, int G, int nb, int long_thresh,
                                   const int32_t* order, const int32_t* bptr, const int64_t* cptr,
-                                  const int32_t* cidx, int32_t* sp, int32_t* src, uint32_t* lmask,
-                                  int* has_long, hipStream_t stream) {
+                                  const int32_t* cidx, const uint8_t* skip, int32_t* sp, int32_t* src,
+                                  uint32_t* lmask, int* has_long, int64_t* n_entries,
+                                  hipStream_t stream) {
     *has_long = 0;
     hipError_t e;
     int32_t *cnt = nullptr, *first = nullptr;
@@ -252,7 +270,7 @@ hipError_t device_rowblock_stream(int64_t n, int32_t d, int64_t nnz, int G, int 
     if ((e = hipMemsetAsync(flag, 0, sizeof(int), stream)) != hipSuccess) return done(e);
     const unsigned blocks = (unsigned)((pairs + 255) / 256);
     hipLaunchKernelGGL(rbs_count_kernel, dim3(blocks), dim3(256), 0, stream, d, G, nb, rows_per,
-                       order, bptr, cptr, cidx, cnt, first);
+                       order, bptr, cptr, cidx, skip, cnt, first);
     size_t temp_bytes = 0;
     if ((e = rocprim::exclusive_scan(nullptr, temp_bytes, cnt, sp, (int32_t)0, nsp,
                                      rocprim::plus<int32_t>(), stream)) != hipSuccess)
@@ -261,15 +279,19 @@ hipError_t device_rowblock_stream(int64_t n, int32_t d, int64_t nnz, int G, int 
     if ((e = rocprim::exclusive_scan(temp, temp_bytes, cnt, sp, (int32_t)0, nsp,
                                      rocprim::plus<int32_t>(), stream)) != hipSuccess)
         return done(e);
-    hipLaunchKernelGGL(rbs_fill_kernel, dim3(blocks), dim3(256), 0, stream, d, G, nb, bptr, cnt, sp,
-                       first, src);
+    hipLaunchKernelGGL(rbs_fill_kernel, dim3(blocks), dim3(256), 0, stream, d, G, nb, bptr, cptr, cidx,
+                       order, rows_per, skip, cnt, sp, first, src);
     hipLaunchKernelGGL(rbs_lmask_kernel, dim3((unsigned)(((int64_t)G * nb + 255) / 256)), dim3(256),
                        0, stream, G, nb, long_thresh, bptr, cnt, lmask, flag);
     if ((e = hipGetLastError()) != hipSuccess) return done(e);
+    int32_t total = 0;  // entries in the stream = the scan's last element
     if ((e = hipMemcpyAsync(has_long, flag, sizeof(int), hipMemcpyDeviceToHost, stream)) !=
             hipSuccess ||
+        (e = hipMemcpyAsync(&total, sp + (nsp - 1), sizeof(int32_t), hipMemcpyDeviceToHost,
+                            stream)) != hipSuccess ||
         (e = hipStreamSynchronize(stream)) != hipSuccess)
         return done(e);
+    if (n_entries) *n_entries = total;
     (void)nnz;
     return done(hipSuccess);
 }

@@ -19,16 +19,23 @@ from . import engine as _engine
 # HIP spreads a process's streams over four hardware queues, and a persistent pass of the
 # default 64 row blocks takes a quarter of the CUs: more fits at once would only queue up
 MAX_CONCURRENT = 4
+# the persistent pbcd pass is bound by its entry loops, which lengthen as its share of the CUs
+# shrinks: two at a time are its best (config 4: 25.4 / 35.3 / 33.1 iterations per second in
+# aggregate with 1 / 2 / 4 fits, profiles/r03_concurrent_fits.jsonl)
+MAX_CONCURRENT_PBCD = 2
 
 
-def fit_concurrently(estimators, X, y, max_concurrent=MAX_CONCURRENT):
+def fit_concurrently(estimators, X, y, max_concurrent=None):
     """Fit every estimator of ``estimators`` on ``(X, y)``, up to ``max_concurrent`` at a time on
-    the GPU.  ``X`` / ``y`` may be one data set for all of them or sequences with one entry per
+    the GPU (default: four, two when all of them use ``solver='pbcd'``).  ``X`` / ``y`` may be one data set for all of them or sequences with one entry per
     estimator (cross-validation folds).  Returns the list of fitted estimators (the same
     objects); the first exception raised by a fit is re-raised after all fits have ended."""
     ests = list(estimators)
     if not ests:
         return ests
+    if max_concurrent is None:
+        all_pbcd = all(getattr(e, "solver", None) == "pbcd" for e in ests)
+        max_concurrent = MAX_CONCURRENT_PBCD if all_pbcd else MAX_CONCURRENT
     if int(max_concurrent) < 1:
         raise ValueError("max_concurrent must be >= 1.")
     per_fit_data = isinstance(X, (list, tuple))
@@ -78,7 +85,7 @@ def fit_concurrently(estimators, X, y, max_concurrent=MAX_CONCURRENT):
     return ests
 
 
-def fit_path(estimator, X, y, max_concurrent=MAX_CONCURRENT, **grid):
+def fit_path(estimator, X, y, max_concurrent=None, **grid):
     """Clones of ``estimator`` with the parameter values of ``grid`` (keyword -> sequence, all of
     one length; e.g. ``gamma=[1e-3, 1e-4, 1e-5]``), fitted side by side.  Returns the fitted
     clones in grid order; ``estimator`` itself is not touched."""

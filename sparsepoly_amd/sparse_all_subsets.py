@@ -143,7 +143,7 @@ class _BaseSparseAllSubsets(BaseSparsePoly, metaclass=ABCMeta):
             warnings.warn("Objective did not converge. Increase max_iter.")
         return self
 
-    def fit_path(self, X, y, max_concurrent=4, **grid):
+    def fit_path(self, X, y, max_concurrent=None, **grid):
         """Clones of this estimator over a parameter grid (``gamma=[...]``, ...), fitted side by
         side on the GPU (sparsepoly_amd/concurrent.py); each equals its solo ``fit``."""
         from .concurrent import fit_path

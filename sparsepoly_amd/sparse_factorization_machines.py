@@ -498,7 +498,7 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 engine.close()
         return self._finish_fit(converged)
 
-    def fit_path(self, X, y, max_concurrent=4, **grid):
+    def fit_path(self, X, y, max_concurrent=None, **grid):
         """Clones of this estimator over a parameter grid (``gamma=[...]``, ``beta=[...]``, ... all
         of one length), fitted side by side on the GPU; see sparsepoly_amd/concurrent.py.  Each
         clone equals its own solo ``fit`` bit for bit."""

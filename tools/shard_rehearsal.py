@@ -27,7 +27,8 @@ def main():
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--d", type=int, default=1_000_000)
     ap.add_argument("--ranks", type=int, default=8)
-    ap.add_argument("--passes", type=int, default=2)
+    ap.add_argument("--passes", type=int, default=30,
+                    help="components per timed epoch (30 = a whole iteration of the configuration)")
     ap.add_argument("--groups", default="0", help="pcdw_groups values to try (0 = default)")
     args = ap.parse_args()
     n, d, N = args.n, args.d, args.ranks
@@ -58,7 +59,7 @@ def run(args, S, X, y, n, d, N, lo, hi, t_struct, groups):
     t_sched = time.time() - t0
     ic = np.arange(args.passes, dtype=np.int32)
     eng.cd_linear_epoch(ALPHA)
-    eng.pcd_epoch(0, 2, BETA, GAMMA, 1.0, ic)          # builds the streams
+    eng.pcd_epoch(0, 2, BETA, GAMMA, 1.0, ic[:2])      # builds the streams
     t0 = time.perf_counter()
     eng.cd_linear_epoch(ALPHA)
     t_lin = time.perf_counter() - t0
@@ -76,7 +77,8 @@ def run(args, S, X, y, n, d, N, lo, hi, t_struct, groups):
                ms_per_cd_linear_epoch=round(1e3 * t_lin, 2),
                ms_per_component_pass=round(1e3 * t_pass, 2),
                us_per_dependent_step=round(1e6 * t_pass / eng.n_batches, 2),
-               est_ms_per_iteration_without_hops=round(1e3 * (t_lin + K * t_pass), 0))
+               passes_timed=args.passes,
+               ms_per_iteration_without_hops=round(1e3 * (t_lin + K * t_pass), 0))
     eng.close()
     print(json.dumps(out), flush=True)
 

@@ -411,3 +411,59 @@ def test_warm_start_keeps_device_session():
     assert a._device_session is not None
     a.release_device()
     assert a._device_session is None
+
+
+def test_fullsize_four_concurrent_fits_equal_their_solo_runs(config2_matrix):
+    """Full BASELINE config-2 size: four handles training side by side (one host thread and one
+    stream each, 64 workgroups per persistent pass: all 256 CUs taken) against the same four
+    trainings one after the other -- bit-identical parameters and predictions, and no pass
+    redone on the multi-kernel engine (sparsepoly_amd/concurrent.py)."""
+    import threading
+
+    from sparsepoly_amd import engine as E
+
+    Xc, y = config2_matrix
+    X = Xc.tocsr()
+    k, d = 30, Xc.shape[1]
+    gammas = [1e-4, 3e-4, 1e-3, 3e-5]
+    P0 = 0.01 * np.random.RandomState(0).randn(1, k, d)
+
+    def make():
+        with E.co_tenancy(4):
+            eng = E.HipEngine(0, "f32")
+        eng.set_data(X, y)
+        eng.set_params(P0, np.zeros(d), np.ones(k))
+        eng.configure("pcd", "squared", "squaredl12", 2)
+        eng.init_pred(2, True, False)
+        eng.set_schedule("colored", np.arange(d, dtype=np.int32))
+        return eng
+
+    def train(eng, gamma, out, i, barrier=None):
+        ic = np.arange(4, dtype=np.int32)      # 4 of the 30 component passes: bounded run time
+        if barrier is not None:
+            barrier.wait()
+        v = [eng.cd_linear_epoch(1.0) + eng.pcd_epoch(0, 2, 10.0, gamma, 1.0, ic)
+             for _ in range(2)]
+        P, w = eng.get_params()
+        out[i] = (np.array(v), P, w, eng.get_y_pred(), eng.get_option("persistent_fallbacks"))
+
+    solo = [None] * 4
+    for f in range(4):
+        eng = make()
+        train(eng, gammas[f], solo, f)
+        eng.close()
+    engs = [make() for _ in range(4)]
+    together = [None] * 4
+    barrier = threading.Barrier(4)
+    th = [threading.Thread(target=train, args=(engs[f], gammas[f], together, f, barrier))
+          for f in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for eng in engs:
+        eng.close()
+    for f in range(4):
+        assert together[f] is not None and together[f][4] == 0
+        for a, b in zip(solo[f][:4], together[f][:4]):
+            assert np.array_equal(a, b)

@@ -14,9 +14,60 @@ import numpy as np
 # those are taken, doubles streams up on a queue -- two persistent passes on one queue run one
 # after the other.  Four fits plus the null stream (PyTorch's default stream, any synchronous
 # hipMemcpy) are five streams.  The variable is read when the HIP runtime initialises, i.e. at the
-# first HIP call of the process: setting it here is early enough unless the host program has
-# already touched the GPU -- it can export the variable itself then.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# first HIP call of the process.  It is NOT set at import (a process-wide side effect on every
+# other HIP user): `ensure_hw_queues` sets it when concurrent fits are first asked for, if the
+# runtime is not up yet, and warns when it is too late.
+
+
+def hip_initialised():
+    """Has the HIP / HSA runtime of this process initialised (then it has read its environment)?
+    The runtime opens /dev/kfd when it does; looking at our own descriptors initialises nothing."""
+    try:
+        for fd in os.listdir("/proc/self/fd"):
+            try:
+                if os.readlink("/proc/self/fd/" + fd) == "/dev/kfd":
+                    return True
+            except OSError:
+                continue
+    except OSError:
+        pass
+    return False
+
+
+HIP_INITIALISED_BEFORE_IMPORT = hip_initialised()
+QUEUES_SET_BY_PACKAGE = False
+
+
+def ensure_hw_queues(n_streams):
+    """Called before `n_streams` fits are started side by side.  Makes sure the HIP runtime maps
+    them onto distinct hardware queues: exports GPU_MAX_HW_QUEUES=8 if the runtime has not
+    initialised yet and the variable is unset; when it is too late for that and fewer queues than
+    streams (+ the null stream) are configured, warns that fits will share queues -- two
+    persistent passes on one queue run one after the other (measured: 279 / 279 / 551 / 551 ms per
+    iteration instead of 4 x 285).  Returns the queue count the runtime is taken to use."""
+    global QUEUES_SET_BY_PACKAGE
+    import warnings
+
+    need = int(n_streams) + 1
+    val = os.environ.get("GPU_MAX_HW_QUEUES")
+    have = int(val) if (val and val.isdigit()) else None
+    if not hip_initialised():
+        if have is None:
+            os.environ["GPU_MAX_HW_QUEUES"] = "8"
+            QUEUES_SET_BY_PACKAGE = True
+            have = 8
+        return have
+    eff = have if have is not None else 4
+    if eff < need and n_streams > 1:
+        warnings.warn(
+            "sparsepoly_amd: %d concurrent fits, but the HIP runtime of this process was "
+            "initialised with %d hardware queues (GPU_MAX_HW_QUEUES %s): fits that share a queue "
+            "run one after the other.  Export GPU_MAX_HW_QUEUES=8 before the process first "
+            "touches the GPU (PyTorch users: before the first torch.cuda call)."
+            % (n_streams, eff, "= %d" % have if have is not None else "unset"),
+            RuntimeWarning, stacklevel=3)
+    return eff
+
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPFM_HIP_LIB") or os.path.join(_HERE, "lib", "libspfm_hip.so")

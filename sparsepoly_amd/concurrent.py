@@ -25,11 +25,31 @@ MAX_CONCURRENT = 4
 MAX_CONCURRENT_PBCD = 2
 
 
-def fit_concurrently(estimators, X, y, max_concurrent=None):
-    """Fit every estimator of ``estimators`` on ``(X, y)``, up to ``max_concurrent`` at a time on
-    the GPU (default: four, two when all of them use ``solver='pbcd'``).  ``X`` / ``y`` may be one data set for all of them or sequences with one entry per
-    estimator (cross-validation folds).  Returns the list of fitted estimators (the same
-    objects); the first exception raised by a fit is re-raised after all fits have ended."""
+def visible_devices():
+    """Ids of the HIP devices of this process (asked of torch without initialising any)."""
+    try:
+        import torch
+
+        return list(range(int(torch.cuda.device_count())))
+    except Exception:
+        return [0]
+
+
+def fit_concurrently(estimators, X, y, max_concurrent=None, devices=None, share_data=True):
+    """Fit every estimator of ``estimators`` on ``(X, y)``, up to ``max_concurrent`` at a time
+    PER DEVICE (default: four, two when all of them use ``solver='pbcd'``).  ``X`` / ``y`` may be
+    one data set for all of them or sequences with one entry per estimator (cross-validation
+    folds).
+
+    ``devices``: ``None`` = each estimator's own ``device`` (one GPU); a list of device ids, or
+    ``"all"``, fans the fits out over those GPUs -- nothing is exchanged between fits, so the
+    aggregate rate grows with the number of devices by construction; an estimator's ``device``
+    attribute is ignored then (and restored afterwards).
+
+    One data set for all: the fits of a device share ONE device image of the matrix and its entry
+    streams (``share_data``; ``spfm_share_data``), and the first fit to reach the colouring
+    computes it for everybody.  Returns the list of fitted estimators (the same objects); the
+    first exception raised by a fit is re-raised after all fits have ended."""
     ests = list(estimators)
     if not ests:
         return ests
@@ -42,39 +62,57 @@ def fit_concurrently(estimators, X, y, max_concurrent=None):
     if per_fit_data:
         if not isinstance(y, (list, tuple)) or len(X) != len(ests) or len(y) != len(ests):
             raise ValueError("X and y must hold one entry per estimator.")
+    if devices == "all":
+        devices = visible_devices()
+    if devices is not None:
+        devices = [int(dv) for dv in devices]
+        if not devices or len(set(devices)) != len(devices) or min(devices) < 0:
+            raise ValueError("devices must be a non-empty list of distinct device ids.")
     for e in ests:
         if getattr(e, "distributed", False):
-            raise ValueError("concurrent fits run on one GPU (distributed=False).")
+            raise ValueError("concurrent fits are independent fits (distributed=False).")
         if getattr(e, "warm_start", False) and getattr(e, "_device_session", None) is not None:
             # a kept device session was sized for a solo fit (all CUs): start it afresh
             e.release_device()
-    n_threads = min(int(max_concurrent), len(ests))
+    slots = [None] if devices is None else devices  # None: the estimator's own device
+    per_dev = min(int(max_concurrent), -(-len(ests) // len(slots)))
     todo = list(enumerate(ests))[::-1]
     lock = threading.Lock()
     errors = []
-
-    def work():
-        while True:
-            with lock:
-                if not todo or errors:
-                    return
-                i, est = todo.pop()
-            try:
-                est.fit(X[i] if per_fit_data else X, y[i] if per_fit_data else y)
-            except BaseException as exc:  # re-raised by the caller's thread
-                with lock:
-                    errors.append(exc)
-                return
-
     _engine._capi.load()  # once, before the threads race for it
+    _engine._capi.ensure_hw_queues(per_dev)
     # one data set for all: the first fit to reach the colouring computes it, the others install
-    # the result (same order, same steps -- what their own colouring would have produced)
-    with _engine.co_tenancy(n_threads, share_schedules=not per_fit_data):
-        threads = [threading.Thread(target=work, name="spfm-fit-%d" % t) for t in range(n_threads)]
+    # the result (same order, same steps -- what their own colouring would have produced); the
+    # same for the device image of the matrix
+    root = _engine.Tenancy(per_dev, share_schedules=not per_fit_data,
+                           share_data=bool(share_data) and not per_fit_data)
+
+    def work(dev):
+        _engine.bind_tenancy(root.on_device(dev))
+        try:
+            while True:
+                with lock:
+                    if not todo or errors:
+                        return
+                    i, est = todo.pop()
+                try:
+                    est.fit(X[i] if per_fit_data else X, y[i] if per_fit_data else y)
+                except BaseException as exc:  # re-raised by the caller's thread
+                    with lock:
+                        errors.append(exc)
+                    return
+        finally:
+            _engine.bind_tenancy(None)
+
+    try:
+        threads = [threading.Thread(target=work, args=(dev,), name="spfm-fit-%s-%d" % (dev, t))
+                   for dev in slots for t in range(per_dev)]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
+    finally:
+        root.close()
     for e in ests:
         # a device session kept by warm_start was sized for a share of the CUs: the next solo fit
         # starts a full-size one (fitted attributes stay)
@@ -85,7 +123,7 @@ def fit_concurrently(estimators, X, y, max_concurrent=None):
     return ests
 
 
-def fit_path(estimator, X, y, max_concurrent=None, **grid):
+def fit_path(estimator, X, y, max_concurrent=None, devices=None, **grid):
     """Clones of ``estimator`` with the parameter values of ``grid`` (keyword -> sequence, all of
     one length; e.g. ``gamma=[1e-3, 1e-4, 1e-5]``), fitted side by side.  Returns the fitted
     clones in grid order; ``estimator`` itself is not touched."""
@@ -105,4 +143,4 @@ def fit_path(estimator, X, y, max_concurrent=None, **grid):
         e = clone(estimator)
         e.set_params(**{name: values[i] for name, values in grid.items()})
         ests.append(e)
-    return fit_concurrently(ests, X, y, max_concurrent=max_concurrent)
+    return fit_concurrently(ests, X, y, max_concurrent=max_concurrent, devices=devices)

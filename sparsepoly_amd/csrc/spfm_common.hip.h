@@ -50,7 +50,8 @@ enum {
     BR_RELAX_ROUNDS = 5,     // ... and the rounds their chains took (diagnostic, not a branch)
     BR_COUNT = 8
 };
-__device__ unsigned g_branch_count[BR_COUNT];
+// (one copy per translation unit: spfm_engine.hip.h SPFM_DEFINE_BRANCH_COUNTS)
+static __device__ unsigned g_branch_count[BR_COUNT];
 // Counted once per step that took the branch.  REDUNDANT = true: the chain runs in every
 // workgroup of the launch (the persistent passes; pcd_chain_sync_kernel, up to the workgroup's own
 // column) -- the LAST workgroup of the grid runs the step's whole chain exactly once and counts;
@@ -179,7 +180,7 @@ __device__ __forceinline__ double grad_factor(const double* a, double x, double 
 
 // ------------------------------------------------------------ control kernels
 
-__global__ void begin_pass_kernel(Ctl* ctl, const int32_t* comp_order, const double* lams) {
+static __global__ void begin_pass_kernel(Ctl* ctl, const int32_t* comp_order, const double* lams) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const int s = comp_order[ctl->pass];
         ctl->s = s;
@@ -191,7 +192,7 @@ __global__ void begin_pass_kernel(Ctl* ctl, const int32_t* comp_order, const dou
 // host-stepped epochs (user-defined regularizer objects): the caller computed the step's new
 // coordinates; pnew_delta[q] holds p_new on entry and p_old - p_new on return (what
 // pcd_sync_kernel consumes), P[s, j] and sum_viol are updated (pcd.py:119-121)
-__global__ void host_apply_pcd_kernel(const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc,
+static __global__ void host_apply_pcd_kernel(const Ctl* __restrict__ ctl, const ColDesc* __restrict__ desc,
                                       int ncols, double* __restrict__ P, int d,
                                       const double* __restrict__ pold,
                                       double* __restrict__ pnew_delta,
@@ -206,12 +207,12 @@ __global__ void host_apply_pcd_kernel(const Ctl* __restrict__ ctl, const ColDesc
 }
 
 // undo of begin_pass_kernel's counter step for a pass that was announced but not launched
-__global__ void unbegin_pass_kernel(Ctl* ctl) {
+static __global__ void unbegin_pass_kernel(Ctl* ctl) {
     if (threadIdx.x == 0 && blockIdx.x == 0) ctl->pass -= 1;
 }
 
 // sum viol_col[0..d) -> out[0]  (one workgroup, fixed order => deterministic)
-__global__ __launch_bounds__(kBlock) void reduce_sum_kernel(const double* __restrict__ v, int n,
+static __global__ __launch_bounds__(kBlock) void reduce_sum_kernel(const double* __restrict__ v, int n,
                                                              double* __restrict__ out) {
     __shared__ double red[16];
     double a = 0, b = 0;
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void reduce_sum_kernel(const double* __rest
 
 // first stage of a long deterministic sum: out[block] = sum of the block's contiguous
 // slice of v (fixed slicing and fixed order inside => reproducible)
-__global__ __launch_bounds__(kBlock) void reduce_partial_kernel(const double* __restrict__ v,
+static __global__ __launch_bounds__(kBlock) void reduce_partial_kernel(const double* __restrict__ v,
                                                                  int64_t n,
                                                                  double* __restrict__ out) {
     __shared__ double red[16];

@@ -1,0 +1,1757 @@
+// spfm_engine_core.hip -- host engine: data images, parameters, schedule, predict, communicators,
+// residency / recovery of the persistent passes, and the C ABI (include/spfm.h).
+#include "spfm_engine.hip.h"
+#include "spfm_linear.hip.h"   // col_norm_kernel
+#include "spfm_predict.hip.h"
+#include "spfm_pbcd.hip.h"     // kPbW
+
+using namespace spfm;
+
+static thread_local std::string g_create_error;
+
+// ------------------------------------------------------------------ RCCL (lazy)
+// RCCL is loaded with dlopen so that the single-GPU path has no link dependency
+// and shares whichever librccl the process already holds (PyTorch ships one).
+namespace {
+struct ncclUniqueId_ {
+    char internal[128];
+};
+enum { ncclSum_ = 0 };
+enum { ncclFloat64_ = 8 };
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId_*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId_, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load(std::string& err) {
+        if (lib) return true;
+        // 1) a copy the process already holds (PyTorch maps its own librccl.so): share it;
+        // 2) otherwise load ROCm's, with local scope so that it never interposes on a
+        //    copy another library may bring later.
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (const char* nm : names) {
+            lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) {
+            const char* fresh[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+            for (const char* nm : fresh) {
+                lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+                if (lib) break;
+            }
+        }
+        if (!lib) {
+            err = std::string("cannot load librccl: ") + dlerror();
+            return false;
+        }
+        GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+        AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) {
+            err = "librccl lacks a required symbol";
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+}  // namespace
+
+spfm_engine::~spfm_engine() {
+    clear_graphs();
+    for (auto& ps : prof)
+        for (auto e : ps.ev) (void)hipEventDestroy(e);
+    if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+    for (size_t r = 0; r < peer_ptr.size(); ++r)
+        if (peer_ptr[r] && peer_ptr[r] != peer_own) (void)hipIpcCloseMemHandle(peer_ptr[r]);
+    if (peer_own) (void)hipFree(peer_own);
+    if (shm.hdr) munmap((void*)shm.hdr, shm.bytes);
+    if (h_scalar) (void)hipHostFree(h_scalar);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+// ------------------------------------------------------------------- comm
+// sense-reversing barrier over the shm header; bounded (30 s) so that a dead peer
+// becomes an error instead of a hang
+int spfm_engine::shm_barrier() {
+    shm.local_sense ^= 1;
+    if (__atomic_add_fetch(&shm.hdr->arrive, 1, __ATOMIC_ACQ_REL) == n_ranks) {
+        __atomic_store_n(&shm.hdr->arrive, 0, __ATOMIC_RELAXED);
+        __atomic_store_n(&shm.hdr->sense, shm.local_sense, __ATOMIC_RELEASE);
+        return SPFM_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (__atomic_load_n(&shm.hdr->sense, __ATOMIC_ACQUIRE) != shm.local_sense) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+            FAIL(SPFM_ERR_RUNTIME, "shm communicator: peer did not arrive within 30 s");
+    }
+    return SPFM_OK;
+}
+
+int spfm_engine::allreduce_shm(double* buf, size_t count) {
+    for (size_t off = 0; off < count; off += ShmComm::kMaxDoubles) {  // long vectors in pieces
+        int rc = allreduce_shm_piece(buf + off, std::min(ShmComm::kMaxDoubles, count - off));
+        if (rc) return rc;
+    }
+    return SPFM_OK;
+}
+
+int spfm_engine::allreduce_shm_piece(double* buf, size_t count) {
+    shm_host.resize(count);
+    HIPC(hipMemcpyAsync(shm_host.data(), buf, sizeof(double) * count, hipMemcpyDeviceToHost,
+                        stream));
+    HIPC(hipStreamSynchronize(stream));
+    std::memcpy(shm.slots + (size_t)rank * ShmComm::kMaxDoubles, shm_host.data(),
+                sizeof(double) * count);
+    int rc = shm_barrier();
+    if (rc) return rc;
+    for (size_t i = 0; i < count; ++i) {  // fixed rank order: identical on every rank
+        double a = 0.0;
+        for (int r = 0; r < n_ranks; ++r) a += shm.slots[(size_t)r * ShmComm::kMaxDoubles + i];
+        shm_host[i] = a;
+    }
+    rc = shm_barrier();  // nobody overwrites a slot before everyone has read it
+    if (rc) return rc;
+    HIPC(hipMemcpyAsync(buf, shm_host.data(), sizeof(double) * count, hipMemcpyHostToDevice,
+                        stream));
+    HIPC(hipStreamSynchronize(stream));
+    return SPFM_OK;
+}
+
+int spfm_engine::allreduce(double* buf, size_t count) {
+    if (shm.hdr) return allreduce_shm(buf, count);
+    if (!comm) return SPFM_OK;
+    int rc = g_rccl.AllReduce(buf, buf, count, ncclFloat64_, ncclSum_, comm, stream);
+    if (rc != 0) {
+        err = std::string("ncclAllReduce: ") +
+              (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+        return SPFM_ERR_RUNTIME;
+    }
+    return SPFM_OK;
+}
+
+int spfm_engine::ensure_col_norm() {
+    if (col_norm_reduced || !dist()) return SPFM_OK;
+    int rc = allreduce(col_norm.as<double>(), (size_t)d);
+    if (rc) return rc;
+    col_norm_reduced = true;
+    return SPFM_OK;
+}
+
+// --------------------------------------------------------- P <-> Pt images
+int spfm_engine::ensure_p() {
+    if (p_valid) return SPFM_OK;
+    for (int o = 0; o < n_orders; ++o) {
+        const size_t off = (size_t)o * k * d;
+        hipLaunchKernelGGL(transpose_kernel, dim3(cdiv((int64_t)k * d, 256)), dim3(256), 0,
+                           stream, Pt.as<double>() + off, d, k, P.as<double>() + off);
+    }
+    HIPC(hipGetLastError());
+    p_valid = true;
+    return SPFM_OK;
+}
+
+int spfm_engine::ensure_pt() {
+    if (pt_valid) return SPFM_OK;
+    HIPC(Pt.alloc(sizeof(double) * (size_t)n_orders * k * d));
+    for (int o = 0; o < n_orders; ++o) {
+        const size_t off = (size_t)o * k * d;
+        hipLaunchKernelGGL(transpose_kernel, dim3(cdiv((int64_t)k * d, 256)), dim3(256), 0,
+                           stream, P.as<double>() + off, k, d, Pt.as<double>() + off);
+    }
+    HIPC(hipGetLastError());
+    pt_valid = true;
+    return SPFM_OK;
+}
+
+// =================================================================== data
+// uploads both images; values in CSC order (`data_csc`) or in CSR order (`data_csr`) --
+// the other order goes through `perm` (position in the wanted order -> position in the
+// given one); conversions to the storage type run on host threads
+template <typename T>
+int spfm_engine::upload_images(const int64_t* h_cp, const int32_t* h_ci, const int64_t* h_rp,
+                  const int32_t* h_ri, const double* data_csc, const double* data_csr,
+                  const int64_t* perm, const double* y) {
+    std::vector<T> cv((size_t)nnz), rv((size_t)nnz);
+    const int T_ = (nnz >= (1 << 20)) ? schedule_threads() : 1;
+    {
+        std::vector<std::thread> pool;
+        auto work = [&](int tid) {
+            const int64_t per = (nnz + T_ - 1) / T_;
+            const int64_t lo = per * tid, hi = std::min<int64_t>(nnz, lo + per);
+            if (data_csc) {
+                for (int64_t ii = lo; ii < hi; ++ii) cv[(size_t)ii] = (T)data_csc[ii];
+                for (int64_t ii = lo; ii < hi; ++ii) rv[(size_t)ii] = (T)data_csc[perm[ii]];
+            } else {
+                for (int64_t ii = lo; ii < hi; ++ii) rv[(size_t)ii] = (T)data_csr[ii];
+                for (int64_t ii = lo; ii < hi; ++ii) cv[(size_t)ii] = (T)data_csr[perm[ii]];
+            }
+        };
+        for (int t = 1; t < T_; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
+    }
+    std::vector<T> hy((size_t)n * 2);
+    for (int64_t i = 0; i < n; ++i) {
+        hy[(size_t)2 * i] = (T)0;
+        hy[(size_t)2 * i + 1] = (T)y[i];
+    }
+    HIPC(cptr.alloc(sizeof(int64_t) * ((size_t)d + 1)));
+    HIPC(cidx.alloc(sizeof(int32_t) * (size_t)nnz));
+    HIPC(cval.alloc(sizeof(T) * (size_t)nnz));
+    HIPC(rptr.alloc(sizeof(int64_t) * ((size_t)n + 1)));
+    HIPC(ridx.alloc(sizeof(int32_t) * (size_t)nnz));
+    HIPC(rval.alloc(sizeof(T) * (size_t)nnz));
+    HIPC(yy.alloc(sizeof(T) * 2 * (size_t)n));
+    HIPC(col_norm.alloc(sizeof(double) * (size_t)d));
+    HIPC(hipMemcpyAsync(cptr.p, h_cp, sizeof(int64_t) * ((size_t)d + 1), hipMemcpyHostToDevice,
+                        stream));
+    HIPC(hipMemcpyAsync(cidx.p, h_ci, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice,
+                        stream));
+    HIPC(hipMemcpyAsync(cval.p, cv.data(), sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice,
+                        stream));
+    HIPC(hipMemcpyAsync(rptr.p, h_rp, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice,
+                        stream));
+    HIPC(hipMemcpyAsync(ridx.p, h_ri, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice,
+                        stream));
+    HIPC(hipMemcpyAsync(rval.p, rv.data(), sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice,
+                        stream));
+    HIPC(hipMemcpyAsync(yy.p, hy.data(), sizeof(T) * 2 * (size_t)n, hipMemcpyHostToDevice,
+                        stream));
+    hipLaunchKernelGGL((col_norm_kernel<T>), dim3(cdiv((int64_t)d * 64, kBlock)),
+                       dim3(kBlock), 0, stream, d, cptr.as<int64_t>(), cval.as<T>(),
+                       col_norm.as<double>());
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(stream));  // host staging vectors die here
+    return SPFM_OK;
+}
+
+template <typename T>
+int spfm_engine::set_data_t(const int64_t* indptr, const int32_t* indices, const double* data,
+               const double* y) {
+    std::vector<int64_t> h_rptr, perm;
+    std::vector<int32_t> h_ridx;
+    csc_to_csr(n, d, indptr, indices, h_rptr, h_ridx, perm);
+    return upload_images<T>(indptr, indices, h_rptr.data(), h_ridx.data(), data, nullptr,
+                            perm.data(), y);
+}
+
+// after the images are on the device: state shared by both ingest forms
+int spfm_engine::data_installed(const double* y) {
+    y_pm1 = true;
+    for (int64_t i = 0; i < n; ++i)
+        if (std::fabs(y[i]) != 1.0) {
+            y_pm1 = false;
+            break;
+        }
+    have_data = true;
+    have_schedule = false;
+    configured = false;
+    col_norm_reduced = false;
+    clear_graphs();
+    HIPC(viol_col.alloc(sizeof(double) * (size_t)d));
+    HIPC(pred_tmp.alloc(sizeof(double) * (size_t)(n > 0 ? n : 1)));
+    HIPC(partial.alloc(sizeof(double) * 1024));
+    return SPFM_OK;
+}
+
+template <typename T>
+int spfm_engine::set_data_csr_device(const int64_t* indptr, const int32_t* indices, const double* data,
+                        const double* y) {
+    std::vector<T> rv((size_t)(nnz > 0 ? nnz : 1));
+    const int T_ = (nnz >= (1 << 20)) ? schedule_threads() : 1;
+    {
+        std::vector<std::thread> pool;
+        auto work = [&](int tid) {
+            const int64_t per = (nnz + T_ - 1) / T_;
+            const int64_t lo = per * tid, hi = std::min<int64_t>(nnz, lo + per);
+            for (int64_t ii = lo; ii < hi; ++ii) rv[(size_t)ii] = (T)data[ii];
+        };
+        for (int t = 1; t < T_; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
+    }
+    std::vector<T> hy((size_t)n * 2 + 2);
+    for (int64_t i = 0; i < n; ++i) {
+        hy[(size_t)2 * i] = (T)0;
+        hy[(size_t)2 * i + 1] = (T)y[i];
+    }
+    const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
+    HIPC(cptr.alloc(sizeof(int64_t) * ((size_t)d + 1)));
+    HIPC(cidx.alloc(sizeof(int32_t) * nz));
+    HIPC(cval.alloc(sizeof(T) * nz));
+    HIPC(rptr.alloc(sizeof(int64_t) * ((size_t)n + 1)));
+    HIPC(ridx.alloc(sizeof(int32_t) * nz));
+    HIPC(rval.alloc(sizeof(T) * nz));
+    HIPC(yy.alloc(sizeof(T) * 2 * (size_t)(n > 0 ? n : 1)));
+    HIPC(col_norm.alloc(sizeof(double) * (size_t)d));
+    HIPC(hipMemcpyAsync(rptr.p, indptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice,
+                        stream));
+    if (nnz > 0) {
+        HIPC(hipMemcpyAsync(ridx.p, indices, sizeof(int32_t) * (size_t)nnz,
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(rval.p, rv.data(), sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice,
+                            stream));
+    }
+    if (n > 0)
+        HIPC(hipMemcpyAsync(yy.p, hy.data(), sizeof(T) * 2 * (size_t)n, hipMemcpyHostToDevice,
+                            stream));
+    HIPC(hipStreamSynchronize(stream));
+    int invalid = 0;
+    hipError_t e = device_csr_to_csc<T>(n, d, nnz, rptr.as<int64_t>(), ridx.as<int32_t>(),
+                                        rval.as<T>(), cptr.as<int64_t>(), cidx.as<int32_t>(),
+                                        cval.as<T>(), &invalid, stream);
+    if (e != hipSuccess) {  // e.g. no room for the sort's scratch: the host path takes over
+        (void)hipGetLastError();
+        return kIngestFallback;
+    }
+    if (invalid)
+        FAIL(SPFM_ERR_INVALID,
+             "set_data: CSR must have sorted, duplicate-free column indices in [0, d)");
+    h_cptr.resize((size_t)d + 1);
+    h_cidx.resize((size_t)nnz);
+    HIPC(hipMemcpyAsync(h_cptr.data(), cptr.p, sizeof(int64_t) * ((size_t)d + 1),
+                        hipMemcpyDeviceToHost, stream));
+    if (nnz > 0)
+        HIPC(hipMemcpyAsync(h_cidx.data(), cidx.p, sizeof(int32_t) * (size_t)nnz,
+                            hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL((col_norm_kernel<T>), dim3(cdiv((int64_t)d * 64, kBlock)), dim3(kBlock), 0,
+                       stream, d, cptr.as<int64_t>(), cval.as<T>(), col_norm.as<double>());
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(stream));
+    return SPFM_OK;
+}
+
+// CSR ingest (replaces get_dataset's X.tocsc(), dataset.py:119-123, too): the CSC image
+// is built on the device (above) or by host threads; the CSR image is the input itself
+int spfm_engine::set_data_csr(int64_t n_, int32_t d_, const int64_t* indptr, const int32_t* indices,
+                 const double* data, const double* y) {
+    if (n_ < 0 || d_ <= 0 || !indptr || !y) FAIL(SPFM_ERR_INVALID, "set_data: bad arguments");
+    if (n_ >= (int64_t)1 << 31) FAIL(SPFM_ERR_UNSUPPORTED, "n_samples must be < 2^31");
+    if (indptr[0] != 0) FAIL(SPFM_ERR_INVALID, "set_data: indptr[0] != 0");
+    for (int64_t i = 0; i < n_; ++i)
+        if (indptr[i + 1] < indptr[i]) FAIL(SPFM_ERR_INVALID, "set_data: indptr not monotone");
+    ingest_device_used = 0;
+    if (ingest_device && indptr[n_] < ((int64_t)1 << 31)) {
+        if (have_params && d_ != d) have_params = false;
+        n = n_;
+        d = d_;
+        nnz = indptr[n_];
+        int rc = dtype == SPFM_F32 ? set_data_csr_device<float>(indptr, indices, data, y)
+                                   : set_data_csr_device<double>(indptr, indices, data, y);
+        if (rc == SPFM_OK) {
+            ingest_device_used = 1;
+            return data_installed(y);
+        }
+        if (rc != kIngestFallback) {
+            have_data = false;
+            return rc;
+        }
+    }
+    std::vector<int64_t> cp, perm;
+    std::vector<int32_t> ci;
+    if (!csr_to_csc(n_, d_, indptr, indices, cp, ci, perm))
+        FAIL(SPFM_ERR_INVALID,
+             "set_data: CSR must have sorted, duplicate-free column indices in [0, d)");
+    if (have_params && d_ != d) have_params = false;
+    n = n_;
+    d = d_;
+    nnz = indptr[n_];
+    h_cptr.swap(cp);
+    h_cidx.swap(ci);
+    int rc = (dtype == SPFM_F32)
+                 ? upload_images<float>(h_cptr.data(), h_cidx.data(), indptr, indices, nullptr,
+                                        data, perm.data(), y)
+                 : upload_images<double>(h_cptr.data(), h_cidx.data(), indptr, indices, nullptr,
+                                         data, perm.data(), y);
+    if (rc) return rc;
+    return data_installed(y);
+}
+
+int spfm_engine::set_data(int64_t n_, int32_t d_, const int64_t* indptr, const int32_t* indices,
+             const double* data, const double* y) {
+    if (n_ < 0 || d_ <= 0 || !indptr || !y) FAIL(SPFM_ERR_INVALID, "set_data: bad arguments");
+    if (n_ >= (int64_t)1 << 31) FAIL(SPFM_ERR_UNSUPPORTED, "n_samples must be < 2^31");
+    if (indptr[0] != 0) FAIL(SPFM_ERR_INVALID, "set_data: indptr[0] != 0");
+    for (int j = 0; j < d_; ++j)
+        if (indptr[j + 1] < indptr[j]) FAIL(SPFM_ERR_INVALID, "set_data: indptr not monotone");
+    const int64_t nz = indptr[d_];
+    for (int64_t ii = 0; ii < nz; ++ii)
+        if (indices[ii] < 0 || indices[ii] >= n_)
+            FAIL(SPFM_ERR_INVALID, "set_data: row index out of range");
+    // canonical CSC required: ascending, duplicate-free rows inside each column
+    for (int j = 0; j < d_; ++j)
+        for (int64_t ii = indptr[j] + 1; ii < indptr[j + 1]; ++ii)
+            if (indices[ii] <= indices[ii - 1])
+                FAIL(SPFM_ERR_INVALID,
+                     "set_data: CSC must have sorted, duplicate-free row indices");
+    if (have_params && d_ != d) have_params = false;
+    n = n_;
+    d = d_;
+    nnz = nz;
+    h_cptr.assign(indptr, indptr + d + 1);
+    h_cidx.assign(indices, indices + nnz);
+    int rc = (dtype == SPFM_F32) ? set_data_t<float>(indptr, indices, data, y)
+                                 : set_data_t<double>(indptr, indices, data, y);
+    if (rc) return rc;
+    return data_installed(y);
+}
+
+// ================================================================= params
+int spfm_engine::set_params(int n_orders_, int k_, int32_t d_, const double* P_, const double* w_,
+               const double* lams_) {
+    if (n_orders_ <= 0 || k_ <= 0 || d_ <= 0 || !P_ || !w_ || !lams_)
+        FAIL(SPFM_ERR_INVALID, "set_params: bad arguments");
+    if (have_data && d_ != d)
+        FAIL(SPFM_ERR_INVALID, "set_params: n_features differs from the data");
+    if (!have_data) d = d_;
+    for (int s = 0; s < k_; ++s)
+        if (std::fabs(lams_[s]) != 1.0) FAIL(SPFM_ERR_INVALID, "Lambdas must be +1 or -1.");
+    if (n_orders_ != n_orders || k_ != k) {
+        configured = false;
+        clear_graphs();
+    }
+    n_orders = n_orders_;
+    k = k_;
+    h_lams.assign(lams_, lams_ + k);
+    HIPC(P.alloc(sizeof(double) * (size_t)n_orders * k * d));
+    HIPC(w.alloc(sizeof(double) * (size_t)d));
+    HIPC(lams.alloc(sizeof(double) * (size_t)k));
+    HIPC(hipMemcpyAsync(P.p, P_, sizeof(double) * (size_t)n_orders * k * d,
+                        hipMemcpyHostToDevice, stream));
+    HIPC(hipMemcpyAsync(w.p, w_, sizeof(double) * (size_t)d, hipMemcpyHostToDevice, stream));
+    HIPC(hipMemcpyAsync(lams.p, lams_, sizeof(double) * (size_t)k, hipMemcpyHostToDevice,
+                        stream));
+    HIPC(hipStreamSynchronize(stream));
+    p_valid = true;
+    pt_valid = false;
+    have_params = true;
+    return SPFM_OK;
+}
+
+int spfm_engine::get_params(double* P_, double* w_) {
+    if (!have_params) FAIL(SPFM_ERR_INVALID, "get_params: no parameters set");
+    int rc = ensure_p();
+    if (rc) return rc;
+    if (P_)
+        HIPC(hipMemcpyAsync(P_, P.p, sizeof(double) * (size_t)n_orders * k * d,
+                            hipMemcpyDeviceToHost, stream));
+    if (w_)
+        HIPC(hipMemcpyAsync(w_, w.p, sizeof(double) * (size_t)d, hipMemcpyDeviceToHost,
+                            stream));
+    HIPC(hipStreamSynchronize(stream));
+    return SPFM_OK;
+}
+
+// ============================================================== configure
+int spfm_engine::configure(int solver_, int loss_, int reg_, int top_degree_) {
+    if (!have_data || !have_params)
+        FAIL(SPFM_ERR_INVALID, "configure: set data and parameters first");
+    if (loss_ < 0 || loss_ > 2) FAIL(SPFM_ERR_INVALID, "Loss function not supported.");
+    if (reg_ < 0 || reg_ > 5) FAIL(SPFM_ERR_INVALID, "Regularizer not supported.");
+    if (solver_ != SPFM_SOLVER_PCD && solver_ != SPFM_SOLVER_PBCD && solver_ != SPFM_SOLVER_PSGD)
+        FAIL(SPFM_ERR_INVALID, "Solver is not supported.");
+    if (solver_ == SPFM_SOLVER_PSGD) return configure_psgd(loss_, reg_, top_degree_);
+    const bool all_subsets = top_degree_ == -1;  // regularizers are called with degree = -1
+    if (!all_subsets && top_degree_ < 2)
+        FAIL(SPFM_ERR_UNSUPPORTED, "degree must be >= 2 (factorization machine) or -1 (all-subsets)");
+    if (top_degree_ > SPFM_MAX_DEGREE)
+        FAIL(SPFM_ERR_UNSUPPORTED, "degree > 6 is not supported by the HIP engine");
+    if (all_subsets) {
+        // sparse_all_subsets.py:33-38: l1 / l21 / omegacs / omegati
+        const bool ok_pcd = (reg_ == SPFM_REG_L1 || reg_ == SPFM_REG_OMEGATI);
+        const bool ok_pbcd = (reg_ == SPFM_REG_L1 || reg_ == SPFM_REG_L21 || reg_ == SPFM_REG_OMEGACS);
+        if ((solver_ == SPFM_SOLVER_PCD && !ok_pcd) || (solver_ == SPFM_SOLVER_PBCD && !ok_pbcd))
+            FAIL(SPFM_ERR_INVALID, "this regularizer cannot be used with this solver (all-subsets)");
+        if (solver_ == SPFM_SOLVER_PBCD && k > 256)
+            FAIL(SPFM_ERR_UNSUPPORTED, "pbcd: n_components > 256 not supported");
+    } else if (solver_ == SPFM_SOLVER_PCD) {
+        // init_cache_pcd exists only for l1 / squaredl12 / omegati (README.md:28-32)
+        if (reg_ != SPFM_REG_L1 && reg_ != SPFM_REG_SQUAREDL12 && reg_ != SPFM_REG_OMEGATI)
+            FAIL(SPFM_ERR_INVALID, "this regularizer cannot be used with solver='pcd'");
+        if (reg_ == SPFM_REG_SQUAREDL12 && top_degree_ > 2)
+            FAIL(SPFM_ERR_INVALID, "SquaredL12 supports only degree=2.");
+    } else {
+        if (reg_ != SPFM_REG_L1 && reg_ != SPFM_REG_L21 && reg_ != SPFM_REG_SQUAREDL21 &&
+            reg_ != SPFM_REG_OMEGACS)
+            FAIL(SPFM_ERR_INVALID, "this regularizer cannot be used with solver='pbcd'");
+        if (reg_ == SPFM_REG_SQUAREDL21 && top_degree_ != 2)
+            FAIL(SPFM_ERR_INVALID, "SquaredL21 supports only degree=2.");
+        if (k > 256) FAIL(SPFM_ERR_UNSUPPORTED, "pbcd: n_components > 256 not supported");
+    }
+    solver = solver_;
+    loss = loss_;
+    reg = reg_;
+    top_degree = top_degree_;
+    clear_graphs();
+    const size_t ncache = kMaxDegree + 2;
+    HIPC(norms.alloc(sizeof(double) * (size_t)d));
+    HIPC(cache.alloc(sizeof(double) * ncache * 2));  // pcd: double-buffered per batch
+    HIPC(dcache.alloc(sizeof(double) * ncache));
+    HIPC(hipMemsetAsync(norms.p, 0, sizeof(double) * (size_t)d, stream));
+    HIPC(hipMemsetAsync(cache.p, 0, sizeof(double) * ncache * 2, stream));
+    double hd[kMaxDegree + 2] = {0};
+    hd[1] = 1.0;  // omegacs.py:46 ; omegati sets it in compute_cache_pcd
+    HIPC(hipMemcpyAsync(dcache.p, hd, sizeof(double) * ncache, hipMemcpyHostToDevice, stream));
+    // pcd keeps the caches of ALL components (one precompute pass per epoch): same
+    // footprint as pbcd's (n, (m-1), k) tensor
+    const size_t arow = (size_t)(top_degree > 0 ? top_degree - 1 : 1) * k;
+    HIPC(A.alloc(tsize() * (size_t)(n > 0 ? n : 1) * arow));
+    HIPC(ctl.alloc(sizeof(Ctl)));
+    HIPC(hipMemsetAsync(ctl.p, 0, sizeof(Ctl), stream));
+    HIPC(comp_order.alloc(sizeof(int32_t) * (size_t)k));
+    HIPC(scalar.alloc(sizeof(double) * 8));
+    HIPC(pb_ticket.alloc(sizeof(int) * 4));
+    if (!h_scalar) HIPC(hipHostMalloc((void**)&h_scalar, sizeof(double) * 8));
+    HIPC(hipStreamSynchronize(stream));
+    configured = true;
+    return alloc_work();
+}
+
+int spfm_engine::alloc_work() {
+    if (!configured || !have_schedule) return SPFM_OK;
+    const size_t per_part = (solver == SPFM_SOLVER_PBCD) ? ((size_t)k + 1) * kPbW : 2;
+    const size_t per_delta = (solver == SPFM_SOLVER_PBCD) ? (size_t)k : 1;
+    HIPC(part.alloc(sizeof(double) * per_part * (size_t)max_batch_cols));
+    HIPC(delta.alloc(sizeof(double) * per_delta * (size_t)max_batch_cols));
+    HIPC(pold.alloc(sizeof(double) * per_delta * (size_t)max_batch_cols));
+    HIPC(pb_scal.alloc(sizeof(double) * 4 * (size_t)max_batch_cols));
+    return SPFM_OK;
+}
+
+int spfm_engine::colour_columns(int64_t rows, const int64_t* cp, const int32_t* ci, bool own,
+                   const int32_t* jf, int max_batch) {
+    colour_device_used = 0;
+    if (own && colour_device && d >= 4096 && nnz >= (1 << 20) && nnz < ((int64_t)1 << 31) &&
+        (int64_t)d / std::max(1, max_batch) < 3500 && rptr.p && cptr.p) {
+        std::vector<int32_t> col((size_t)d);
+        int nc = 0, ovf = 0;
+        const hipError_t e = device_first_fit(n, d, nnz, cptr.as<int64_t>(), cidx.as<int32_t>(),
+                                              rptr.as<int64_t>(), jf, max_batch, col.data(), &nc,
+                                              &ovf, stream);
+        if (e == hipSuccess && !ovf && nc > 0) {
+            // classes in colour order, their columns in visiting order (stable counting sort)
+            std::vector<int32_t> bp((size_t)nc + 1, 0);
+            for (int q = 0; q < d; ++q) bp[(size_t)col[(size_t)q] + 1]++;
+            for (int c = 0; c < nc; ++c) bp[(size_t)c + 1] += bp[(size_t)c];
+            std::vector<int32_t> pos(bp.begin(), bp.end() - 1);
+            order.assign((size_t)d, 0);
+            for (int q = 0; q < d; ++q) order[(size_t)pos[(size_t)col[(size_t)q]]++] = jf[q];
+            batch_ptr = std::move(bp);
+            colour_device_used = 1;
+            return SPFM_OK;
+        }
+        (void)hipGetLastError();
+    }
+    schedule_colored(rows, d, cp, ci, jf, max_batch, order, batch_ptr);
+    return SPFM_OK;
+}
+
+int spfm_engine::set_schedule(int mode, const int32_t* indices_feature, const int64_t* cf_indptr,
+                 const int32_t* cf_indices, int64_t cf_rows, int32_t* order_out,
+                 int32_t* n_batches_out) {
+    if (!have_data) FAIL(SPFM_ERR_INVALID, "set_schedule: no data");
+    if (!indices_feature) FAIL(SPFM_ERR_INVALID, "set_schedule: indices_feature is NULL");
+    std::vector<char> seen((size_t)d, 0);
+    for (int q = 0; q < d; ++q) {
+        const int j = indices_feature[q];
+        if (j < 0 || j >= d || seen[(size_t)j])
+            FAIL(SPFM_ERR_INVALID, "set_schedule: indices_feature is not a permutation");
+        seen[(size_t)j] = 1;
+    }
+    const int64_t* cp = cf_indptr ? cf_indptr : h_cptr.data();
+    const int32_t* ci = cf_indptr ? cf_indices : h_cidx.data();
+    const int64_t rows = cf_indptr ? cf_rows : n;
+    if (cf_indptr && (!cf_indices || cf_rows <= 0))
+        FAIL(SPFM_ERR_INVALID, "set_schedule: bad conflict structure");
+    // persistent passes: 64 columns per step; the wide passes (degree-2 pcd, cd_linear) 512
+    const bool pers = persistent && (!dist() || peer_ready);
+    const bool wide_cfg = wide_on && configured && solver == SPFM_SOLVER_PCD && top_degree == 2;
+    const int max_batch =
+        pers ? std::min(max_batch_opt, wide_cfg ? 512 : 64) : max_batch_opt;
+    if (mode == SPFM_SCHED_EXACT) {
+        order.assign(indices_feature, indices_feature + d);
+        schedule_exact(rows, d, cp, ci, indices_feature, max_batch, batch_ptr);
+    } else if (mode == SPFM_SCHED_COLORED) {
+        colour_columns(rows, cp, ci, !cf_indptr, indices_feature, max_batch);
+        if (pers && max_batch > 64 && batch_ptr.size() > 1) {
+            // A wide step costs about twice a 64-column step (two fabric hops, 7.0 vs 3.2 us
+            // on one GPU): classes of moderate width are cheaper as more, narrower steps.
+            // 110 columns per class is where d/64 steps of the 64-column pass equal the
+            // classes' count of wide steps; below it, colour again with 64.
+            int32_t widest = 0;
+            for (size_t b = 0; b + 1 < batch_ptr.size(); ++b)
+                widest = std::max(widest, batch_ptr[b + 1] - batch_ptr[b]);
+            const double mean_cols = (double)d / (double)(batch_ptr.size() - 1);
+            // ... with the 64-column pass's rows in LDS; when the row blocks of 64 workgroups
+            // do not fit (float storage: > ~1.1 M rows per GPU; double storage: never) its
+            // step costs 5.7 us and the break-even is 80 columns
+            // Decided from GLOBAL inputs only (the conflict structure's row count over the
+            // ranks, the loss, the options): every rank of a sharded run must
+            // cut its sweep into the same steps, or the exchange of the replicated chain
+            // mismatches.  Same LDS formula as pcd_pass_prb (degree 2: one cache value).
+            int lds_max = 0, ncu = 0;
+            HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock,
+                                       device));
+            HIPC(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+            const int nr_eff = dist() ? n_ranks : 1;
+            const int64_t rows_rank = (rows + nr_eff - 1) / nr_eff;  // largest row shard
+            const int Gp = std::max(1, std::min(prb_G, ncu));
+            const size_t lds_lr = sizeof(double) * kPrbLdsFixed +
+                                  (size_t)((rows_rank + Gp - 1) / Gp) *
+                                      (4 + (loss == SPFM_LOSS_SQUARED ? 4 : 5)) + 16;
+            // (a non-squared loss keeps its rows in LDS only when all targets are +-1 --
+            // the classifiers' case; that rank-local fact is deliberately NOT part of the
+            // decision, which must come out the same on every rank without a collective:
+            // rank 0 alone may be colouring, bench.py / a cached Schedule)
+            const bool rows_fit = dtype == SPFM_F32 && prb_lds && lds_lr <= (size_t)lds_max;
+            const double limit = rows_fit ? (double)wide_min_cols : 0.72 * (double)wide_min_cols;
+            if (widest > 64 && mean_cols < limit)
+                colour_columns(rows, cp, ci, !cf_indptr, indices_feature, 64);
+        }
+    } else {
+        FAIL(SPFM_ERR_INVALID, "set_schedule: unknown mode");
+    }
+    int rc = install_schedule();
+    if (rc) return rc;
+    if (order_out) std::memcpy(order_out, order.data(), sizeof(int32_t) * (size_t)d);
+    if (n_batches_out) *n_batches_out = (int32_t)batch_ptr.size() - 1;
+    return SPFM_OK;
+}
+
+// upload order / descriptors / batch boundaries of the schedule in `order`, `batch_ptr`
+int spfm_engine::install_schedule() {
+    max_batch_cols = 1;
+    for (size_t b = 0; b + 1 < batch_ptr.size(); ++b)
+        max_batch_cols = std::max(max_batch_cols, batch_ptr[b + 1] - batch_ptr[b]);
+    std::vector<ColDesc> hdesc((size_t)d);
+    for (int q = 0; q < d; ++q) {
+        const int j = order[(size_t)q];
+        hdesc[(size_t)q].start = h_cptr[(size_t)j];
+        hdesc[(size_t)q].len = (int32_t)(h_cptr[(size_t)j + 1] - h_cptr[(size_t)j]);
+        hdesc[(size_t)q].j = j;
+    }
+    HIPC(d_order.alloc(sizeof(int32_t) * (size_t)d));
+    HIPC(d_desc.alloc(sizeof(ColDesc) * (size_t)d));
+    HIPC(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * (size_t)d,
+                        hipMemcpyHostToDevice, stream));
+    HIPC(hipMemcpyAsync(d_desc.p, hdesc.data(), sizeof(ColDesc) * (size_t)d,
+                        hipMemcpyHostToDevice, stream));
+    std::vector<int32_t> hb(batch_ptr.begin(), batch_ptr.end());
+    HIPC(d_bptr.alloc(sizeof(int32_t) * hb.size()));
+    HIPC(hipMemcpyAsync(d_bptr.p, hb.data(), sizeof(int32_t) * hb.size(),
+                        hipMemcpyHostToDevice, stream));
+    HIPC(hipStreamSynchronize(stream));
+    have_schedule = true;
+    prb_ready = false;
+    pb_stream_ready = false;
+    wide_ready = false;
+    relax_state = 0;
+    ++sched_version;
+    clear_graphs();
+    return alloc_work();
+}
+
+int spfm_engine::set_schedule_raw(const int32_t* order_in, const int32_t* bptr_in, int32_t nb,
+                     const int64_t* cf_indptr, const int32_t* cf_indices, int64_t cf_rows) {
+    if (!have_data) FAIL(SPFM_ERR_INVALID, "set_schedule_raw: no data");
+    if (!order_in || !bptr_in || nb < 1) FAIL(SPFM_ERR_INVALID, "set_schedule_raw: bad arguments");
+    if (bptr_in[0] != 0 || bptr_in[nb] != d)
+        FAIL(SPFM_ERR_INVALID, "set_schedule_raw: batch_ptr must run from 0 to n_features");
+    std::vector<char> seen((size_t)d, 0);
+    for (int q = 0; q < d; ++q) {
+        const int j = order_in[q];
+        if (j < 0 || j >= d || seen[(size_t)j])
+            FAIL(SPFM_ERR_INVALID, "set_schedule_raw: order is not a permutation");
+        seen[(size_t)j] = 1;
+    }
+    const int64_t* cp = cf_indptr ? cf_indptr : h_cptr.data();
+    const int32_t* ci = cf_indptr ? cf_indices : h_cidx.data();
+    const int64_t rows = cf_indptr ? cf_rows : n;
+    if (cf_indptr && (!cf_indices || cf_rows <= 0))
+        FAIL(SPFM_ERR_INVALID, "set_schedule_raw: bad conflict structure");
+    std::vector<int32_t> stamp((size_t)rows, -1);
+    for (int b = 0; b < nb; ++b) {
+        if (bptr_in[b + 1] < bptr_in[b])
+            FAIL(SPFM_ERR_INVALID, "set_schedule_raw: batch_ptr is not monotone");
+        for (int q = bptr_in[b]; q < bptr_in[b + 1]; ++q) {
+            const int j = order_in[q];
+            for (int64_t ii = cp[j]; ii < cp[j + 1]; ++ii) {
+                if (stamp[(size_t)ci[ii]] == b)
+                    FAIL(SPFM_ERR_INVALID,
+                         "set_schedule_raw: two columns of one batch share a row");
+                stamp[(size_t)ci[ii]] = b;
+            }
+        }
+    }
+    order.assign(order_in, order_in + d);
+    batch_ptr.assign(bptr_in, bptr_in + nb + 1);
+    return install_schedule();
+}
+
+// ================================================================ predict
+template <typename T, int M>
+void spfm_engine::launch_anova(int64_t rows, const int64_t* rp, const int32_t* ri, const T* rv,
+                  const double* Pt_o, double* out) {
+    hipLaunchKernelGGL((anova_predict_kernel<T, M>), dim3(cdiv(rows * 64, kBlock)),
+                       dim3(kBlock), 0, stream, rows, k, rp, ri, rv, Pt_o, lams.as<double>(),
+                       out);
+}
+
+template <typename T>
+int spfm_engine::anova_dispatch(int M, int64_t rows, const int64_t* rp, const int32_t* ri, const T* rv,
+                   const double* Pt_o, double* out) {
+    switch (M) {
+        case 0: launch_anova<T, 0>(rows, rp, ri, rv, Pt_o, out); break;
+        case 2: launch_anova<T, 2>(rows, rp, ri, rv, Pt_o, out); break;
+        case 3: launch_anova<T, 3>(rows, rp, ri, rv, Pt_o, out); break;
+        case 4: launch_anova<T, 4>(rows, rp, ri, rv, Pt_o, out); break;
+        case 5: launch_anova<T, 5>(rows, rp, ri, rv, Pt_o, out); break;
+        case 6: launch_anova<T, 6>(rows, rp, ri, rv, Pt_o, out); break;
+        default: FAIL(SPFM_ERR_UNSUPPORTED, "degree outside 2..6");
+    }
+    HIPC(hipGetLastError());
+    return SPFM_OK;
+}
+
+// out (device, f64, length rows) = _get_output on the given CSR image
+template <typename T>
+int spfm_engine::output_t(int64_t rows, const int64_t* rp, const int32_t* ri, const T* rv, int degree,
+             int fit_linear, int add_lower, double* out) {
+    if (rows == 0) return SPFM_OK;
+    int rc = ensure_p();
+    if (rc) return rc;
+    pt_valid = false;  // P is the source of truth here
+    rc = ensure_pt();
+    if (rc) return rc;
+    HIPC(hipMemsetAsync(out, 0, sizeof(double) * (size_t)rows, stream));
+    rc = anova_dispatch<T>(kind_of(degree), rows, rp, ri, rv, Pt.as<double>(), out);
+    if (rc) return rc;
+    if (add_lower) {
+        if (n_orders < 2) FAIL(SPFM_ERR_INVALID, "add_lower_deg2 needs P_[1]");
+        rc = anova_dispatch<T>(2, rows, rp, ri, rv, Pt.as<double>() + (size_t)k * d, out);
+        if (rc) return rc;
+    }
+    if (fit_linear) {
+        hipLaunchKernelGGL((linear_predict_kernel<T>), dim3(cdiv(rows, kBlock)), dim3(kBlock),
+                           0, stream, rows, rp, ri, rv, w.as<double>(), out);
+        HIPC(hipGetLastError());
+    }
+    return SPFM_OK;
+}
+
+template <typename T>
+int spfm_engine::init_pred_t(int degree, int fit_linear, int add_lower) {
+    int rc = output_t<T>(n, rptr.as<int64_t>(), ridx.as<int32_t>(), rval.as<T>(), degree,
+                         fit_linear, add_lower, pred_tmp.as<double>());
+    if (rc) return rc;
+    if (n > 0) {
+        hipLaunchKernelGGL((store_pred_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, stream, n,
+                           pred_tmp.as<double>(), yy.as<T>());
+        HIPC(hipGetLastError());
+    }
+    return sync();
+}
+
+int spfm_engine::init_pred(int degree, int fit_linear, int add_lower) {
+    if (!have_data || !have_params) FAIL(SPFM_ERR_INVALID, "init_pred: no data/params");
+    have_pred_args = true;
+    pa_degree = degree;
+    pa_lin = fit_linear;
+    pa_lower = add_lower;
+    return dtype == SPFM_F32 ? init_pred_t<float>(degree, fit_linear, add_lower)
+                             : init_pred_t<double>(degree, fit_linear, add_lower);
+}
+
+template <typename T>
+int spfm_engine::get_y_pred_t(double* out) {
+    if (n == 0) return SPFM_OK;
+    hipLaunchKernelGGL((load_pred_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, stream, n,
+                       yy.as<T>(), pred_tmp.as<double>());
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(out, pred_tmp.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
+                        stream));
+    return sync();
+}
+
+template <typename T>
+int spfm_engine::loss_sum_t(double* out) {
+    const int nb = 512;
+    hipLaunchKernelGGL((loss_partial_kernel<T>), dim3(nb), dim3(kBlock), 0, stream, n,
+                       yy.as<typename Vec2<T>::type>(), loss, partial.as<double>());
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(kBlock), 0, stream,
+                       partial.as<double>(), nb, scalar.as<double>());
+    HIPC(hipGetLastError());
+    int rc = allreduce(scalar.as<double>(), 1);
+    if (rc) return rc;
+    HIPC(hipMemcpyAsync(h_scalar, scalar.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+    rc = sync();
+    if (rc) return rc;
+    *out = h_scalar[0];
+    return SPFM_OK;
+}
+
+template <typename T>
+int spfm_engine::predict_csr_t(int64_t rows, const int64_t* indptr, const int32_t* indices,
+                  const double* data, int degree, int fit_linear, int add_lower,
+                  double* out) {
+    if (rows == 0) return SPFM_OK;
+    const int64_t nz = indptr[rows];
+    for (int64_t ii = 0; ii < nz; ++ii)
+        if (indices[ii] < 0 || indices[ii] >= d)
+            FAIL(SPFM_ERR_INVALID, "predict: column index out of range");
+    std::vector<T> hv((size_t)nz);
+    for (int64_t ii = 0; ii < nz; ++ii) hv[(size_t)ii] = (T)data[ii];
+    DevBuf rp, ri, rv, o;
+    HIPC(rp.alloc(sizeof(int64_t) * ((size_t)rows + 1)));
+    HIPC(ri.alloc(sizeof(int32_t) * (size_t)nz));
+    HIPC(rv.alloc(sizeof(T) * (size_t)nz));
+    HIPC(o.alloc(sizeof(double) * (size_t)rows));
+    HIPC(hipMemcpyAsync(rp.p, indptr, sizeof(int64_t) * ((size_t)rows + 1),
+                        hipMemcpyHostToDevice, stream));
+    HIPC(hipMemcpyAsync(ri.p, indices, sizeof(int32_t) * (size_t)nz, hipMemcpyHostToDevice,
+                        stream));
+    HIPC(hipMemcpyAsync(rv.p, hv.data(), sizeof(T) * (size_t)nz, hipMemcpyHostToDevice,
+                        stream));
+    int rc = output_t<T>(rows, rp.as<int64_t>(), ri.as<int32_t>(), rv.as<T>(), degree,
+                         fit_linear, add_lower, o.as<double>());
+    if (rc) return rc;
+    HIPC(hipMemcpyAsync(out, o.p, sizeof(double) * (size_t)rows, hipMemcpyDeviceToHost,
+                        stream));
+    return sync();
+}
+
+// ================================================================== epochs
+int spfm_engine::epoch_prologue() {
+    if (!have_data || !have_params || !configured)
+        FAIL(SPFM_ERR_INVALID, "epoch: data, parameters and configuration are required");
+    if (!have_schedule) FAIL(SPFM_ERR_INVALID, "epoch: call spfm_set_schedule first");
+    int rc = ensure_col_norm();
+    if (rc) return rc;
+    HIPC(hipMemsetAsync(viol_col.p, 0, sizeof(double) * (size_t)d, stream));
+    return SPFM_OK;
+}
+
+int spfm_engine::epoch_epilogue(double* viol) {
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(kBlock), 0, stream,
+                       viol_col.as<double>(), d, scalar.as<double>());
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(h_scalar, scalar.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPC(hipStreamSynchronize(stream));
+    prof_collect();
+    if (viol) *viol = h_scalar[0];
+    return SPFM_OK;
+}
+
+// ---- residency and recovery of the persistent passes
+// All workgroups of a persistent launch must be resident at once (they wait for each other
+// inside the kernel).  `fn` with `threads` threads and `lds` bytes of dynamic LDS: do G
+// workgroups fit the device (times the ranks that share it in a one-GPU rehearsal)?
+bool spfm_engine::resident_ok(const void* fn, int threads, size_t lds, int G) {
+    int per_cu = 0;
+    auto it = resident_cache.find(fn);
+    if (it != resident_cache.end()) {
+        per_cu = it->second;
+    } else {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            per_cu = 1;  // unknown: the in-kernel time-out stays the safety net
+        }
+        resident_cache[fn] = per_cu;
+    }
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
+        return true;
+    // host-shm communicator: ranks on one GPU; co_tenants: handles of this process whose
+    // persistent passes run side by side (concurrent fits, one stream each)
+    const int64_t sharers = (int64_t)(shm.hdr ? n_ranks : 1) * co_tenants;
+    return (int64_t)per_cu * ncu >= (int64_t)G * sharers;
+}
+
+int spfm_engine::snapshot_state(const double* params, size_t count, DevBuf& dst) {
+    HIPC(dst.alloc(sizeof(double) * count));
+    HIPC(hipMemcpyAsync(dst.p, params, sizeof(double) * count, hipMemcpyDeviceToDevice, stream));
+    const size_t nc = kMaxDegree + 2;
+    HIPC(snapC.alloc(sizeof(double) * nc * 3));
+    HIPC(hipMemcpyAsync(snapC.p, cache.p, sizeof(double) * nc * 2, hipMemcpyDeviceToDevice,
+                        stream));
+    HIPC(hipMemcpyAsync(snapC.as<double>() + nc * 2, dcache.p, sizeof(double) * nc,
+                        hipMemcpyDeviceToDevice, stream));
+    return SPFM_OK;
+}
+
+// did the persistent launches of this epoch time out?  With several ranks the answer is
+// agreed on (sum of the flags), so that all of them redo the epoch together.
+int spfm_engine::persistent_aborted(bool* out) {
+    *out = false;
+    if (!prb_abort.p) return SPFM_OK;
+    unsigned flag = 0;
+    HIPC(hipMemcpyAsync(&flag, prb_abort.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    HIPC(hipStreamSynchronize(stream));
+    double any = flag ? 1.0 : 0.0;
+    if (dist()) {
+        HIPC(hipMemcpyAsync(scalar.as<double>() + 6, &any, sizeof(double),
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipStreamSynchronize(stream));
+        int rc = allreduce(scalar.as<double>() + 6, 1);
+        if (rc) return rc;
+        HIPC(hipMemcpyAsync(&any, scalar.as<double>() + 6, sizeof(double),
+                            hipMemcpyDeviceToHost, stream));
+        HIPC(hipStreamSynchronize(stream));
+    }
+    if (flag) HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
+    *out = any != 0.0;
+    return SPFM_OK;
+}
+
+// after a time-out: parameters and regularizer state back to the epoch's start, y_pred
+// recomputed from them, the persistent passes switched off for this handle
+int spfm_engine::recover_from_abort(double* params, size_t count, const DevBuf& src, const char* what) {
+    pers_failed = true;
+    pers_fallbacks += 1;
+    pers_reason = std::string(what) +
+                  " timed out waiting for its workgroups (not all resident, or a peer GPU "
+                  "did not answer)";
+    if (!have_pred_args)
+        FAIL(SPFM_ERR_RUNTIME, pers_reason + "; the model is half-updated (no spfm_init_pred "
+                                             "call to recompute y_pred from)");
+    const size_t nc = kMaxDegree + 2;
+    HIPC(hipMemcpyAsync(params, src.p, sizeof(double) * count, hipMemcpyDeviceToDevice, stream));
+    HIPC(hipMemcpyAsync(cache.p, snapC.p, sizeof(double) * nc * 2, hipMemcpyDeviceToDevice,
+                        stream));
+    HIPC(hipMemcpyAsync(dcache.p, snapC.as<double>() + nc * 2, sizeof(double) * nc,
+                        hipMemcpyDeviceToDevice, stream));
+    clear_graphs();
+    return init_pred(pa_degree, pa_lin, pa_lower);
+}
+
+// tag 0 = "not yet" in the own exchange slab; all ranks must have passed the previous launch
+// before anybody clears (the caller's epochs are collective: one clear per launch, and a
+// rank only starts writing to a peer after that peer's clear because the first remote store
+// of a launch follows a local sweep that needs ... nothing remote).  To be safe the clear is
+// followed by a barrier over the host communicator.
+int spfm_engine::peer_clear(size_t off_doubles, size_t n_doubles) {
+    if (!peer_ready) return SPFM_OK;
+    HIPC(hipMemsetAsync(reinterpret_cast<double*>(peer_own) + off_doubles, 0,
+                        sizeof(double) * n_doubles, stream));
+    HIPC(hipStreamSynchronize(stream));
+    return host_barrier();
+}
+
+int spfm_engine::host_barrier() {
+    if (shm.hdr) return shm_barrier();
+    if (comm) {  // a 1-element all-reduce doubles as the barrier
+        int rc = allreduce(scalar.as<double>() + 4, 1);
+        if (rc) return rc;
+        HIPC(hipStreamSynchronize(stream));
+    }
+    return SPFM_OK;
+}
+
+// ======================================================================= C ABI
+#define GUARD(h)                  \
+    if (!(h)) return SPFM_ERR_INVALID; \
+    if (hipSetDevice((h)->device) != hipSuccess) { \
+        (h)->err = "hipSetDevice failed";          \
+        return SPFM_ERR_RUNTIME;                   \
+    }
+
+extern "C" {
+
+int spfm_create(spfm_handle* out, int device_id, int dtype) {
+    if (!out) return SPFM_ERR_INVALID;
+    *out = nullptr;
+    if (dtype != SPFM_F32 && dtype != SPFM_F64) {
+        g_create_error = "dtype must be SPFM_F32 or SPFM_F64";
+        return SPFM_ERR_INVALID;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return SPFM_ERR_RUNTIME;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        g_create_error = "device id out of range";
+        return SPFM_ERR_INVALID;
+    }
+    if ((e = hipSetDevice(device_id)) != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return SPFM_ERR_RUNTIME;
+    }
+    spfm_engine* h = new spfm_engine();
+    h->device = device_id;
+    h->dtype = dtype;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->devname = prop.gcnArchName;
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        delete h;
+        return SPFM_ERR_RUNTIME;
+    }
+    *out = h;
+    return SPFM_OK;
+}
+
+void spfm_destroy(spfm_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+const char* spfm_last_error(spfm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+#ifndef SPFM_BUILD_TAG
+#define SPFM_BUILD_TAG "untagged"
+#endif
+const char* spfm_build_tag(void) { return SPFM_BUILD_TAG; }
+
+int spfm_device_name(spfm_handle h, char* out, int cap) {
+    if (!h || !out || cap <= 0) return SPFM_ERR_INVALID;
+    snprintf(out, (size_t)cap, "%s", h->devname.c_str());
+    return SPFM_OK;
+}
+
+int spfm_set_data_csc(spfm_handle h, int64_t n, int32_t d, const int64_t* indptr,
+                      const int32_t* indices, const double* data, const double* y) {
+    GUARD(h);
+    return h->set_data(n, d, indptr, indices, data, y);
+}
+
+int spfm_set_data_csr(spfm_handle h, int64_t n, int32_t d, const int64_t* indptr,
+                      const int32_t* indices, const double* data, const double* y) {
+    GUARD(h);
+    return h->set_data_csr(n, d, indptr, indices, data, y);
+}
+
+int spfm_set_params(spfm_handle h, int n_orders, int k, int32_t d, const double* P,
+                    const double* w, const double* lams) {
+    GUARD(h);
+    return h->set_params(n_orders, k, d, P, w, lams);
+}
+
+int spfm_get_params(spfm_handle h, double* P, double* w) {
+    GUARD(h);
+    return h->get_params(P, w);
+}
+
+int spfm_configure(spfm_handle h, int solver, int loss, int regularizer, int top_degree) {
+    GUARD(h);
+    return h->configure(solver, loss, regularizer, top_degree);
+}
+
+int spfm_init_pred(spfm_handle h, int degree, int fit_linear, int add_lower_deg2) {
+    GUARD(h);
+    return h->init_pred(degree, fit_linear, add_lower_deg2);
+}
+
+int spfm_get_y_pred(spfm_handle h, double* out) {
+    GUARD(h);
+    if (!h->have_data || !out) return SPFM_ERR_INVALID;
+    return h->dtype == SPFM_F32 ? h->get_y_pred_t<float>(out) : h->get_y_pred_t<double>(out);
+}
+
+int spfm_loss_sum(spfm_handle h, double* out) {
+    GUARD(h);
+    if (!h->have_data || !h->configured || !out) {
+        h->err = "loss_sum: data and configuration required";
+        return SPFM_ERR_INVALID;
+    }
+    return h->dtype == SPFM_F32 ? h->loss_sum_t<float>(out) : h->loss_sum_t<double>(out);
+}
+
+int spfm_predict_csr(spfm_handle h, int64_t n, const int64_t* indptr, const int32_t* indices,
+                     const double* data, int degree, int fit_linear, int add_lower_deg2,
+                     double* out) {
+    GUARD(h);
+    if (!h->have_params) {
+        h->err = "predict: no parameters set";
+        return SPFM_ERR_INVALID;
+    }
+    if (n < 0 || !indptr || !out) return SPFM_ERR_INVALID;
+    return h->dtype == SPFM_F32
+               ? h->predict_csr_t<float>(n, indptr, indices, data, degree, fit_linear,
+                                         add_lower_deg2, out)
+               : h->predict_csr_t<double>(n, indptr, indices, data, degree, fit_linear,
+                                          add_lower_deg2, out);
+}
+
+int spfm_set_schedule(spfm_handle h, int mode, const int32_t* indices_feature,
+                      const int64_t* conflict_indptr, const int32_t* conflict_indices,
+                      int64_t conflict_n_rows, int32_t* order_out, int32_t* n_batches_out) {
+    GUARD(h);
+    return h->set_schedule(mode, indices_feature, conflict_indptr, conflict_indices,
+                           conflict_n_rows, order_out, n_batches_out);
+}
+
+int spfm_set_schedule_raw(spfm_handle h, const int32_t* order, const int32_t* batch_ptr,
+                          int32_t n_batches, const int64_t* conflict_indptr,
+                          const int32_t* conflict_indices, int64_t conflict_n_rows) {
+    GUARD(h);
+    return h->set_schedule_raw(order, batch_ptr, n_batches, conflict_indptr, conflict_indices,
+                               conflict_n_rows);
+}
+
+int spfm_get_schedule(spfm_handle h, int32_t* order_out, int32_t* batch_ptr_out,
+                      int32_t* n_batches_out) {
+    if (!h) return SPFM_ERR_INVALID;
+    if (!h->have_schedule) {
+        h->err = "get_schedule: no schedule installed";
+        return SPFM_ERR_INVALID;
+    }
+    if (order_out)
+        std::memcpy(order_out, h->order.data(), sizeof(int32_t) * h->order.size());
+    if (batch_ptr_out)
+        std::memcpy(batch_ptr_out, h->batch_ptr.data(), sizeof(int32_t) * h->batch_ptr.size());
+    if (n_batches_out) *n_batches_out = (int32_t)h->batch_ptr.size() - 1;
+    return SPFM_OK;
+}
+
+int spfm_schedule_build(int mode, int64_t n_rows, int32_t d, const int64_t* indptr,
+                        const int32_t* indices, const int32_t* indices_feature, int max_batch,
+                        int32_t* order_out, int32_t* batch_ptr_out, int32_t* n_batches_out) {
+    if (n_rows < 0 || d <= 0 || !indptr || !indices_feature || !order_out || !batch_ptr_out ||
+        !n_batches_out)
+        return SPFM_ERR_INVALID;
+    if (max_batch <= 0) max_batch = 4096;
+    std::vector<char> seen((size_t)d, 0);
+    for (int q = 0; q < d; ++q) {
+        const int j = indices_feature[q];
+        if (j < 0 || j >= d || seen[(size_t)j]) return SPFM_ERR_INVALID;
+        seen[(size_t)j] = 1;
+    }
+    std::vector<int32_t> order, bp;
+    if (mode == SPFM_SCHED_EXACT) {
+        order.assign(indices_feature, indices_feature + d);
+        schedule_exact(n_rows, d, indptr, indices, indices_feature, max_batch, bp);
+    } else if (mode == SPFM_SCHED_COLORED) {
+        schedule_colored(n_rows, d, indptr, indices, indices_feature, max_batch, order, bp);
+    } else {
+        return SPFM_ERR_INVALID;
+    }
+    std::memcpy(order_out, order.data(), sizeof(int32_t) * (size_t)d);
+    std::memcpy(batch_ptr_out, bp.data(), sizeof(int32_t) * bp.size());
+    *n_batches_out = (int32_t)bp.size() - 1;
+    return SPFM_OK;
+}
+
+int spfm_cd_linear_epoch(spfm_handle h, double alpha, double* viol) {
+    GUARD(h);
+    return h->cd_linear_epoch(alpha, viol);
+}
+
+int spfm_pcd_epoch(spfm_handle h, int order_idx, int degree, double beta, double gamma,
+                   double eta, const int32_t* indices_component, int n_comp, double* viol) {
+    GUARD(h);
+    return h->pcd_epoch(order_idx, degree, beta, gamma, eta, indices_component, n_comp, viol);
+}
+
+int spfm_pbcd_epoch(spfm_handle h, int order_idx, int degree, double beta, double gamma,
+                    double eta, double* viol) {
+    GUARD(h);
+    return h->pbcd_epoch(order_idx, degree, beta, gamma, eta, viol);
+}
+
+int spfm_host_epoch_begin(spfm_handle h, int order_idx, int degree) {
+    GUARD(h);
+    return h->host_epoch_begin(order_idx, degree);
+}
+int spfm_host_pass_begin(spfm_handle h, int component) {
+    GUARD(h);
+    return h->host_pass_begin(component);
+}
+int spfm_host_step_sums(spfm_handle h, int step, double* sums_out) {
+    GUARD(h);
+    return h->host_step(true, step, sums_out, nullptr, nullptr);
+}
+int spfm_host_step_apply(spfm_handle h, int step, const double* p_new, const double* p_old) {
+    GUARD(h);
+    return h->host_step(false, step, nullptr, p_new, p_old);
+}
+int spfm_host_epoch_end(spfm_handle h, double* viol) {
+    GUARD(h);
+    return h->host_epoch_end(viol);
+}
+
+int spfm_psgd_epoch(spfm_handle h, int degree, double alpha, double beta, double gamma,
+                    double eta0, int learning_rate, double power_t, int64_t batch_size,
+                    const int32_t* indices_samples, int64_t n_samples, int fit_linear,
+                    int64_t* it, double* sum_loss) {
+    GUARD(h);
+    return h->psgd_epoch(degree, alpha, beta, gamma, eta0, learning_rate, power_t, batch_size,
+                         indices_samples, n_samples, fit_linear, it, sum_loss);
+}
+
+int spfm_comm_unique_id(char* id128) {
+    if (!id128) return SPFM_ERR_INVALID;
+    std::string e;
+    if (!g_rccl.load(e)) {
+        g_create_error = e;
+        return SPFM_ERR_RUNTIME;
+    }
+    ncclUniqueId_ id;
+    if (g_rccl.GetUniqueId(&id) != 0) {
+        g_create_error = "ncclGetUniqueId failed";
+        return SPFM_ERR_RUNTIME;
+    }
+    std::memcpy(id128, id.internal, 128);
+    return SPFM_OK;
+}
+
+int spfm_comm_init(spfm_handle h, const char* id128, int n_ranks, int rank) {
+    GUARD(h);
+    if (!id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return SPFM_ERR_INVALID;
+    if (!g_rccl.load(h->err)) return SPFM_ERR_RUNTIME;
+    ncclUniqueId_ id;
+    std::memcpy(id.internal, id128, 128);
+    int rc = g_rccl.CommInitRank(&h->comm, n_ranks, id, rank);
+    if (rc != 0) {
+        h->err = std::string("ncclCommInitRank: ") +
+                 (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+        h->comm = nullptr;
+        return SPFM_ERR_RUNTIME;
+    }
+    h->n_ranks = n_ranks;
+    h->rank = rank;
+    h->col_norm_reduced = false;
+    h->clear_graphs();
+    return SPFM_OK;
+}
+
+int spfm_comm_init_shm(spfm_handle h, const char* shm_name, int n_ranks, int rank) {
+    GUARD(h);
+    if (!shm_name || n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks)
+        return SPFM_ERR_INVALID;
+    if (h->comm || h->shm.hdr) {
+        h->err = "a communicator is already attached";
+        return SPFM_ERR_INVALID;
+    }
+    using Shm = spfm_engine::ShmComm;
+    const size_t bytes = sizeof(Shm::Hdr) + sizeof(double) * Shm::kMaxDoubles * (size_t)n_ranks;
+    int fd = shm_open(shm_name, O_RDWR | O_CREAT, 0600);
+    if (fd < 0) {
+        h->err = std::string("shm_open failed: ") + std::strerror(errno);
+        return SPFM_ERR_RUNTIME;
+    }
+    if (ftruncate(fd, (off_t)bytes) != 0) {  // new segments are zero-filled
+        h->err = std::string("ftruncate failed: ") + std::strerror(errno);
+        close(fd);
+        return SPFM_ERR_RUNTIME;
+    }
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+        h->err = std::string("mmap failed: ") + std::strerror(errno);
+        return SPFM_ERR_RUNTIME;
+    }
+    h->shm.hdr = reinterpret_cast<Shm::Hdr*>(p);
+    h->shm.slots = reinterpret_cast<double*>(reinterpret_cast<char*>(p) + sizeof(Shm::Hdr));
+    h->shm.bytes = bytes;
+    h->shm.local_sense = 0;
+    h->n_ranks = n_ranks;
+    h->rank = rank;
+    h->col_norm_reduced = false;
+    h->clear_graphs();
+    return SPFM_OK;
+}
+
+int spfm_peer_alloc(spfm_handle h, char* handle64) {
+    GUARD(h);
+    if (!handle64) return SPFM_ERR_INVALID;
+    if (!h->peer_own) {
+        void* p = nullptr;
+        // fine-grained device memory: remote stores become visible to local polling loads
+        // without a kernel boundary.  There is NO coarse-grained fall-back: plain hipMalloc
+        // memory maps just as well over IPC, but does not promise that visibility, and the first
+        // persistent pass would spin into its time-out -- the caller takes the per-step
+        // collective instead when this fails (sparsepoly_amd.distributed.connect_peers).
+        hipError_t ae = hipExtMallocWithFlags(&p, sizeof(double) * spfm_engine::kPeerDoubles,
+                                              hipDeviceMallocFinegrained);
+        if (ae != hipSuccess) {
+            (void)hipGetLastError();
+            h->err = std::string("peer slab: fine-grained device memory is not available (") +
+                     hipGetErrorString(ae) + "); use the per-step collective";
+            return SPFM_ERR_RUNTIME;
+        }
+        if (hipMemsetAsync(p, 0, sizeof(double) * spfm_engine::kPeerDoubles, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) {
+            (void)hipFree(p);
+            h->err = "peer slab memset failed";
+            return SPFM_ERR_RUNTIME;
+        }
+        h->peer_own = p;
+    }
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    hipIpcMemHandle_t ih;
+    hipError_t e = hipIpcGetMemHandle(&ih, h->peer_own);
+    if (e != hipSuccess) {
+        h->err = std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e);
+        return SPFM_ERR_RUNTIME;
+    }
+    std::memcpy(handle64, &ih, 64);
+    return SPFM_OK;
+}
+
+int spfm_peer_connect(spfm_handle h, int n_ranks, int rank, const char* handles) {
+    GUARD(h);
+    if (!handles || n_ranks < 2 || n_ranks > 8 || rank < 0 || rank >= n_ranks)
+        return SPFM_ERR_INVALID;
+    if (!h->peer_own) {
+        h->err = "spfm_peer_connect: call spfm_peer_alloc first";
+        return SPFM_ERR_INVALID;
+    }
+    if (!h->dist() || h->n_ranks != n_ranks || h->rank != rank) {
+        h->err = "spfm_peer_connect: attach the communicator (spfm_comm_init[_shm]) with the "
+                 "same ranks first";
+        return SPFM_ERR_INVALID;
+    }
+    h->peer_ptr.assign((size_t)n_ranks, nullptr);
+    for (int r = 0; r < n_ranks; ++r) {
+        if (r == rank) {
+            h->peer_ptr[(size_t)r] = h->peer_own;
+            continue;
+        }
+        hipIpcMemHandle_t ih;
+        std::memcpy(&ih, handles + (size_t)r * 64, 64);
+        void* p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            h->err = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e);
+            return SPFM_ERR_RUNTIME;
+        }
+        h->peer_ptr[(size_t)r] = p;
+    }
+    std::vector<double*> t1((size_t)n_ranks), t2((size_t)n_ranks);
+    for (int r = 0; r < n_ranks; ++r) {
+        t1[(size_t)r] = reinterpret_cast<double*>(h->peer_ptr[(size_t)r]) + spfm_engine::kPeerPcdOff;
+        t2[(size_t)r] = reinterpret_cast<double*>(h->peer_ptr[(size_t)r]) + spfm_engine::kPeerPbOff;
+    }
+    if (h->peer_tab_pcd.alloc(sizeof(double*) * 8) != hipSuccess ||
+        h->peer_tab_pb.alloc(sizeof(double*) * 8) != hipSuccess ||
+        hipMemcpyAsync(h->peer_tab_pcd.p, t1.data(), sizeof(double*) * (size_t)n_ranks,
+                       hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(h->peer_tab_pb.p, t2.data(), sizeof(double*) * (size_t)n_ranks,
+                       hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) {
+        h->err = "peer table upload failed";
+        return SPFM_ERR_RUNTIME;
+    }
+    // handshake: every rank's store into every slab must reach a kernel that is already polling
+    // (what the persistent passes assume); all ranks are in this call together
+    {
+        DevBuf okb;
+        int ok = 0;
+        h->peer_generation += 1;
+        const unsigned long long word = 0x5350464d00000000ull + (unsigned)h->peer_generation;
+        const unsigned long long ticks = 100ull * 1000 * 1000 * 10;  // 10 s of the 100 MHz counter
+        if (okb.alloc(sizeof(int) * 4) != hipSuccess ||
+            hipMemsetAsync(okb.p, 0, sizeof(int) * 4, h->stream) != hipSuccess) {
+            h->err = "peer handshake: allocation failed";
+            return SPFM_ERR_RUNTIME;
+        }
+        hipLaunchKernelGGL(peer_probe_kernel, dim3(1), dim3(kWave), 0, h->stream,
+                           h->peer_tab_pcd.as<double*>(),
+                           spfm_engine::kPeerProbeOff - spfm_engine::kPeerPcdOff, n_ranks, rank,
+                           word, ticks, okb.as<int>());
+        if (hipMemcpyAsync(&ok, okb.p, sizeof(int), hipMemcpyDeviceToHost, h->stream) !=
+                hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) {
+            h->err = "peer handshake kernel failed";
+            return SPFM_ERR_RUNTIME;
+        }
+        if (!ok) {
+            h->err = "peer handshake timed out: a peer's store into this GPU's exchange slab did "
+                     "not become visible to a running kernel (use the per-step collective)";
+            return SPFM_ERR_RUNTIME;
+        }
+    }
+    h->peer_ready = true;
+    h->have_schedule = false;  // the step cap depends on the engine: set the schedule again
+    h->prb_ready = false;
+    h->pb_stream_ready = false;
+    h->wide_ready = false;
+    h->clear_graphs();
+    return SPFM_OK;
+}
+
+int spfm_profile_enable(spfm_handle h, int on) {
+    if (!h) return SPFM_ERR_INVALID;
+    h->prof_on = on != 0;
+    return SPFM_OK;
+}
+
+int spfm_profile_get(spfm_handle h, int which, double* ms, int64_t* launches, int64_t* nnz) {
+    if (!h || which < 0 || which > 4) return SPFM_ERR_INVALID;
+    if (ms) *ms = h->prof[which].ms;
+    if (launches) *launches = h->prof[which].launches;
+    if (nnz) *nnz = h->prof[which].nnz;
+    return SPFM_OK;
+}
+
+int spfm_profile_reset(spfm_handle h) {
+    if (!h) return SPFM_ERR_INVALID;
+    for (auto& ps : h->prof) {
+        ps.ms = 0;
+        ps.launches = 0;
+        ps.nnz = 0;
+        ps.used = 0;
+    }
+    return SPFM_OK;
+}
+
+int spfm_set_option(spfm_handle h, const char* key, int value) {
+    if (!h || !key) return SPFM_ERR_INVALID;
+    const std::string k(key);
+    if (k == "use_graph") {
+        h->use_graph = value != 0;
+    } else if (k == "fuse_chain") {
+        h->fuse_chain = value != 0;
+    } else if (k == "persistent") {
+        h->persistent = value != 0;
+        h->prb_ready = false;
+    } else if (k == "prb_long") {
+        if (value < 16) {
+            h->err = "prb_long must be >= 16";
+            return SPFM_ERR_INVALID;
+        }
+        h->prb_long = value;
+        h->prb_ready = false;
+        h->relax_state = 0;
+    } else if (k == "prb_pack") {  // packed row records for degree-3 passes (rows in global memory)
+        h->prb_pack = value != 0;
+    } else if (k == "co_tenants") {  // concurrent fits: handles sharing the device's CUs
+        if (value < 1 || value > 64) {
+            h->err = "co_tenants must be in [1, 64]";
+            return SPFM_ERR_INVALID;
+        }
+        h->co_tenants = value;
+        // every tenant keeps to its share of the CUs (one persistent workgroup per CU)
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+        const int share = std::max(1, ncu / value);
+        if (h->prb_G > share) {
+            h->prb_G = share;
+            h->prb_ready = false;
+            h->relax_state = 0;
+        }
+        if (h->pbprb_G > share) {
+            h->pbprb_G = share;
+            h->pb_stream_ready = false;
+        }
+        h->wide_ready = false;  // the wide pass caps itself (wide_groups)
+    } else if (k == "stream_device") {  // entry stream of the 64-column passes: device or host threads
+        h->stream_device = value != 0;
+        h->prb_ready = false;
+    } else if (k == "colour_device") {  // first-fit colouring on the device (default) or by host threads
+        h->colour_device = value != 0;
+    } else if (k == "ingest_device") {  // CSR -> CSC on the device (default) or by host threads
+        h->ingest_device = value != 0;
+    } else if (k == "relax") {  // merged steps for schedules of tiny steps
+        h->relax_on = value != 0;
+        h->relax_state = 0;
+    } else if (k == "prb_stamps") {
+        h->prb_stamp_on = value != 0;
+    } else if (k == "debug_spin_max") {  // test hook: polls before a persistent pass gives up
+        if (value < 64) {
+            h->err = "debug_spin_max must be >= 64";
+            return SPFM_ERR_INVALID;
+        }
+        h->spin_max = (unsigned)value;
+    } else if (k == "debug_drop_group") {  // test hook: the next `value` persistent launches
+        h->debug_drop = value;             // lack their last workgroup (they time out)
+    } else if (k == "persistent_failed") {  // 0: try the persistent passes again
+        h->pers_failed = value != 0;
+    } else if (k == "psgd_graph_sweeps") {
+        if (value < 0 || value > 64) {
+            h->err = "psgd_graph_sweeps must be in 0..64";
+            return SPFM_ERR_INVALID;
+        }
+        h->psgd_graph_sweeps = value;
+    } else if (k == "psgd_eager") {
+        h->psgd_force_eager = value != 0;
+    } else if (k == "pbcd_fuse") {
+        h->pbcd_fuse = value != 0;
+    } else if (k == "wide") {
+        h->wide_on = value != 0;
+    } else if (k == "pcdw_groups") {
+        if (value < 1) {
+            h->err = "pcdw_groups must be >= 1";
+            return SPFM_ERR_INVALID;
+        }
+        h->pcdw_G = value;
+        h->wide_ready = false;
+    } else if (k == "pbcd_persistent") {
+        h->pb_persistent = value != 0;
+    } else if (k == "peer_exchange") {
+        // 0: give the in-kernel cross-GPU exchange up (a rank could not map its peers): the
+        // passes fall back to the per-step collective.  (1 is set by spfm_peer_connect only.)
+        if (value != 0) {
+            h->err = "peer_exchange: only 0 can be set; connect with spfm_peer_connect";
+            return SPFM_ERR_INVALID;
+        }
+        h->peer_ready = false;
+        h->have_schedule = false;
+        h->prb_ready = false;
+        h->pb_stream_ready = false;
+        h->wide_ready = false;
+    } else if (k == "probe_xcd") {
+        h->probe_xcd = (int)value;
+    } else if (k == "probe_lds") {
+        h->probe_lds = (int)value;
+    } else if (k == "pbprb_dbg") {
+        h->pb_dbg = value;
+    } else if (k == "wide_min_cols") {
+        h->wide_min_cols = value;
+    } else if (k == "pcdw_stamps") {
+        h->wide_stamp_on = value != 0;
+    } else if (k == "pbprb_stamps") {
+        h->pb_stamp_on = value != 0;
+    } else if (k == "pbprb_owners") {  // dedicated owner workgroups (default 0)
+        if (value < 0 || value > 64) {
+            h->err = "pbprb_owners must be in 0..64";
+            return SPFM_ERR_INVALID;
+        }
+        h->pbprb_owners = value;
+        h->pb_stream_ready = false;
+    } else if (k == "pbprb_groups") {
+        if (value < 1) {
+            h->err = "pbprb_groups must be >= 1";
+            return SPFM_ERR_INVALID;
+        }
+        h->pbprb_G = value;
+        h->pb_stream_ready = false;
+    } else if (k == "prb_lds") {
+        h->prb_lds = value != 0;
+    } else if (k == "prb_groups") {
+        if (value < 1) {
+            h->err = "prb_groups must be >= 1";
+            return SPFM_ERR_INVALID;
+        }
+        h->prb_G = value;
+        h->prb_ready = false;
+        h->relax_state = 0;
+    } else if (k == "max_batch") {
+        if (value < 1) {
+            h->err = "max_batch must be >= 1";
+            return SPFM_ERR_INVALID;
+        }
+        h->max_batch_opt = value;
+    } else {
+        h->err = "unknown option: " + k;
+        return SPFM_ERR_INVALID;
+    }
+    h->clear_graphs();
+    return SPFM_OK;
+}
+
+int spfm_get_option(spfm_handle h, const char* key, int* value) {
+    if (!h || !key || !value) return SPFM_ERR_INVALID;
+    const std::string k(key);
+    if (k == "use_graph") *value = h->use_graph;
+    else if (k == "fuse_chain") *value = h->fuse_chain;
+    else if (k == "max_batch") *value = h->max_batch_opt;
+    else if (k == "persistent") *value = h->persistent;
+    else if (k == "prb_groups") *value = h->prb_G;
+    else if (k == "prb_lds") *value = h->prb_lds;
+    else if (k == "psgd_redone") *value = h->psgd_redone;
+    else if (k == "prb_lds_active") *value = h->prb_lds_active;
+    else if (k == "pbcd_persistent") *value = h->pb_persistent;
+    else if (k == "wide") *value = h->wide_on;
+    else if (k == "wide_active") *value = h->have_schedule && h->wide_usable();
+    else if (k == "wide_lds_active") *value = h->wide_lr_active;
+    else if (k == "pbprb_groups") *value = h->pbprb_G;
+    else if (k == "pcdw_groups") *value = h->wide_ready ? h->wide_G : h->pcdw_G;  // 0 = not chosen yet
+    else if (k == "pbprb_owners") *value = h->pb_GO;
+    else if (k == "pbprb_active") *value = h->pbprb_active;
+    else if (k == "persistent_active")
+        *value = h->have_schedule && (h->prb_usable() || h->wide_usable());
+    else if (k == "relax") *value = h->relax_on;
+    else if (k == "ingest_device") *value = h->ingest_device;
+    else if (k == "colour_device") *value = h->colour_device;
+    else if (k == "colour_device_used") *value = h->colour_device_used;
+    else if (k == "stream_device") *value = h->stream_device;
+    else if (k == "stream_device_used") *value = h->stream_device_used;
+    else if (k == "co_tenants") *value = h->co_tenants;
+    else if (k == "ingest_device_used") *value = h->ingest_device_used;
+    else if (k == "prb_pack_active") *value = h->prb_pack_active;
+    else if (k == "relax_steps")
+        *value = h->relax_state == 1 ? (int)h->r_batch_ptr.size() - 1 : 0;
+    else if (k == "persistent_fallbacks") *value = h->pers_fallbacks;
+    else if (k == "persistent_failed") *value = h->pers_failed;
+    else if (k == "n_ranks") *value = h->dist() ? h->n_ranks : 1;
+    else if (k == "peer_ready") *value = h->peer_ready;
+    else if (k == "wide_min_cols") *value = h->wide_min_cols;
+    else {
+        h->err = "unknown option: " + k;
+        return SPFM_ERR_INVALID;
+    }
+    return SPFM_OK;
+}
+
+int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap) {
+    GUARD(h);
+    if ((h->pb_dbg & 8) && out && cap >= 8) {  // diagnostic counters of the persistent pbcd pass
+        static unsigned v[16 + 4096];
+        if (hipMemcpy(v, h->pb_dbgbuf.p, sizeof v, hipMemcpyDeviceToHost) != hipSuccess)
+            return SPFM_ERR_RUNTIME;
+        int i = 0;
+        for (; i < 16 + 4096 && i < cap; ++i) out[i] = (long long)v[i];
+        return i - (i % 16);
+    }
+    if (h->wide_stamp_on && h->wide_stamps.p && out) {  // wide pcd pass's timers
+        const int nv = (int)(h->wide_stamps.bytes / sizeof(long long));
+        if (cap < nv) return SPFM_ERR_INVALID;
+        if (hipMemcpy(out, h->wide_stamps.p, sizeof(long long) * (size_t)nv,
+                      hipMemcpyDeviceToHost) != hipSuccess)
+            return SPFM_ERR_RUNTIME;
+        return nv;
+    }
+    if (h->pb_stamp_on && h->pb_stream_ready && out) {  // persistent pbcd pass's timers
+        const int nv = 16 * (h->pb_stream_G + h->pb_GO);
+        if (cap < nv) return SPFM_ERR_INVALID;
+        if (hipMemcpy(out, h->pb_stamps.p, sizeof(long long) * (size_t)nv,
+                      hipMemcpyDeviceToHost) != hipSuccess)
+            return SPFM_ERR_RUNTIME;
+        return nv;
+    }
+    if (!h->prb_ready || !out) return SPFM_ERR_INVALID;
+    const int nval = 16 * h->prb_G;
+    if (cap < nval) return SPFM_ERR_INVALID;
+    if (hipMemcpy(out, h->prb_stamps.p, sizeof(long long) * (size_t)nval, hipMemcpyDeviceToHost) !=
+        hipSuccess)
+        return SPFM_ERR_RUNTIME;
+    return nval;
+}
+
+int spfm_debug_hop_latency(spfm_handle h, int partner, int rounds, double* ns_per_hop,
+                           int* xcc_ids /* [2] */) {
+    GUARD(h);
+    if (partner < 1 || partner > 255 || rounds < 1 || rounds > (1 << 20) || !ns_per_hop)
+        return SPFM_ERR_INVALID;
+    DevBuf words, info;
+    if (words.alloc(sizeof(unsigned long long) * 32) != hipSuccess ||
+        info.alloc(sizeof(int) * 4) != hipSuccess)
+        return SPFM_ERR_RUNTIME;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return SPFM_ERR_RUNTIME;
+    float best = 1e30f;
+    int hinfo[4] = {0, 0, 0, 0};
+    for (int rep = 0; rep < 3; ++rep) {  // first repetition warms the code path
+        (void)hipMemsetAsync(words.p, 0, sizeof(unsigned long long) * 32, h->stream);
+        (void)hipMemsetAsync(info.p, 0, sizeof(int) * 4, h->stream);
+        (void)hipEventRecord(e0, h->stream);
+        hipLaunchKernelGGL(hop_pingpong_kernel, dim3(partner + 1), dim3(kWave), 0, h->stream,
+                           words.as<unsigned long long>(), rounds, partner, info.as<int>());
+        (void)hipEventRecord(e1, h->stream);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) {
+            h->err = "hop_pingpong_kernel failed";
+            return SPFM_ERR_RUNTIME;
+        }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipMemcpy(hinfo, info.p, sizeof(int) * 4, hipMemcpyDeviceToHost);
+        if (hinfo[2] != 0) {
+            h->err = "hop latency probe: partner workgroup did not respond";
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            return SPFM_ERR_RUNTIME;
+        }
+        if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ns_per_hop = (double)best * 1e6 / (2.0 * rounds);
+    if (xcc_ids) {
+        xcc_ids[0] = hinfo[0];
+        xcc_ids[1] = hinfo[1];
+    }
+    return SPFM_OK;
+}
+
+int spfm_debug_exchange_cost(spfm_handle h, int groups, int ncols, int readers_mod, int rounds,
+                             double* ns_per_round) {
+    GUARD(h);
+    if (groups < 1 || groups > 256 || ncols < 1 || ncols > 64 || readers_mod == 0 ||
+        rounds < 1 || rounds > (1 << 20) || !ns_per_round)
+        return SPFM_ERR_INVALID;
+    DevBuf slab, abortw;
+    const size_t bytes = sizeof(double) * 2 * (2 * (size_t)groups + 2) * 64 * 2;
+    if (slab.alloc(bytes) != hipSuccess || abortw.alloc(16) != hipSuccess) return SPFM_ERR_RUNTIME;
+    PrbArgs a{};
+    a.G = groups;
+    a.slab = slab.as<double>();
+    a.abort_flag = abortw.as<unsigned>();
+    a.spin_max = 1u << 21;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return SPFM_ERR_RUNTIME;
+    (void)hipFuncSetAttribute((const void*)exchange_probe_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->kPrbLds);
+    float best = 1e30f;
+    unsigned aborted = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipMemsetAsync(slab.p, 0, bytes, h->stream);
+        (void)hipMemsetAsync(abortw.p, 0, 16, h->stream);
+        (void)hipEventRecord(e0, h->stream);
+        // probe_xcd = x+1: single-XCD variant on XCD x (8x oversized grid, see the kernel)
+        hipLaunchKernelGGL(exchange_probe_kernel, dim3(h->probe_xcd ? 8 * groups + 64 : groups),
+                           dim3(readers_mod == -12 ? 768 : 512),
+                           h->probe_xcd ? (size_t)h->probe_lds : (size_t)h->kPrbLds, h->stream, a,
+                           rounds, ncols, readers_mod, h->probe_xcd);
+        (void)hipEventRecord(e1, h->stream);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) {
+            h->err = "exchange_probe_kernel failed";
+            return SPFM_ERR_RUNTIME;
+        }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipMemcpy(&aborted, abortw.p, sizeof(unsigned), hipMemcpyDeviceToHost);
+        if (aborted) break;
+        if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (aborted) {
+        h->err = "exchange probe timed out (workgroups not co-resident?)";
+        return SPFM_ERR_RUNTIME;
+    }
+    *ns_per_round = (double)best * 1e6 / rounds;
+    return SPFM_OK;
+}
+
+int spfm_debug_stream_probe(spfm_handle h, int64_t* bytes_out) {
+    GUARD(h);
+    return h->debug_stream_probe(bytes_out);
+}
+
+int spfm_debug_branch_counts(spfm_handle h, unsigned* out8, int reset) {
+    GUARD(h);
+    if (!out8) return SPFM_ERR_INVALID;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return SPFM_ERR_RUNTIME;
+    // one copy of the counters per translation unit that runs chains: add them up
+    for (int i = 0; i < BR_COUNT; ++i) out8[i] = 0;
+    hipError_t (*const units[])(unsigned*, int) = {
+        spfm_branch_counts_pcd,       spfm_branch_counts_prb_f32,   spfm_branch_counts_prb_f64,
+        spfm_branch_counts_wide,      spfm_branch_counts_pbcd,      spfm_branch_counts_pbprb_f32,
+        spfm_branch_counts_pbprb_f64};
+    for (auto unit : units)
+        if (unit(out8, reset) != hipSuccess) return SPFM_ERR_RUNTIME;
+    return SPFM_OK;
+}
+
+int spfm_set_use_graph(spfm_handle h, int on) {
+    if (!h) return SPFM_ERR_INVALID;
+    h->use_graph = on != 0;
+    if (!on) h->clear_graphs();
+    return SPFM_OK;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,188 @@
+// spfm_engine_pbprb.inc.h -- persistent pbcd pass (pbcd_prb_kernel) of the engine for ONE storage type
+// SPFM_TU_T; included by spfm_engine_pbprb_f32.hip / _f64.hip
+#include "spfm_engine.hip.h"
+#include "spfm_pbprb.hip.h"
+
+using namespace spfm;
+
+// entry stream (workgroup, step, slot, row) for G row blocks; shares the pcd pass's when
+// the workgroup counts agree
+template <typename T>
+int spfm_engine::ensure_pb_stream(int NG) {
+    int ncu = 0;
+    HIPC(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+    // pbprb_groups workgroups in all: GO dedicated owners + G row workgroups
+    const int Gtot = std::max(1, std::min(pbprb_G, ncu));
+    int GO = pbprb_owners;
+    GO = std::max(0, std::min({GO, 64, Gtot - 1}));
+    const int G = Gtot - GO;
+    if (pb_stream_ready && pb_stream_G == G && pb_stream_NG == NG && pb_GO == GO)
+        return SPFM_OK;
+    pb_GO = GO;
+    std::vector<int32_t> gsp, src;
+    std::vector<uint8_t> meta;
+    build_pb_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, G, NG, gsp, src, meta);
+    // every bound pbcd_prb_kernel indexes with, checked on the host for problems where that
+    // is free (and on request, SPFM_VALIDATE=1): an out-of-range row or slot index would be
+    // a device memory fault, i.e. a dead process
+    if (nnz < ((int64_t)1 << 22) || getenv("SPFM_VALIDATE")) {
+        const char* bad = validate_pb_stream(G, NG, gsp, src, meta);
+        if (bad) FAIL(SPFM_ERR_RUNTIME, std::string("internal: pbcd entry stream: ") + bad);
+    }
+    DevBuf d_src;
+    HIPC(d_src.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    HIPC(pb_sp.alloc(sizeof(int32_t) * gsp.size()));
+    HIPC(pb_erow.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1) + 256));
+    HIPC(pb_eval.alloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1) + 256));
+    HIPC(pb_meta.alloc((size_t)(nnz > 0 ? nnz : 1) + 256));
+    HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
+    HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
+    HIPC(pb_stamps.alloc(sizeof(long long) * 16 * (size_t)(G + GO)));
+    HIPC(hipMemsetAsync(pb_stamps.p, 0, pb_stamps.bytes, stream));
+    HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
+    HIPC(hipMemcpyAsync(pb_sp.p, gsp.data(), sizeof(int32_t) * gsp.size(),
+                        hipMemcpyHostToDevice, stream));
+    if (nnz > 0) {
+        HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * (size_t)nnz,
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(pb_meta.p, meta.data(), (size_t)nnz, hipMemcpyHostToDevice,
+                            stream));
+        hipLaunchKernelGGL((prb_gather_kernel<T>), dim3(cdiv(nnz, 256)), dim3(256), 0, stream,
+                           nnz, d_src.as<int32_t>(), cidx.as<int32_t>(), cval.as<T>(),
+                           pb_erow.as<int32_t>(), pb_eval.as<T>());
+        HIPC(hipGetLastError());
+    }
+    HIPC(hipStreamSynchronize(stream));
+    pb_stream_G = G;
+    pb_stream_NG = NG;
+    pb_stream_ready = true;
+    return SPFM_OK;
+}
+
+template <typename T, int M, int L>
+int spfm_engine::pbcd_prb_l(int order_idx, double beta, double gamma, double eta) {
+    const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
+    double* Po = Pt.as<double>() + (size_t)order_idx * k * d;  // (d,k)
+    RegState rs = regstate();
+    int rc = ensure_pb_stream<T>(kPbPrbThreads / L);
+    if (rc) return rc;
+    const int G = pb_stream_G;
+    // the rows' state as packed records (cache values, yhat, y: one line per row at k <= 30,
+    // degree 2, float): the precompute pass of pbcd.py:18-33 writes them
+    constexpr int AS = Kind<M>::AS;
+    HIPC(pb_rec.alloc(sizeof(T) * (size_t)n * AS * L + 256));
+    hipLaunchKernelGGL((pbprb_pack_kernel<T, M, L>), dim3(cdiv(n * L, kBlock)), dim3(kBlock), 0,
+                       stream, n, k, rptr.as<int64_t>(), ridx.as<int32_t>(), rval.as<T>(), Po,
+                       yy.as<T>(), pb_rec.as<T>());
+    const bool chained = (reg == SPFM_REG_SQUAREDL21 || reg == SPFM_REG_OMEGACS);
+    if (chained) {
+        hipLaunchKernelGGL(pbcd_norms_kernel, dim3(cdiv((int64_t)d * 64, kBlock)),
+                           dim3(kBlock), 0, stream, d, k, Po, rs.norms);
+        hipLaunchKernelGGL((pbcd_compute_cache_kernel<M>), dim3(1), dim3(kBlock), 0, stream, d,
+                           reg, rs);
+    }
+    HIPC(pb_slabA.alloc(sizeof(double) * 2 * 64 * (size_t)G * L));
+    HIPC(pb_slabB.alloc(sizeof(double) * 2 * 64 * L));
+    HIPC(hipMemsetAsync(pb_slabA.p, 0, sizeof(double) * 2 * 64 * (size_t)G * L, stream));
+    HIPC(hipMemsetAsync(pb_slabB.p, 0, sizeof(double) * 2 * 64 * L, stream));
+    {
+        int prc = peer_clear(kPeerPbOff, kPeerProbeOff - kPeerPbOff);
+        if (prc) return prc;
+    }
+    PbPrbArgs a;
+    a.G = G;
+    a.GO = pb_GO;
+    a.nb = n_batches();
+    a.bptr = d_bptr.as<int32_t>();
+    a.jsched = d_order.as<int32_t>();
+    a.gsp = pb_sp.as<int32_t>();
+    a.erow = pb_erow.as<int32_t>();
+    a.emeta = pb_meta.as<uint8_t>();
+    a.slabA = pb_slabA.as<double>();
+    a.slabB = pb_slabB.as<double>();
+    a.rows_per = (int)std::max<int64_t>((n + G - 1) / G, 1);
+    a.n_rows = (int)n;
+    a.abort_flag = prb_abort.as<unsigned>();
+    a.spin_max = spin_max;
+    a.n_ranks = peer_ready ? n_ranks : 1;
+    a.rank = rank;
+    a.slabC = peer_ready ? peer_tab_pb.as<double*>() : nullptr;
+    if (peer_ready && L * n_ranks > 64 * 8)
+        FAIL(SPFM_ERR_UNSUPPORTED, "persistent pbcd pass: more than 8 ranks");
+    a.stamps = pb_stamp_on ? pb_stamps.as<long long>() : nullptr;
+    a.dbg = pb_dbg;
+    HIPC(pb_dbgbuf.alloc(sizeof(unsigned) * (16 + 4096)));
+    if (pb_dbg & 8) HIPC(hipMemsetAsync(pb_dbgbuf.p, 0, sizeof(unsigned) * (16 + 4096), stream));
+    if (pb_dbg & 8) {
+        unsigned init[16] = {0, 0, 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        HIPC(hipMemcpyAsync(pb_dbgbuf.p, init, sizeof init, hipMemcpyHostToDevice, stream));
+    }
+    a.dbg_out = pb_dbgbuf.as<unsigned>();
+    const int ncache = top_degree > 0 ? top_degree + 1 : 1;
+    prof_begin(2, nnz);
+    auto go = [&](auto stamp_tag, auto down_tag) -> int {
+        constexpr bool STc = decltype(stamp_tag)::value;
+        constexpr bool DWc = decltype(down_tag)::value;
+        const size_t lds = std::max(kPrbLds, pbcd_prb_lds_bytes<T, M, L>());
+        const int grid = G + (DWc ? pb_GO : 0);
+        HIPC(hipFuncSetAttribute((const void*)pbcd_prb_kernel<T, M, L, STc, DWc>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (!resident_ok((const void*)pbcd_prb_kernel<T, M, L, STc, DWc>, kPbPrbThreads, lds,
+                         grid))
+            return kNotResident;
+        hipLaunchKernelGGL((pbcd_prb_kernel<T, M, L, STc, DWc>), dim3(launch_groups(grid)),
+                           dim3(kPbPrbThreads),
+                           lds, stream, a, pb_eval.as<T>(), pb_rec.as<T>(), Po, k, d,
+                           lams.as<double>(), loss, reg, rs, ncache, mu, beta, gamma, eta,
+                           prb_viol.as<double>());
+        return SPFM_OK;
+    };
+    constexpr bool can_stamp = std::is_same<T, float>::value && M == 2 && L == 32;
+    if (pb_stamp_on && !can_stamp)
+        FAIL(SPFM_ERR_UNSUPPORTED, "pbprb_stamps: built for float storage, degree 2, k <= 30");
+    const bool down = pb_GO > 0;
+    if constexpr (can_stamp) {
+        if (pb_stamp_on)
+            rc = down ? go(std::true_type{}, std::true_type{})
+                      : go(std::true_type{}, std::false_type{});
+        else
+            rc = down ? go(std::false_type{}, std::true_type{})
+                      : go(std::false_type{}, std::false_type{});
+    } else {
+        rc = down ? go(std::false_type{}, std::true_type{})
+                  : go(std::false_type{}, std::false_type{});
+    }
+    if (rc == kNotResident) prof_cancel(2, nnz);
+    if (rc) return rc;
+    prof_end(2);
+    hipLaunchKernelGGL((pbprb_unpack_kernel<T, AS, L>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                       n, pb_rec.as<T>(), yy.as<T>());
+    hipLaunchKernelGGL(fold_viol_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
+                       d_desc.as<ColDesc>(), prb_viol.as<double>(), viol_col.as<double>());
+    HIPC(hipGetLastError());
+    return SPFM_OK;
+}
+
+template <typename T, int M>
+int spfm_engine::pbcd_prb_m(int order_idx, double beta, double gamma, double eta) {
+    if (k <= 30) return pbcd_prb_l<T, M, 32>(order_idx, beta, gamma, eta);
+    return pbcd_prb_l<T, M, 64>(order_idx, beta, gamma, eta);
+}
+
+template <typename T>
+int spfm_engine::pbcd_prb_dispatch(int M, int order_idx, double beta, double gamma, double eta) {
+    switch (M) {
+        case 0: return pbcd_prb_m<T, 0>(order_idx, beta, gamma, eta);
+        case 2: return pbcd_prb_m<T, 2>(order_idx, beta, gamma, eta);
+        case 3: return pbcd_prb_m<T, 3>(order_idx, beta, gamma, eta);
+        case 4: return pbcd_prb_m<T, 4>(order_idx, beta, gamma, eta);
+    }
+    FAIL(SPFM_ERR_UNSUPPORTED, "persistent pbcd pass: degree outside {2,3,4,all-subsets}");
+}
+
+
+#define SPFM_CAT_(a, b) a##b
+#define SPFM_CAT(a, b) SPFM_CAT_(a, b)
+SPFM_DEFINE_BRANCH_COUNTS(SPFM_CAT(spfm_branch_counts_pbprb_, SPFM_TU_TAG))
+
+template int spfm_engine::pbcd_prb_dispatch<SPFM_TU_T>(int, int, double, double, double);

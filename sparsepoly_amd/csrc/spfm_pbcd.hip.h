@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void pbcd_precompute_kernel(
 
 // norms[j] = ||P[j,:]||_2 for all j (squaredl21.py:36-38, omegacs.py:64-66):
 // one wave per feature.
-__global__ __launch_bounds__(kBlock) void pbcd_norms_kernel(int d, int k,
+static __global__ __launch_bounds__(kBlock) void pbcd_norms_kernel(int d, int k,
                                                             const double* __restrict__ P,
                                                             double* __restrict__ norms) {
     const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;

@@ -374,7 +374,7 @@ __device__ __forceinline__ void pcd_sync_entry_rec(size_t i, double x, double p_
 }
 
 // rows of component ctl->s as packed records, and back (degree 3, float; pcd_prb_kernel LR = 3)
-__global__ void prb_pack3_kernel(const Ctl* __restrict__ ctl, int64_t n, size_t a_stride,
+static __global__ void prb_pack3_kernel(const Ctl* __restrict__ ctl, int64_t n, size_t a_stride,
                                  const float* __restrict__ yy, const float* __restrict__ A_all,
                                  float4* __restrict__ rec) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -388,7 +388,7 @@ __global__ void prb_pack3_kernel(const Ctl* __restrict__ ctl, int64_t n, size_t 
         rec[i] = r;
     }
 }
-__global__ void prb_unpack3_kernel(const Ctl* __restrict__ ctl, int64_t n, size_t a_stride,
+static __global__ void prb_unpack3_kernel(const Ctl* __restrict__ ctl, int64_t n, size_t a_stride,
                                    const float4* __restrict__ rec, float* __restrict__ yy,
                                    float* __restrict__ A_all) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1504,7 +1504,7 @@ __global__ __launch_bounds__(kPrbThreads) void lin_prb_kernel(
 // two hops "store becomes visible to the other CU's load".  Workgroups are dealt to the 8
 // XCDs round-robin, so partner = 1 crosses XCDs and partner = 8 stays inside XCD 0; the
 // XCC_ID register of both players is returned for confirmation.  Bounded spins.
-__global__ __launch_bounds__(kWave) void hop_pingpong_kernel(unsigned long long* words,
+static __global__ __launch_bounds__(kWave) void hop_pingpong_kernel(unsigned long long* words,
                                                              int rounds, int partner,
                                                              int* info /* [4] */) {
     const int b = blockIdx.x;
@@ -1573,7 +1573,7 @@ __device__ __forceinline__ bool prb_poll(const PrbArgs& a, const double* p,
 // number themselves through a counter (abort_flag[1]); their publishes are PLAIN stores (the
 // line stays in that XCD's L2, MI355X_MICROARCH.md store table) and the sc1 loads of the
 // sweep are served by that L2.
-__global__ __launch_bounds__(768) void exchange_probe_kernel(PrbArgs a, int rounds,
+static __global__ __launch_bounds__(768) void exchange_probe_kernel(PrbArgs a, int rounds,
                                                                      int ncols, int readers_mod,
                                                                      int xcd_mode) {
     __shared__ double quart[8 * 64 * 2];
@@ -1678,7 +1678,7 @@ __global__ __launch_bounds__(768) void exchange_probe_kernel(PrbArgs a, int roun
 // rank's position and polls the own region at position r until rank r's word arrives; bounded
 // by wall-clock ticks (wall_clock64: the 100 MHz constant counter), since the ranks enter this kernel milliseconds
 // apart.  ok[0] = 1 when every rank's word arrived.
-__global__ __launch_bounds__(kWave) void peer_probe_kernel(double* const* slabs, size_t off,
+static __global__ __launch_bounds__(kWave) void peer_probe_kernel(double* const* slabs, size_t off,
                                                            int n_ranks, int rank,
                                                            unsigned long long word,
                                                            unsigned long long max_ticks, int* ok) {
@@ -1726,14 +1726,14 @@ __global__ __launch_bounds__(kPrbThreads) void prb_stream_probe_kernel(PrbArgs a
 }
 
 // out[pos] = v[desc[pos].j]
-__global__ void gather_sched_kernel(int d, const ColDesc* __restrict__ desc,
+static __global__ void gather_sched_kernel(int d, const ColDesc* __restrict__ desc,
                                     const double* __restrict__ v, double* __restrict__ out) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos < d) out[pos] = v[desc[pos].j];
 }
 
 // viol_col[desc[pos].j] += viol_pos[pos]   (sum_viol bookkeeping of the persistent pass)
-__global__ void fold_viol_kernel(int d, const ColDesc* __restrict__ desc,
+static __global__ void fold_viol_kernel(int d, const ColDesc* __restrict__ desc,
                                  const double* __restrict__ viol_pos,
                                  double* __restrict__ viol_col) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1741,7 +1741,7 @@ __global__ void fold_viol_kernel(int d, const ColDesc* __restrict__ desc,
 }
 
 // in visiting order: out[pos] = P[s, desc[pos].j]
-__global__ void snapshot_row_kernel(const Ctl* __restrict__ ctl, const double* __restrict__ P,
+static __global__ void snapshot_row_kernel(const Ctl* __restrict__ ctl, const double* __restrict__ P,
                                     int d, const ColDesc* __restrict__ desc,
                                     double* __restrict__ out) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;

@@ -9,7 +9,7 @@ namespace spfm {
 // ------------------------------------------------------------------- predict
 
 // (k,d) -> (d,k)
-__global__ void transpose_kernel(const double* __restrict__ in, int rows, int cols,
+static __global__ void transpose_kernel(const double* __restrict__ in, int rows, int cols,
                                  double* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)rows * cols) return;

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void psgd_update_kernel(
 
 // One wave per vector: fold its NB partials in fixed order, derive the next thresholds,
 // mark the vector converged when its support size did not change.
-__global__ __launch_bounds__(kBlock) void psgd_mich_finish_kernel(
+static __global__ __launch_bounds__(kBlock) void psgd_mich_finish_kernel(
     MichState ms, double strength, const PsgdBatch* __restrict__ sched, const int* __restrict__ idx) {
     if (sched) strength = sched[idx[1]].strength;  // table-driven (graph replay)
     const int v = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
@@ -441,14 +441,14 @@ __global__ __launch_bounds__(kBlock) void psgd_mich_reduce_kernel(
 }
 
 // done <- every vector converged (read by the host between chunks of sweeps)
-__global__ __launch_bounds__(kBlock) void psgd_mich_check_kernel(MichState ms) {
+static __global__ __launch_bounds__(kBlock) void psgd_mich_check_kernel(MichState ms) {
     const bool all = mich_all_converged(ms);
     if (threadIdx.x == 0) *ms.done = all ? 1 : 0;
 }
 
 // graph replay: a fixed number of sweeps was recorded; if that was not enough for some
 // minibatch, say so (sticky) -- the host then redoes the epoch from its snapshot, eagerly
-__global__ __launch_bounds__(kBlock) void psgd_mich_verify_kernel(MichState ms, int* failed) {
+static __global__ __launch_bounds__(kBlock) void psgd_mich_verify_kernel(MichState ms, int* failed) {
     const bool all = mich_all_converged(ms);
     if (threadIdx.x == 0 && !all) *failed = 1;
 }

@@ -40,18 +40,57 @@ def canonical_csc(X):
     return Xc
 
 
-# handles created inside `co_tenancy(n)` announce that n of them train side by side on one GPU
-# (sparsepoly_amd/concurrent.py): every persistent pass keeps to 1/n of the CUs
-_CO_TENANTS = 1
-
-
-# ... and, when they all train on ONE data set, share the colouring: the first fit that asks for
-# a (mode, visiting order) computes the schedule, the others install its result
-_SHARED_SCHEDULES = None
+# Engines created inside `co_tenancy(n)` -- or by the worker threads of one
+# `fit_concurrently` call -- announce that n of them train side by side on one GPU
+# (sparsepoly_amd/concurrent.py): every persistent pass keeps to 1/n of the CUs.  The state of
+# such a call is a `Tenancy` object bound to the THREADS that take part in it (thread-local), so
+# two calls that overlap in time from different threads do not see each other's shares.
+_TLS = threading.local()
 _SHARED_LOCK = threading.Lock()
 _SCHEDULE_LRU = collections.OrderedDict()
 _SCHEDULE_LRU_SIZE = 8
 _SCHEDULE_STATS = {"hits": 0, "misses": 0}
+
+
+class Tenancy(object):
+    """What the fits of ONE concurrent call share: the number of tenants per device, the device
+    a worker thread fits on (``devices=[...]`` fan-out), and -- one data set for all -- the
+    coloured schedule and the device data image (first come computes / uploads, the others
+    install / attach)."""
+
+    def __init__(self, n, share_schedules=False, share_data=False, device=None):
+        self.n = max(1, int(n))
+        self.schedules = {} if share_schedules else None
+        self.images = {} if share_data else None  # key -> {"done": Event, "keeper": HipEngine}
+        self.device = device
+        self.lock = threading.Lock()
+
+    def on_device(self, device):
+        """The same call's state as seen by a worker bound to `device` (shared caches are per
+        device: a schedule object is portable, a device image is not)."""
+        t = Tenancy.__new__(Tenancy)
+        t.n, t.lock, t.device = self.n, self.lock, device
+        t.schedules, t.images = self.schedules, self.images
+        return t
+
+    def close(self):
+        if self.images:
+            for ent in self.images.values():
+                k = ent.get("keeper")
+                if k is not None:
+                    k.close()
+            self.images.clear()
+
+
+def current_tenancy():
+    return getattr(_TLS, "tenancy", None)
+
+
+def bind_tenancy(tenancy):
+    """Bind `tenancy` (or None) to the calling thread; returns what was bound before."""
+    old = getattr(_TLS, "tenancy", None)
+    _TLS.tenancy = tenancy
+    return old
 
 
 def structure_key(X):
@@ -71,29 +110,31 @@ def structure_key(X):
 
 
 class co_tenancy(object):
-    def __init__(self, n, share_schedules=False):
-        self.n = max(1, int(n))
-        self.share = bool(share_schedules)
+    """``with co_tenancy(n):`` -- engines created by THIS thread inside the block share the device
+    with n - 1 others (per-call state: see Tenancy)."""
+
+    def __init__(self, n, share_schedules=False, share_data=False, device=None):
+        self.tenancy = Tenancy(n, share_schedules, share_data, device)
 
     def __enter__(self):
-        global _CO_TENANTS, _SHARED_SCHEDULES
-        self._old = (_CO_TENANTS, _SHARED_SCHEDULES)
-        _CO_TENANTS = self.n
-        _SHARED_SCHEDULES = {} if self.share else None
-        return self
+        if self.tenancy.n > 1:
+            _capi.ensure_hw_queues(self.tenancy.n)
+        self._old = bind_tenancy(self.tenancy)
+        return self.tenancy
 
     def __exit__(self, *exc):
-        global _CO_TENANTS, _SHARED_SCHEDULES
-        _CO_TENANTS, _SHARED_SCHEDULES = self._old
+        bind_tenancy(self._old)
+        self.tenancy.close()
         return False
 
 
 def shared_schedule(key, compute, install):
-    """Inside ``co_tenancy(..., share_schedules=True)``: ``compute()`` (-> order, Schedule) runs
-    in the first thread that asks for ``key``; every other thread waits for it and calls
-    ``install(schedule)`` (-> order).  Outside such a context the process-wide memory of
-    schedules is consulted instead."""
-    cache = _SHARED_SCHEDULES
+    """Inside a concurrent call that shares schedules: ``compute()`` (-> order, Schedule) runs in
+    the first thread that asks for ``key``; every other thread waits for it and calls
+    ``install(schedule)`` (-> order).  Outside such a call the process-wide memory of schedules
+    is consulted instead."""
+    ten = current_tenancy()
+    cache = ten.schedules if ten is not None else None
     if cache is None:
         # one fit at a time: a small process-wide memory of coloured schedules, so that a second
         # fit on the same matrix in the same visiting order (a grid search, a restart) does not
@@ -111,7 +152,7 @@ def shared_schedule(key, compute, install):
             while len(_SCHEDULE_LRU) > _SCHEDULE_LRU_SIZE:
                 _SCHEDULE_LRU.popitem(last=False)
         return order
-    with _SHARED_LOCK:
+    with ten.lock:
         entry = cache.get(key)
         leader = entry is None
         if leader:
@@ -126,6 +167,20 @@ def shared_schedule(key, compute, install):
     if entry["sched"] is None:
         return compute()[0]
     return install(entry["sched"])
+
+
+def hw_queue_report():
+    """How many hardware queues the HIP runtime of this process maps streams onto, as far as the
+    environment tells (GPU_MAX_HW_QUEUES is read when the runtime initialises; default 4).  More
+    concurrent fits than queues share queues, and two persistent passes on one queue run one
+    after the other (independent fits side by side)."""
+    import os
+
+    val = os.environ.get("GPU_MAX_HW_QUEUES")
+    return {"GPU_MAX_HW_QUEUES": int(val) if val and val.isdigit() else None,
+            "runtime_default": 4,
+            "set_by_package": bool(_capi.QUEUES_SET_BY_PACKAGE),
+            "hip_initialised_before_import": bool(_capi.HIP_INITIALISED_BEFORE_IMPORT)}
 
 
 class HipEngine(object):
@@ -143,8 +198,11 @@ class HipEngine(object):
         self.n = self.d = self.k = self.n_orders = None
         self.order = None
         self.n_batches = None
-        if _CO_TENANTS > 1:
-            self.set_option("co_tenants", _CO_TENANTS)
+        self.device = int(device)
+        ten = current_tenancy()
+        self.tenants = ten.n if ten is not None else 1
+        if self.tenants > 1:
+            self.set_option("co_tenants", self.tenants)
 
     def close(self):
         if getattr(self, "_h", None):

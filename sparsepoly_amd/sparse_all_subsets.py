@@ -57,8 +57,9 @@ class _BaseSparseAllSubsets(BaseSparsePoly, metaclass=ABCMeta):
         self.device = device
 
     def _new_engine(self):
-        dev = int(os.environ.get("LOCAL_RANK", "0")) if self.device is None else self.device
-        return HipEngine(device=dev, precision=self.precision)
+        from .sparse_factorization_machines import _fit_device
+
+        return HipEngine(device=_fit_device(self), precision=self.precision)
 
     def _set_schedule(self, engine, indices_feature):
         if isinstance(self.schedule, Schedule):

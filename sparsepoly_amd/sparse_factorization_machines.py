@@ -55,6 +55,15 @@ def _default_device():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def _fit_device(est):
+    """The device a fit runs on: the worker's device inside a ``fit_concurrently(devices=...)``
+    call, else the estimator's ``device``, else LOCAL_RANK."""
+    ten = _engine_mod.current_tenancy()
+    if ten is not None and ten.device is not None:
+        return int(ten.device)
+    return _default_device() if est.device is None else est.device
+
+
 def _fingerprint(Xc, y):
     """Cheap content hash of the training set (structure, values, targets): decides
     whether a warm-started fit may reuse the device-resident data of the previous one."""
@@ -165,8 +174,7 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         return self.alpha, self.beta, self.gamma
 
     def _new_engine(self):
-        dev = _default_device() if self.device is None else self.device
-        return HipEngine(device=dev, precision=self.precision)
+        return HipEngine(device=_fit_device(self), precision=self.precision)
 
     def _set_schedule(self, engine, indices_feature, conflict_csc):
         """Fix the visiting order of the next epochs (the reference passes
@@ -192,8 +200,12 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
             # (sparsepoly_amd/concurrent.py) compute it once, and so do later fits of this process
             mode = self.schedule
             jf = np.ascontiguousarray(indices_feature, dtype=np.int32)
+            # (the step-width policy of spfm_set_schedule also looks at the CU share of a
+            # co-tenant and at the device: both are part of the key, so that a colouring made for
+            # a quarter of the CUs is never installed by a solo fit, or the reverse)
             key = (self._struct_key, mode, hash(jf.tobytes()), self.solver, self.loss,
-                   self.precision, self.degree, self.fit_lower, self.fit_linear)
+                   self.precision, self.degree, self.fit_lower, self.fit_linear,
+                   getattr(engine, "tenants", 1), getattr(engine, "device", 0))
 
             def compute():
                 o = engine.set_schedule(mode, jf, None)
@@ -429,7 +441,7 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         engine = None
         if self.warm_start and not self.distributed:
             key = (_fingerprint(X if csr_direct else Xc, y), "csr" if csr_direct else "csc",
-                   self.precision, _default_device() if self.device is None else self.device)
+                   self.precision, _fit_device(self))
             cached = getattr(self, "_device_session", None)
             self._device_session = None
             if cached is not None:

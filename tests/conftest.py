@@ -11,6 +11,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the test process starts concurrent fits long after its first GPU call: configure the HIP
+# runtime's hardware queues while that still works (sparsepoly_amd/_capi.py ensure_hw_queues)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

@@ -25,8 +25,12 @@ def test_argument_checks_come_before_any_device_call():
         fit_concurrently([est], [X, X], [y, y])
     with pytest.raises(ValueError, match="max_concurrent"):
         fit_concurrently([est], X, y, max_concurrent=0)
-    with pytest.raises(ValueError, match="one GPU"):
+    with pytest.raises(ValueError, match="independent fits"):
         fit_concurrently([SparseFactorizationMachineRegressor(distributed=True)], X, y)
+    with pytest.raises(ValueError, match="distinct device ids"):
+        fit_concurrently([est], X, y, devices=[0, 0])
+    with pytest.raises(ValueError, match="distinct device ids"):
+        fit_concurrently([est], X, y, devices=[])
     assert fit_concurrently([], X, y) == []
     assert hasattr(est, "fit_path")
 
@@ -34,23 +38,79 @@ def test_argument_checks_come_before_any_device_call():
 def test_co_tenancy_context_nests_and_restores():
     from sparsepoly_amd import engine as E
 
-    assert E._CO_TENANTS == 1
+    def tenants():
+        t = E.current_tenancy()
+        return 1 if t is None else t.n
+
+    assert tenants() == 1
     with E.co_tenancy(4):
-        assert E._CO_TENANTS == 4
+        assert tenants() == 4
         with E.co_tenancy(2):
-            assert E._CO_TENANTS == 2
-        assert E._CO_TENANTS == 4
-    assert E._CO_TENANTS == 1
+            assert tenants() == 2
+        assert tenants() == 4
+    assert tenants() == 1
     with pytest.raises(RuntimeError):
         with E.co_tenancy(3):
             raise RuntimeError("x")
-    assert E._CO_TENANTS == 1
+    assert tenants() == 1
 
 
-def test_hardware_queue_default_is_set_before_the_runtime_starts():
-    import sparsepoly_amd._capi  # noqa: F401
+def test_overlapping_concurrent_calls_from_different_threads_keep_their_own_shares():
+    """Two `co_tenancy` blocks open at the same time in two threads: each thread sees its own
+    tenant count (the state is per call, bound to the threads that take part), and a thread that
+    takes part in neither sees none."""
+    import threading
 
-    assert int(os.environ["GPU_MAX_HW_QUEUES"]) >= 4
+    from sparsepoly_amd import engine as E
+
+    seen = {}
+    inside = threading.Barrier(2)
+
+    def call(name, n):
+        with E.co_tenancy(n):
+            inside.wait(5)            # both blocks are open now
+            seen[name] = E.current_tenancy().n
+            inside.wait(5)
+        seen[name + "_after"] = E.current_tenancy()
+
+    a = threading.Thread(target=call, args=("a", 4))
+    b = threading.Thread(target=call, args=("b", 2))
+    a.start()
+    b.start()
+    a.join()
+    b.join()
+    assert seen == {"a": 4, "b": 2, "a_after": None, "b_after": None}
+    assert E.current_tenancy() is None
+    # a worker of a fan-out sees its device, the shared caches are the call's
+    root = E.Tenancy(4, share_schedules=True, share_data=True)
+    w = root.on_device(3)
+    assert (w.n, w.device) == (4, 3) and w.schedules is root.schedules and w.images is root.images
+
+
+def test_hardware_queues_are_configured_on_demand_not_at_import(monkeypatch):
+    """Importing the package leaves GPU_MAX_HW_QUEUES alone; asking for concurrent fits exports it
+    while the HIP runtime is not up yet, and warns -- instead of silently running two fits per
+    queue -- when it is too late."""
+    import warnings
+
+    from sparsepoly_amd import _capi
+
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.setattr(_capi, "hip_initialised", lambda: False)
+    assert _capi.ensure_hw_queues(4) == 8 and os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
+    assert _capi.ensure_hw_queues(4) == 16 and os.environ["GPU_MAX_HW_QUEUES"] == "16"
+    # runtime already initialised by the host program (any PyTorch user) with the default 4
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.setattr(_capi, "hip_initialised", lambda: True)
+    with pytest.warns(RuntimeWarning, match="hardware queues"):
+        assert _capi.ensure_hw_queues(4) == 4
+    assert "GPU_MAX_HW_QUEUES" not in os.environ
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert _capi.ensure_hw_queues(1) == 4          # a single fit needs no warning
+        monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+        assert _capi.ensure_hw_queues(4) == 8          # enough queues: quiet
 
 
 def test_shared_schedule_is_computed_once_and_installed_by_the_others():
@@ -76,9 +136,12 @@ def test_shared_schedule_is_computed_once_and_installed_by_the_others():
     assert E.shared_schedule(("k",), compute, install) == "order"
     assert calls == {"compute": 1, "install": 0}
     out = []
-    with E.co_tenancy(4, share_schedules=True):
-        th = [threading.Thread(target=lambda: out.append(E.shared_schedule(("k",), compute, install)))
-              for _ in range(4)]
+    with E.co_tenancy(4, share_schedules=True) as ten:
+        def member():  # a worker thread of the call: bound to its state
+            E.bind_tenancy(ten)
+            out.append(E.shared_schedule(("k",), compute, install))
+
+        th = [threading.Thread(target=member) for _ in range(4)]
         for t in th:
             t.start()
         for t in th:
@@ -86,7 +149,7 @@ def test_shared_schedule_is_computed_once_and_installed_by_the_others():
         assert E.shared_schedule(("other",), compute, install) == "order"   # another key: computed
     assert out == ["order"] * 4
     assert calls == {"compute": 3, "install": 3}
-    assert E._SHARED_SCHEDULES is None
+    assert E.current_tenancy() is None
 
 
 def test_shared_schedule_leader_failure_lets_the_followers_compute():
@@ -106,13 +169,17 @@ def test_shared_schedule_leader_failure_lets_the_followers_compute():
 
     res = []
 
+    box = {}
+
     def run():
+        E.bind_tenancy(box["ten"])
         try:
             res.append(E.shared_schedule(("k",), compute, lambda s: "installed"))
         except RuntimeError:
             res.append("error")
 
-    with E.co_tenancy(2, share_schedules=True):
+    with E.co_tenancy(2, share_schedules=True) as ten:
+        box["ten"] = ten
         a = threading.Thread(target=run)
         a.start()
         import time

@@ -225,6 +225,61 @@ def test_fullsize_reference_order_merged_steps_vs_oracle(oracle, config2_matrix)
     np.testing.assert_allclose(a["yp"], ypo, rtol=0, atol=2e-4 * max(1.0, np.abs(ypo).max()))
 
 
+@pytest.mark.parametrize("schedule", ["colored", "exact"])
+def test_fullsize_config3_vs_oracle(oracle, config2_matrix, schedule):
+    """BASELINE configs[2] at full size (1M x 100k, degree 3, k = 16, omegati, pcd, the default
+    fit_lower='explicit': sparse_factorization_machines.py:207-243 with omegati.py:62-104): one
+    cd_linear epoch, one component pass of the explicit degree-2 order on P_[1], two component
+    passes of the degree-3 order on P_[0], f32 storage, against the oracle in the same order --
+    the coloured one, and the reference's own (merged steps with replayed conflict rows, DESIGN.md
+    3f).  The degree-3 passes must have run on the packed 16-byte row records with the rows in
+    global memory (they do not fit LDS at this size).  Tolerance as for config 2."""
+    Xc, y = config2_matrix
+    n, d = Xc.shape
+    k = 16
+    # (omegati's strength is gamma * e_2(|p_s|) at degree 3 -- a sum over all column PAIRS, ~50 at
+    # d = 100k with |p| ~ 0.01: gamma = 1e-6, as bench.py's config 3, keeps ~60 % of P non-zero;
+    # 1e-4 thresholds every coordinate away in the first pass)
+    beta, gamma = 10.0, 1e-6
+    eng, order, P0 = _engine(Xc, y, k, 3, "pcd", "omegati", "f32", schedule)
+    assert P0.shape == (2, k, d)
+    y0 = eng.get_y_pred()
+    ic2, ic3 = np.arange(1, dtype=np.int32), np.arange(2, dtype=np.int32)
+    v_lin = eng.cd_linear_epoch(1.0)
+    v2 = eng.pcd_epoch(1, 2, beta, gamma, 1.0, ic2)
+    v3 = eng.pcd_epoch(0, 3, beta, gamma, 1.0, ic3)
+    assert eng.get_option("prb_pack_active") == 1 and eng.get_option("prb_lds_active") == 0
+    assert eng.get_option("persistent_fallbacks") == 0
+    if schedule == "exact":
+        np.testing.assert_array_equal(order, np.arange(d))
+        assert 3_000 < eng.get_option("relax_steps") < 0.25 * eng.n_batches
+    P, w = eng.get_params()
+    yp = eng.get_y_pred()
+    eng.close()
+    ds = oracle.CSC(Xc)
+    regc = oracle.Regularizer("omegati")
+    regc.init_cache_pcd(3, d, k)
+    wo = np.zeros(d)
+    ypo = np.ascontiguousarray(y0.copy())
+    cn = np.asarray(Xc.multiply(Xc).sum(axis=0)).ravel()
+    jf = np.ascontiguousarray(order)
+    lams = np.ones(k)
+    A = np.zeros((n, 4))
+    vo_lin = oracle.cd_linear_epoch(wo, ds, y, ypo, cn, 1.0, "squared", jf)
+    P_low = np.ascontiguousarray(P0[1].copy())
+    P_top = np.ascontiguousarray(P0[0].copy())
+    vo2 = oracle.pcd_epoch(P_low, ds, y, ypo, lams, 2, beta, gamma, 1.0, regc, "squared", A, ic2, jf)
+    vo3 = oracle.pcd_epoch(P_top, ds, y, ypo, lams, 3, beta, gamma, 1.0, regc, "squared", A, ic3, jf)
+    assert (P_top[:2] != 0).mean() > 0.05  # the model did not collapse
+    np.testing.assert_allclose(v_lin, vo_lin, rtol=1e-5)
+    np.testing.assert_allclose(v2, vo2, rtol=1e-5)
+    np.testing.assert_allclose(v3, vo3, rtol=1e-5)
+    np.testing.assert_allclose(w, wo, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(P[1], P_low, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(P[0], P_top, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(yp, ypo, rtol=0, atol=2e-4 * max(1.0, np.abs(ypo).max()))
+
+
 def test_estimator_augment_and_warm_start(oracle):
     """fit_lower='augment' (dummy columns, sparse_factorization_machines.py:86-92) and
     warm_start=True (P_, w_, lams_ reused, y_pred recomputed: :380-391,408)."""

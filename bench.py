@@ -265,6 +265,12 @@ class Bench(object):
         # rehearsal on a one-GPU box: SPFM_DEVICE=0 SPFM_COMM=shm runs all ranks on device 0 with
         # the engine's host shared-memory exchange instead of RCCL (see spfm_comm_init_shm)
         self.local_rank = int(os.environ.get("SPFM_DEVICE", local_rank))
+        if self.world == 1:
+            # the concurrent-fits extra starts four fits side by side: the HIP runtime's hardware
+            # queues must be configured before the first GPU call of the process
+            from sparsepoly_amd import _capi
+
+            _capi.ensure_hw_queues(4)
         import torch
 
         self.torch = torch

@@ -286,8 +286,8 @@ int spfm_set_use_graph(spfm_handle h, int on);
  * added; "wide" / "wide_min_cols" / "max_batch" also the coloured schedule built next (never an
  * order the caller passed as 'exact'). */
 int spfm_set_option(spfm_handle h, const char* key, int value);
-/* Round 3: "pbprb_owners" (dedicated owner workgroups of the persistent pbcd pass, in front of
- * the row workgroups in the grid; default 0), "relax" (0/1, default 1: a schedule of tiny steps --
+/* Round 3: "pbprb_owners" (dedicated owner workgroups of the persistent pbcd pass: removed in
+ * round 4, only 0 is accepted), "relax" (0/1, default 1: a schedule of tiny steps --
  * the reference order, fewer than 12 columns per step on average -- is run by the degree-2 pcd
  * pass as merged steps of ~20 consecutive columns whose shared rows the chains replay in order;
  * same result as the sequential sweep), "prb_pack" (0/1, default 1: degree-3 passes with their

@@ -43,8 +43,9 @@ void build_wide_stream(int64_t, const int64_t*, const int32_t*, const std::vecto
                        const std::vector<int32_t>&, int, std::vector<int32_t>&,
                        std::vector<int32_t>&, std::vector<int32_t>&, std::vector<uint8_t>&);
 void build_pb_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
-                     const std::vector<int32_t>&, int, int, std::vector<int32_t>&,
-                     std::vector<int32_t>&, std::vector<uint8_t>&);
+                     const std::vector<int32_t>&, int, int, int, std::vector<int32_t>&,
+                     std::vector<int32_t>&, std::vector<uint8_t>&, std::vector<uint16_t>&,
+                     std::vector<uint8_t>&);
 void build_rowblock_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
                            const std::vector<int32_t>&, int, int, std::vector<int32_t>&,
                            std::vector<int32_t>&, std::vector<uint32_t>&, const uint8_t*);
@@ -232,13 +233,13 @@ struct spfm_engine {
     // stream when that differs from the pcd / cd_linear pass's
     bool pb_persistent = true;
     int pbprb_G = 256;
-    int pbprb_owners = 0;   // dedicated owner workgroups (measured, no gain; off)
-    int pb_GO = 0;          // what the installed stream was built for
     int probe_xcd = 0, probe_lds = 60 * 1024;  // diagnostics (spfm_debug_exchange_cost)
     bool pb_stream_ready = false;
-    int pb_stream_G = 0, pb_stream_NG = 0;
+    int pb_stream_G = 0, pb_stream_NG = 0, pb_stream_ER = 0;
+    DevBuf pb_fwd, pb_drain;  // forwarding table of the persistent pbcd pass (efwd / edrain)
     DevBuf pb_sp, pb_erow, pb_eval, pb_meta, pb_slabA, pb_slabB, pb_slabC, pb_stamps, pb_rec;
     bool pb_stamp_on = false;
+    bool pb_early = false;  // early phase of the persistent pbcd pass (measured slower; off)
     int pbprb_active = 0;  // what the last pbcd epoch used
     int pb_dbg = 0;
     DevBuf pb_dbgbuf;
@@ -636,7 +637,7 @@ struct spfm_engine {
                                    const std::vector<uint8_t>& meta) const;
 
     template <typename T>
-    int ensure_pb_stream(int NG);
+    int ensure_pb_stream(int NG, int ER);
 
     template <typename T, int M, int L>
     int pbcd_prb_l(int order_idx, double beta, double gamma, double eta);

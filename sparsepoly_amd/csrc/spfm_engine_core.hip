@@ -1512,13 +1512,15 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->wide_stamp_on = value != 0;
     } else if (k == "pbprb_stamps") {
         h->pb_stamp_on = value != 0;
-    } else if (k == "pbprb_owners") {  // dedicated owner workgroups (default 0)
-        if (value < 0 || value > 64) {
-            h->err = "pbprb_owners must be in 0..64";
-            return SPFM_ERR_INVALID;
+    } else if (k == "pbprb_early") {  // next step's unshared-row sums in the collect wait
+        h->pb_early = value != 0;
+    } else if (k == "pbprb_owners") {
+        // round 3's dedicated owner workgroups: measured, no gain, removed in round 4 (their
+        // pacing rule does not survive the early publish of the partial vectors)
+        if (value != 0) {
+            h->err = "pbprb_owners: dedicated owner workgroups were removed (only 0 is accepted)";
+            return SPFM_ERR_UNSUPPORTED;
         }
-        h->pbprb_owners = value;
-        h->pb_stream_ready = false;
     } else if (k == "pbprb_groups") {
         if (value < 1) {
             h->err = "pbprb_groups must be >= 1";
@@ -1567,7 +1569,7 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "wide_lds_active") *value = h->wide_lr_active;
     else if (k == "pbprb_groups") *value = h->pbprb_G;
     else if (k == "pcdw_groups") *value = h->wide_ready ? h->wide_G : h->pcdw_G;  // 0 = not chosen yet
-    else if (k == "pbprb_owners") *value = h->pb_GO;
+    else if (k == "pbprb_owners") *value = 0;
     else if (k == "pbprb_active") *value = h->pbprb_active;
     else if (k == "persistent_active")
         *value = h->have_schedule && (h->prb_usable() || h->wide_usable());
@@ -1613,7 +1615,7 @@ int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap) {
         return nv;
     }
     if (h->pb_stamp_on && h->pb_stream_ready && out) {  // persistent pbcd pass's timers
-        const int nv = 16 * (h->pb_stream_G + h->pb_GO);
+        const int nv = 16 * h->pb_stream_G;
         if (cap < nv) return SPFM_ERR_INVALID;
         if (hipMemcpy(out, h->pb_stamps.p, sizeof(long long) * (size_t)nv,
                       hipMemcpyDeviceToHost) != hipSuccess)

@@ -93,7 +93,7 @@ const char* spfm_engine::validate_pb_stream(int G, int NG, const std::vector<int
                     const int64_t row = h_cidx[(size_t)pos];
                     if (row < 0 || row >= n) return "row index out of range";
                     if (row / rows_per != g) return "entry outside its workgroup's row block";
-                    const int slot = meta[(size_t)e] & 0x7f;
+                    const int slot = meta[(size_t)e] & 0x3f;  // (0x80 / 0x40: shared-row flags)
                     if (slot >= qm) return "slot index >= slots per group";
                     if (slot < prev_slot) return "a group's entries are not sorted by slot";
                     prev_slot = slot;

@@ -70,16 +70,20 @@ namespace spfm {
 
 struct PbPrbArgs {
     int G;                 // row workgroups (each owns a block of rows)
-    int GO;                // dedicated owner workgroups in front of them in the grid (0: the row
-                           // workgroups own the slots themselves)
     int nb;                // steps in the sweep
     const int32_t* bptr;   // [nb+1]
     const int32_t* jsched; // [d] column ids in visiting order
     const int32_t* gsp;    // [G][nb][NG+1] group boundaries into the entry stream
     const int32_t* erow;   // entry rows, sorted by (workgroup, step, group, slot, row)
     const uint8_t* emeta;  // slot index inside the group | 0x80 (row touched by previous step)
+                           // | 0x40 (... and its new record arrives through LDS, see efwd)
+    const uint16_t* efwd;  // 0x100 | group << 4 | entry: where the NEXT step has this entry's row
+                           // in its LDS row buffer (the scatter writes the new record there too);
+                           // 0: the next step does not touch the row (or not on its fast path)
+    const uint8_t* edrain; // [G][nb] 1: the step's end barrier must drain the scatter stores (the
+                           // next step reads one of its rows from global memory)
     double* slabA;         // [2][64][G][L] partial vectors
-    double* slabB;         // [2][64][L]    published block updates
+    double* slabB;         // [3][64][L]    published block updates (triple-buffered by step)
     int rows_per, n_rows;
     unsigned* abort_flag;
     unsigned spin_max;     // polls of one wait before the pass gives up (default 2^21)
@@ -91,6 +95,14 @@ struct PbPrbArgs {
 };
 
 constexpr int kPbPrbThreads = 512;
+
+// entries of a slot group whose rows are staged in LDS (64 KB for the two row buffers); the
+// host's stream builder needs it for the forwarding table (efwd / edrain)
+template <typename T, int M>
+constexpr int pbprb_er() {
+    constexpr int ER0 = (int)(16 * 4 / sizeof(T)) / Kind<M>::AS;
+    return ER0 >= 8 ? (ER0 / 8) * 8 : (ER0 >= 4 ? 4 : (ER0 >= 2 ? 2 : 1));
+}
 
 __device__ __forceinline__ bool pbprb_poll_fail(const PbPrbArgs& a, unsigned& spins) {
     if ((++spins & 63u) == 0) {
@@ -325,209 +337,38 @@ __global__ void pbprb_unpack_kernel(int64_t n, const T* __restrict__ R, T* __res
     if (i < n) yy[2 * (size_t)i] = R[(size_t)i * AS * L + (L - 2)];
 }
 
-// Dedicated OWNER workgroup o of the persistent pbcd pass (round 3; grid = GO owners + G row
-// workgroups).  With the slots owned by row workgroups, the owner's poll, reduction and step sit
-// on the critical path of a workgroup that also has rows to sum and scatter, and every other
-// workgroup waits for it; an owner without rows starts polling at once, and the row workgroups
-// issue their prefetch while the exchange is in flight.  Owner o serves the slots o, o + GO, ...
-// (< 64): per step and slot it sums the G partial vectors in fixed order, adds the other GPUs'
-// vectors, takes pbcd._update's step (pbcd.py:68-78) with the cache-independent part of
-// prox_bcd and publishes the result -- exactly the work of phase 2 below.
-template <typename T, int L, bool STAMP>
-__device__ __forceinline__ void pbprb_owner_role(const PbPrbArgs& a, int o, const double* __restrict__ P,
-                                                 int k, const double* __restrict__ lams, int reg,
-                                                 double mu, double beta, double gamma, double eta,
-                                                 double* lds) {
-    constexpr int NG = kPbPrbThreads / L;
-    double* sh_red = lds;  // [2][NG][L]
-    int* sh_ok = reinterpret_cast<int*>(lds + 2 * NG * L);
-    const int tid = threadIdx.x, lane = tid % L, grp = tid / L;
-    const bool kl = lane < k;
-    const double lam = kl ? lams[lane] : 0.0;
-    if (tid == 0) *sh_ok = 1;
-    __syncthreads();
-    long long acc[4] = {0, 0, 0, 0};
-    long long tprev = STAMP ? clock64() : 0;
-    int c0 = a.bptr[0], c1 = a.bptr[min(1, a.nb)];
-    int c2 = a.bptr[min(2, a.nb)], c3 = a.bptr[min(3, a.nb)];
-    int buf = 0;
-    bool alive = true;
-    for (int b = 0; b < a.nb && alive; ++b) {
-        const int ncols = c1 - c0;
-        const int c4 = a.bptr[min(b + 4, a.nb)];
-        const int nw = max(ncols, c3 - c2);  // slots (re)written this step, see the row role
-        const unsigned long long tag = prb_tag(b);
-        const int par = b & 1;
-        const double* slabA = a.slabA + (size_t)par * 64 * a.G * L;
-        double* slabB = a.slabB + (size_t)par * 64 * L;
-        if (o >= ncols) {
-            // No slot of this step to wait for -- but an owner must never run ahead of the row
-            // workgroups: its zero-rewrites below would clobber slabB words that a step still in
-            // progress has to read, and the tags repeat every six steps.  Pace on the step
-            // itself: the slot-0 vector of one row workgroup (slot 0 is written at every step).
-            // Any one will do: a row workgroup that has published step b has collected step
-            // b-1, which needed every row workgroup's partials of step b-1, i.e. everybody is
-            // done with step b-2 -- the last user of this parity's buffers.
-            const double* pace = slabA + (size_t)(o % a.G) * L + lane;
-            unsigned spins = 0;
-            while ((prb_load_granule(pace) & 3ull) != tag) {
-                if (pbprb_poll_fail(a, spins)) {
-                    *sh_ok = 0;
-                    break;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (!*sh_ok) {
-                alive = false;
-                break;
-            }
-        }
-        for (int q = o; q < nw; q += a.GO) {
-            if (q >= ncols) {
-                // slot unused in this step but read at the buffer's next use: rewritten now
-                if (grp == 0) {
-                    prb_store_granule(slabB + (size_t)q * L + lane, 0.0, tag);
-                    if (a.n_ranks > 1) {
-                        const size_t off = ((size_t)par * 64 + q) * a.n_ranks * L;
-                        for (int rr = 0; rr < a.n_ranks; ++rr)
-                            prb_store_granule_sys(a.slabC[rr] + off + (size_t)a.rank * L + lane, 0.0,
-                                                  tag);
-                    }
-                }
-                continue;
-            }
-            // the column's block (group 0's lanes), in flight during the poll
-            const int j = a.jsched[c0 + q];
-            const double pold = (grp == 0 && kl) ? P[(size_t)j * k + lane] : 0.0;
-            double* red = sh_red + (size_t)buf * NG * L;
-            buf ^= 1;
-            {   // group `grp` sums the source workgroups grp, grp + NG, ... in that order
-                double tot = 0.0;
-                constexpr int GU = (L == 32) ? 16 : 8;
-                for (int s0 = grp; s0 < a.G; s0 += NG * GU) {
-                    unsigned long long t[GU];
-                    unsigned spins = 0;
-                    bool ok = true;
-                    for (;;) {
-                        bool all = true;
-#pragma unroll
-                        for (int u = 0; u < GU; ++u) {
-                            const int src = s0 + u * NG;
-                            t[u] = (src < a.G)
-                                       ? prb_load_granule(slabA + ((size_t)q * a.G + src) * L + lane)
-                                       : tag;
-                            all = all && ((t[u] & 3ull) == tag);
-                        }
-                        if (all) break;
-                        if (pbprb_poll_fail(a, spins)) {
-                            ok = false;
-                            break;
-                        }
-                    }
-                    if (!ok) {
-                        *sh_ok = 0;
-                        break;
-                    }
-#pragma unroll
-                    for (int u = 0; u < GU; ++u)
-                        if (s0 + u * NG < a.G)
-                            tot += __longlong_as_double((long long)(t[u] & ~3ull));
-                }
-                red[grp * L + lane] = tot;
-            }
-            if constexpr (STAMP) {
-                if (tid == 0) {
-                    const long long tn = clock64();
-                    acc[0] += tn - tprev;
-                    tprev = tn;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // part sums in LDS
-            if (!*sh_ok) {
-                alive = false;
-                break;
-            }
-            if (grp == 0) {
-                double tot = red[lane];
-#pragma unroll
-                for (int w = 1; w < NG; ++w) tot += red[w * L + lane];
-                if (a.n_ranks > 1) {
-                    // one xGMI hop: this GPU's vector into every GPU's slabC[slot][rank], then
-                    // the n_ranks vectors of the own slabC summed in rank order
-                    const size_t off = ((size_t)par * 64 + q) * a.n_ranks * L;
-                    for (int rr = 0; rr < a.n_ranks; ++rr)
-                        prb_store_granule_sys(a.slabC[rr] + off + (size_t)a.rank * L + lane, tot, tag);
-                    double gt = 0.0;
-                    bool ok = true;
-                    const double* mine = a.slabC[a.rank];
-                    for (int rr = 0; rr < a.n_ranks && ok; ++rr) {
-                        unsigned long long t;
-                        unsigned spins = 0;
-                        for (;;) {
-                            t = prb_load_granule_sys(mine + off + (size_t)rr * L + lane);
-                            if ((t & 3ull) == tag) break;
-                            if (pbprb_poll_fail(a, spins)) {
-                                ok = false;
-                                break;
-                            }
-                        }
-                        gt += __longlong_as_double((long long)(t & ~3ull));
-                    }
-                    if (!ok) *sh_ok = 0;  // (seen at the next barrier; the abort word is set)
-                    tot = gt;
-                }
-                // pbcd._update (pbcd.py:68-79) up to the cache-dependent part of prox_bcd
-                const double hsum = pb_bcast<L>(tot, L - 2, grp);  // grp == 0 here
-                double inv = hsum * mu;
-                inv += beta;
-                const double st0 = eta * gamma / inv;
-                double v = 0.0;
-                if (kl) {
-                    double gr = tot * lam;
-                    gr += beta * pold;
-                    gr /= inv;
-                    v = pold - eta * gr;
-                    if (reg == REG_L1) {  // l1.py:44-45, element-wise
-                        const double sg = (v > 0) ? 1.0 : ((v < 0) ? -1.0 : 0.0);
-                        const double m = fabs(v) - st0;
-                        v = sg * (m > 0.0 ? m : 0.0);
-                    } else if (reg == REG_SQL21) {
-                        v /= 1 + 2 * st0;  // squaredl21.py:46
-                    }
-                }
-                const double l2 = sqrt(pb_group_allsum<L>(v * v));
-                const double outv = (lane == L - 2) ? l2 : ((lane == L - 1) ? st0 : v);
-                prb_store_granule(slabB + (size_t)q * L + lane, outv, tag);
-            }
-            if constexpr (STAMP) {
-                if (tid == 0) {
-                    const long long tn = clock64();
-                    acc[1] += tn - tprev;
-                    tprev = tn;
-                }
-            }
-        }
-        c0 = c1;
-        c1 = c2;
-        c2 = c3;
-        c3 = c4;
-    }
-    if (STAMP && a.stamps != nullptr && tid == 0) {
-        a.stamps[(size_t)(a.G + o) * 16 + 2] = acc[0];  // owner poll
-        a.stamps[(size_t)(a.G + o) * 16 + 3] = acc[1];  // reduce + step + publish
-    }
-}
-
 template <typename T>
 struct PbESet {  // lane u <-> entry e0 + u of the group (u < min(cnt, L))
     int e0, cnt;
-    int row, meta;
+    int row, meta;  // meta: emeta | efwd << 8
     T x;
 };
 
-// DOWN = true: the grid's first a.GO workgroups are dedicated owners (pbprb_owner_role), the
-// row workgroups behind them skip phase 2 altogether.
-template <typename T, int M, int L, bool STAMP = false, bool DOWN = false>
+// tag of a slabB word: the published block updates are TRIPLE-buffered by step (see "early
+// publish" below), consecutive uses of one buffer (b, b+3, b+6) carry different tags
+__device__ __forceinline__ unsigned long long pb_tag3(int b) {
+    return (unsigned long long)(((b / 3) % 3) + 1);
+}
+
+// EARLY (round 4; L = 32, i.e. k <= 30: LDS has room for the parked accumulators).  A step's
+// critical path used to be: scatter -> rows this step shares with the last one -> partial sums of
+// ALL entries -> publish -> owners -> collect -> chain -> scatter, with every workgroup idle in
+// the collect poll for ~3.5 us.  98 % of a step's entries sit on rows the previous step does not
+// touch: their rows are staged in LDS one step ahead anyway, so their part of the sums
+// (pbcd.py:56-67) is formed DURING the previous step's collect wait ("early phase"), and
+//   * a slot group none of whose entries is on a shared row publishes its vectors right then --
+//     one step ahead, off the critical path, and spread out in time instead of one burst of 2 MB;
+//   * a group that does have shared rows (or more entries than LDS row slots) parks its
+//     accumulators in LDS, adds the shared rows after the scatter and publishes then.
+// Early publishing lets a workgroup run one step further ahead of the slowest one than before
+// (it publishes step b+1 before it has collected step b), so slabB -- written by owners, read
+// by everybody -- is triple-buffered: the buffer of step b+1 was last used by step b-2, which
+// every workgroup has collected once all partial vectors of step b+1's slot are in.  slabA (and
+// the cross-GPU slabC) stay double-buffered: a workgroup writes step b+1's partial vectors
+// after it has collected step b-1, by when the owners are done with that parity's buffer.
+// The sums are formed in a fixed order (unshared rows in row order, then shared rows in row
+// order): deterministic, association differs from the row-order sum by rounding only.
+template <typename T, int M, int L, bool STAMP = false, bool EARLY = false>
 __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     PbPrbArgs a, const T* __restrict__ eval, T* __restrict__ R /* packed row records */,
     double* __restrict__ P /* (d,k) */, int k, int d, const double* __restrict__ lams, int loss,
@@ -537,28 +378,23 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     constexpr int QM = 64 / NG;            // slots per group (<= 64 slots per step)
     constexpr int AS = Kind<M>::AS;
     constexpr int NW = kPbPrbThreads / 64;  // waves
-    // entries of a group whose rows are staged in LDS: 64 KB for the two row buffers
-    constexpr int ER0 = (int)(16 * 4 / sizeof(T)) / AS;
-    constexpr int ER = ER0 >= 8 ? (ER0 / 8) * 8 : (ER0 >= 4 ? 4 : (ER0 >= 2 ? 2 : 1));
+    static_assert(!EARLY || L == 32, "the early phase parks its accumulators in LDS: k <= 30 only");
+    constexpr int ER = pbprb_er<T, M>();
+    static_assert(ER <= 16 && NG <= 16, "efwd packs (group, entry) into 4 + 4 bits");
     using ESet = PbESet<T>;
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
-    if constexpr (DOWN) {
-        if ((int)blockIdx.x < a.GO) {
-            pbprb_owner_role<T, L, STAMP>(a, (int)blockIdx.x, P, k, lams, reg, mu, beta, gamma, eta,
-                                          dyn_lds);
-            return;
-        }
-    }
     double* sh_red = dyn_lds;                    // [2][NG][L] owner part sums
     double* sh_pt = dyn_lds + 2 * NG * L;        // [64][L] published vectors of the step
     double* sh_scal = sh_pt + 64 * L;            // [64][4] l2, st0, f, -
-    double2* sh_xd = reinterpret_cast<double2*>(sh_scal + 256);  // [NG][L] (x, dloss) per entry
-    double* sh_cache = sh_scal + 256 + 2 * NG * L;  // [2][kMaxDegree+2] regularizer cache, dcache
+    double2* sh_xd = reinterpret_cast<double2*>(sh_scal + 256);  // [2][NG][L] (x, dloss) per entry
+    double* sh_cache = sh_scal + 256 + 4 * NG * L;  // [2][kMaxDegree+2] regularizer cache, dcache
     int2* sh_rm = reinterpret_cast<int2*>(sh_cache + 2 * (kMaxDegree + 2));  // [2][NG][L] (row, meta)
     int* sh_ok = reinterpret_cast<int*>(sh_rm + 2 * NG * L);
-    // row buffers [2][NW][ER][AS][64]: a wave's slice is written lane-linearly by LDS-DMA
-    T* sh_rows = reinterpret_cast<T*>(sh_ok + 4);
-    const int g = DOWN ? (int)blockIdx.x - a.GO : (int)blockIdx.x;
+    // parked accumulators [2 * QM][threads] (EARLY), then the row buffers [2][NW][ER][AS][64]: a
+    // wave's slice is written lane-linearly by LDS-DMA
+    double* sh_acc = reinterpret_cast<double*>(sh_ok + 4);
+    T* sh_rows = reinterpret_cast<T*>(sh_acc + (EARLY ? 2 * QM * kPbPrbThreads : 0));
+    const int g = (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid % L, grp = tid / L;
     const int wlane = tid & 63, wave = tid >> 6;
     const int gb = grp * L;  // the group's slice of the per-entry LDS arrays
@@ -566,7 +402,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     const bool kl = lane < k;
     const double lam = kl ? lams[lane] : 0.0;
     const bool chained = (reg == REG_SQL21 || reg == REG_OMEGACS);
-    const bool fixed_owner = !DOWN && a.G >= 64;
+    const bool fixed_owner = a.G >= 64;
     const int oq = fixed_owner ? pbprb_owned_slot(a.G, g, 0) : -1;  // the slot this WG owns
     if (wave == 0 && wlane < 2 * (kMaxDegree + 2)) {
         const int t = wlane % (kMaxDegree + 2);
@@ -601,15 +437,16 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         s.cnt = e1 - e0;
         const bool v = lane < s.cnt;
         s.row = v ? a.erow[e0 + lane] : 0;
-        s.meta = v ? (int)a.emeta[e0 + lane] : 0;
+        s.meta = v ? ((int)a.emeta[e0 + lane] | ((int)a.efwd[e0 + lane] << 8)) : 0;
         s.x = v ? eval[e0 + lane] : (T)0;
     };
     auto rows_at = [&](int par, int u, int t) __attribute__((always_inline)) -> T* {
         return sh_rows + ((((size_t)par * NW + wave) * ER + u) * AS + t) * 64;
     };
     // packed rows of a set (-> LDS buffer `par`); hz = 0: the entries not flagged, 1: the flagged
-    // ones (after the barrier that ends the step which updated them).  Every lane fetches its own
-    // element of the record: the group's L lanes take one contiguous, aligned slice.
+    // ones whose record does not come through LDS (0x80 without 0x40; after the barrier that ends
+    // the step which updated them).  Every lane fetches its own element of the record: the
+    // group's L lanes take one contiguous, aligned slice.
     auto fetch_rows = [&](ESet& s, int par, int hz) __attribute__((always_inline)) {
         const int2* rm_ = sh_rm + par * NG * L + gb;
         const int nf = min(s.cnt, ER);
@@ -626,7 +463,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
 #pragma unroll
             for (int uu = 0; uu < 4; ++uu) {
                 const int u = ub + uu;
-                if (u < nf && ((rm[uu].y >> 7) & 1) == hz) {
+                if (u < nf && (rm[uu].y & 0xC0) == (hz ? 0x80 : 0x00)) {
                     const size_t base = (size_t)rm[uu].x * rowlen + lane;
 #pragma unroll
                     for (int t = 0; t < AS; ++t) {
@@ -654,6 +491,92 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     };
     auto col_id = [&](int c, int ncols_of, int q) __attribute__((always_inline)) -> int {
         return (q >= 0 && q < ncols_of) ? a.jsched[c + q] : -1;
+    };
+    // the group's lanes' bits of a ballot (lane u of the group <-> bit u)
+    auto group_bits = [&](unsigned long long bal) __attribute__((always_inline)) -> unsigned long long {
+        return (L == 64) ? bal : ((bal >> (32 * (grp & 1))) & 0xffffffffull);
+    };
+    // the group's fast entries are sorted by slot: segment t = [seg[t], seg[t+1]) (one ballot per
+    // slot on the lane-parallel slot indices), so the slot's p_j is a static register
+    auto segments = [&](const ESet& s, int nfast, int (&seg)[QM + 1]) __attribute__((always_inline)) {
+        seg[0] = 0;
+#pragma unroll
+        for (int t = 0; t < QM; ++t)
+            seg[t + 1] = __builtin_popcountll(
+                group_bits(__ballot(lane < nfast && (s.meta & 7) <= t)));
+    };
+    // fast entries of the set that sit on a row the previous step updates (host flag 0x80)
+    auto hazard_bits = [&](const ESet& s, int nfast) __attribute__((always_inline)) -> unsigned long long {
+        return group_bits(__ballot(lane < nfast && (s.meta & 0x80) != 0));
+    };
+    // (sum dloss * dA, sum dA^2) contribution of the group's fast entry u (buffers of parity q)
+    auto entry_sums = [&](int q, int u, double p, double& gacc, double& hacc)
+                          __attribute__((always_inline)) {
+        const double2 xd = sh_xd[q * NG * L + gb + u];
+        double ad[AS];
+#pragma unroll
+        for (int tt = 0; tt < AS; ++tt) ad[tt] = (double)rows_at(q, u, tt)[wlane];
+        const double dprev = kl ? grad_factor<M>(ad, xd.x, p) : 0.0;
+        gacc += xd.y * dprev;
+        hacc += dprev * dprev;
+    };
+    // the group's QM vectors (slots grp + t * NG) -> slabA: sum_s inv_step_sizes[s]
+    // (pbcd.py:68-70) of the QM slots by one butterfly: lane l ends with the sum of slot
+    // (l & (QM-1)); lane L-2 of slot t's vector needs slot t.  Slots beyond the step's columns
+    // but below `nw_` are rewritten with zeros (stale-tag rule).
+    auto publish_vectors = [&](const double (&gs)[QM], const double (&hs)[QM], double* slabA_,
+                               int nw_, unsigned long long tag_) __attribute__((always_inline)) {
+        double hv[QM];
+#pragma unroll
+        for (int t = 0; t < QM; ++t) hv[t] = hs[t];
+        const double hr = pb_multi_reduce<QM, L>(hv, lane);
+#pragma unroll
+        for (int t = 0; t < QM; ++t) {
+            const int q = grp + t * NG;
+            const double hsum = pb_bcast<L>(hr, t, grp);
+            if (q < nw_) {
+                const double v = (lane == L - 2) ? hsum : (kl ? gs[t] : 0.0);
+                prb_store_granule(slabA_ + ((size_t)q * a.G + g) * L + lane, v, tag_);
+            }
+        }
+    };
+    // EARLY phase for the entry set `s` of a step (buffers of parity q, the slots' blocks pp[]):
+    // dloss of the entries on unshared rows, their part of the sums; published if the group has
+    // no shared row (and no entry beyond the LDS row slots), else parked
+    auto early_phase = [&](const ESet& s, int q, const double (&pp)[QM], double* slabA_, int nw_,
+                           unsigned long long tag_) __attribute__((always_inline)) {
+        const int nf = min(s.cnt, ER);
+        {
+            double dl = 0.0;
+            if (lane < nf && (s.meta & 0x80) == 0) {
+                const T* r0 = rows_at(q, lane, 0) + (wlane - lane);
+                dl = dloss_dev(loss, (double)r0[L - 2], (double)r0[L - 1]);
+            }
+            sh_xd[q * NG * L + gb + lane] = make_double2((double)s.x, dl);
+        }
+        wave_lds_sync();
+        int seg[QM + 1];
+        segments(s, nf, seg);
+        const unsigned long long hzb = hazard_bits(s, nf);
+        double gs[QM], hs[QM];
+#pragma unroll
+        for (int t = 0; t < QM; ++t) {
+            double gacc = 0.0, hacc = 0.0;
+            const double p = pp[t];
+            for (int u = seg[t]; u < seg[t + 1]; ++u)
+                if (((hzb >> u) & 1ull) == 0) entry_sums(q, u, p, gacc, hacc);
+            gs[t] = gacc;
+            hs[t] = hacc;
+        }
+        if (hzb == 0ull && s.cnt <= ER) {
+            publish_vectors(gs, hs, slabA_, nw_, tag_);
+        } else {
+#pragma unroll
+            for (int t = 0; t < QM; ++t) {
+                sh_acc[(2 * t) * kPbPrbThreads + tid] = gs[t];
+                sh_acc[(2 * t + 1) * kPbPrbThreads + tid] = hs[t];
+            }
+        }
     };
 
     int c0 = a.bptr[0], c1 = a.bptr[min(1, a.nb)];
@@ -694,105 +617,107 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     double cn0 = (cj0 >= 0 && chained) ? rs.norms[cj0] : 0.0, cn1 = 0.0;
     int cjp = -1;           // chain: column of the previous step held by this lane ...
     double l2n_prev = 0.0;  // ... and its new block norm, stored one step late
+    if constexpr (EARLY) {
+        // step 0's early phase (no step in front of it: nothing is flagged)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_sync();
+        early_phase(cur, 0, po, a.slabA, max(c1 - c0, c3 - c2), prb_tag(0));
+    }
     __syncthreads();
 
     for (int b = 0; b < a.nb; ++b) {
         const int ncols = c1 - c0;
-        const int c4 = a.bptr[min(b + 4, a.nb)];  // used from the next iteration on
+        const int c4 = a.bptr[min(b + 4, a.nb)];
         // slots written this step: this step's and those of the buffer's next use, so that a
-        // word read at step b+2 was rewritten at step b (its tag is never tag(b+2))
+        // word read at the next use was rewritten now (its tag is never that use's): slabA /
+        // slabC are double-buffered (next use b+2), slabB is triple-buffered (next use b+3)
         const int nw = max(ncols, c3 - c2);
+        const int nwB = max(ncols, c4 - c3);
         const unsigned long long tag = prb_tag(b);
+        const unsigned long long tagB = pb_tag3(b);
         const int par = b & 1;
         double* slabA = a.slabA + (size_t)par * 64 * a.G * L;
-        double* slabB = a.slabB + (size_t)par * 64 * L;
+        double* slabB = a.slabB + (size_t)(b % 3) * 64 * L;
+        const bool drain_now = a.edrain[(size_t)g * a.nb + b] != 0;  // (workgroup-uniform)
         const int2* srm = sh_rm + par * NG * L + gb;  // (row, meta) of the group's entries
+        const double2* sxd = sh_xd + par * NG * L + gb;
         const int nfast = min(cur.cnt, ER);
 
-        // ---- phase 0: rows this step shares with the previous one (after its barrier)
-        fetch_rows(cur, par, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed in LDS
+        // ---- phase 0: rows this step shares with the previous one (after its barrier): their
+        // new records were written into this step's row buffer by the previous step's scatter
+        // (efwd); the rare ones that were not (an entry beyond the LDS row slots on either side)
+        // come from global memory -- the previous step's end barrier drained its stores (edrain)
+        if (__ballot(lane < nfast && (cur.meta & 0xC0) == 0x80) != 0ull) {
+            fetch_rows(cur, par, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed in LDS
+        }
         wave_lds_sync();
         {   // lane u <-> entry u: dloss from the record's (yhat, y) (lanes L-2, L-1 of slice 0),
-            // with x -> LDS for the group's broadcast reads
-            double dl = 0.0;
-            if (lane < nfast) {
+            // with x -> LDS for the group's broadcast reads.  EARLY: only the shared rows are
+            // new, the other entries' values are there since the early phase.
+            if (lane < nfast && (!EARLY || (cur.meta & 0x80) != 0)) {
                 const T* r0 = rows_at(par, lane, 0) + (wlane - lane);
-                dl = dloss_dev(loss, (double)r0[L - 2], (double)r0[L - 1]);
+                const double dl = dloss_dev(loss, (double)r0[L - 2], (double)r0[L - 1]);
+                sh_xd[par * NG * L + gb + lane] = make_double2((double)cur.x, dl);
+            } else if (!EARLY) {
+                sh_xd[par * NG * L + gb + lane] = make_double2((double)cur.x, 0.0);
             }
-            sh_xd[gb + lane] = make_double2((double)cur.x, dl);
         }
         wave_lds_sync();
         PB_STAMP(0)
         // ---- phase 1: partial sums of the own rows (pbcd.py:56-67), published per slot
-        double gs[QM], hs[QM];
-#pragma unroll
-        for (int t = 0; t < QM; ++t) {
-            gs[t] = 0.0;
-            hs[t] = 0.0;
-        }
-        // the group's fast entries are sorted by slot: segment t = [seg[t], seg[t+1]) (one ballot
-        // per slot on the lane-parallel slot indices), so the slot's p_j is a static register
         int seg[QM + 1];
-        seg[0] = 0;
+        segments(cur, nfast, seg);
+        const unsigned long long hzb = EARLY ? hazard_bits(cur, nfast) : 0ull;
+        if (!EARLY || hzb != 0ull || cur.cnt > ER) {
+            double gs[QM], hs[QM];
+            if constexpr (EARLY) {
 #pragma unroll
-        for (int t = 0; t < QM; ++t) {
-            const unsigned long long bal = __ballot(lane < nfast && (cur.meta & 7) <= t);
-            seg[t + 1] = (L == 64) ? __builtin_popcountll(bal)
-                                   : __builtin_popcount((unsigned)(bal >> (32 * (grp & 1))));
-        }
+                for (int t = 0; t < QM; ++t) {
+                    gs[t] = sh_acc[(2 * t) * kPbPrbThreads + tid];
+                    hs[t] = sh_acc[(2 * t + 1) * kPbPrbThreads + tid];
+                }
+                // the entries on shared rows, in row order inside their slot
 #pragma unroll
-        for (int t = 0; t < QM; ++t) {
-            double gacc = 0.0, hacc = 0.0;
-            const double p = po[t];
-            for (int u = seg[t]; u < seg[t + 1]; ++u) {
-                const double2 xd = sh_xd[gb + u];
-                double ad[AS];
+                for (int t = 0; t < QM; ++t) {
+                    double gacc = 0.0, hacc = 0.0;
+                    const double p = po[t];
+                    for (int u = seg[t]; u < seg[t + 1]; ++u)
+                        if (((hzb >> u) & 1ull) != 0) entry_sums(par, u, p, gacc, hacc);
+                    gs[t] += gacc;
+                    hs[t] += hacc;
+                }
+            } else {
 #pragma unroll
-                for (int tt = 0; tt < AS; ++tt) ad[tt] = (double)rows_at(par, u, tt)[wlane];
-                const double dprev = kl ? grad_factor<M>(ad, xd.x, p) : 0.0;
-                gacc += xd.y * dprev;
-                hacc += dprev * dprev;
-            }
-            gs[t] = gacc;
-            hs[t] = hacc;
-        }
-        for (int u = ER; u < cur.cnt; ++u) {  // slow path: beyond the LDS-staged rows
-            const int e = cur.e0 + u;
-            const int i = a.erow[e];
-            const int qi = (int)a.emeta[e] & 7;
-            const double x = (double)eval[e];
-            const T* ri = R + (size_t)i * rowlen;
-            const double dl = dloss_dev(loss, (double)ri[L - 2], (double)ri[L - 1]);
-            double ad[AS];
-#pragma unroll
-            for (int t = 0; t < AS; ++t) ad[t] = kl ? (double)ri[(size_t)t * L + lane] : 0.0;
-            const double p = pb_sel(po, qi);
-            const double dprev = kl ? grad_factor<M>(ad, x, p) : 0.0;
-            pb_acc<QM>(gs, qi, dl * dprev);
-            pb_acc<QM>(hs, qi, dprev * dprev);
-        }
-        {
-            // sum_s inv_step_sizes[s] (pbcd.py:68-70) of the QM slots by one butterfly: lane l
-            // ends with the sum of slot (l & (QM-1)); lane L-2 of slot t's vector needs slot t
-            double hv[QM];
-#pragma unroll
-            for (int t = 0; t < QM; ++t) hv[t] = hs[t];
-            const double hr = pb_multi_reduce<QM, L>(hv, lane);
-#pragma unroll
-            for (int t = 0; t < QM; ++t) {
-                const int q = grp + t * NG;
-                const double hsum = pb_bcast<L>(hr, t, grp);
-                if (q < nw) {
-                    const double v = (lane == L - 2) ? hsum : (kl ? gs[t] : 0.0);
-                    prb_store_granule(slabA + ((size_t)q * a.G + g) * L + lane, v, tag);
+                for (int t = 0; t < QM; ++t) {
+                    double gacc = 0.0, hacc = 0.0;
+                    const double p = po[t];
+                    for (int u = seg[t]; u < seg[t + 1]; ++u) entry_sums(par, u, p, gacc, hacc);
+                    gs[t] = gacc;
+                    hs[t] = hacc;
                 }
             }
+            for (int u = ER; u < cur.cnt; ++u) {  // slow path: beyond the LDS-staged rows
+                const int e = cur.e0 + u;
+                const int i = a.erow[e];
+                const int qi = (int)a.emeta[e] & 7;
+                const double x = (double)eval[e];
+                const T* ri = R + (size_t)i * rowlen;
+                const double dl = dloss_dev(loss, (double)ri[L - 2], (double)ri[L - 1]);
+                double ad[AS];
+#pragma unroll
+                for (int t = 0; t < AS; ++t) ad[t] = kl ? (double)ri[(size_t)t * L + lane] : 0.0;
+                const double p = pb_sel(po, qi);
+                const double dprev = kl ? grad_factor<M>(ad, x, p) : 0.0;
+                pb_acc<QM>(gs, qi, dl * dprev);
+                pb_acc<QM>(hs, qi, dprev * dprev);
+            }
+            publish_vectors(gs, hs, slabA, nw, tag);
         }
         PB_STAMP(1)
 
         // ---- phase 2: owners reduce their slot over the workgroups and take the step
-        const int n_rounds = DOWN ? 0 : (fixed_owner ? 1 : (nw + a.G - 1) / a.G);
+        const int n_rounds = fixed_owner ? 1 : max(1, (max(nw, nwB) + a.G - 1) / a.G);
         for (int r = 0; r < n_rounds; ++r) {
             const int q = fixed_owner ? oq : pbprb_owned_slot(a.G, g, r);
             const bool own = q >= 0 && q < ncols;
@@ -833,11 +758,15 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 red[grp * L + lane] = tot;
             }
             PB_STAMP(2)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // part sums in LDS
-            if (q >= ncols && q < nw && grp == 0) {
-                // slot unused in this step but read at the buffer's next use: rewritten now
-                prb_store_granule(slabB + (size_t)q * L + lane, 0.0, tag);
-                if (a.n_ranks > 1) {
+            // part sums in LDS.  vmcnt(0): the previous step's scatter stores of this wave are
+            // complete (an owner's poll loads have returned behind them; everybody else waits a
+            // store's round trip here, in the shadow of the exchange), so that after the barrier
+            // the prefetch below may read any row of the block
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (q >= 0 && q >= ncols && grp == 0) {
+                // slot unused in this step but read at a buffer's next use: rewritten now
+                if (q < nwB) prb_store_granule(slabB + (size_t)q * L + lane, 0.0, tagB);
+                if (a.n_ranks > 1 && q < nw) {
                     const size_t off = ((size_t)par * 64 + q) * a.n_ranks * L;
                     for (int rr = 0; rr < a.n_ranks; ++rr)
                         prb_store_granule_sys(a.slabC[rr] + off + (size_t)a.rank * L + lane, 0.0, tag);
@@ -898,7 +827,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 }
                 const double l2 = sqrt(pb_group_allsum<L>(v * v));
                 const double outv = (lane == L - 2) ? l2 : ((lane == L - 1) ? st0 : v);
-                prb_store_granule(slabB + (size_t)q * L + lane, outv, tag);
+                prb_store_granule(slabB + (size_t)q * L + lane, outv, tagB);
             }
         }
         PB_STAMP(3)
@@ -908,11 +837,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         // in front of the collect poll: vmcnt retires in order, so the first tag check waits for
         // these loads too -- but everybody waits about that long for the owners anyway.  (In
         // front of the owner poll it delays the owners themselves: 13.1 vs 12.4 us per step;
-        // behind the collect poll its issue time sits on the critical path: 14.1.  Round 3:
-        // waves 1..7 polling at once with an empty load queue and prefetching during wave 0's
-        // chain instead: 12.1 vs 11.0 -- the totals arrive ~5 us after the publish whoever polls
-        // and however early; the exchange is bound by the burst of 2 MB of partial vectors that
-        // all workgroups write, and the owners read, at the same instant.)
+        // behind the collect poll its issue time sits on the critical path: 14.1.)
         int b3e0, b3e1;
         bounds(b + 3, b3e0, b3e1);
         load_entries(nn, b2e0, b2e1);
@@ -928,6 +853,14 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         const int cj2 = (wave == 0) ? col_id(c2, c3 - c2, wlane) : -1;
         cn1 = (cj1 >= 0 && chained) ? rs.norms[cj1] : 0.0;
         PB_STAMP(4)
+        // ---- early phase of step b+1 (in the shadow of the exchange): see the header
+        if constexpr (EARLY) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its rows have landed in LDS
+            wave_lds_sync();
+            early_phase(nxt, par ^ 1, pon, a.slabA + (size_t)(par ^ 1) * 64 * a.G * L,
+                        max(c2 - c1, c4 - c3), prb_tag(b + 1));
+        }
+        PB_STAMP(10)
         // ---- phase 3: every workgroup collects the published vectors of all slots
         {
             const int total = ncols * L;
@@ -940,8 +873,8 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
                     const int idx = tid + u * kPbPrbThreads;
-                    t[u] = (idx < total) ? prb_load_granule(slabB + idx) : tag;
-                    all = all && ((t[u] & 3ull) == tag);
+                    t[u] = (idx < total) ? prb_load_granule(slabB + idx) : tagB;
+                    all = all && ((t[u] & 3ull) == tagB);
                 }
                 if (all) break;
                 if (pbprb_poll_fail(a, spins)) {
@@ -1007,12 +940,8 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 pn[t] = (vq && kl) ? pt * f : 0.0;
                 up[t] = (vq && kl) ? po[t] - pn[t] : 0.0;
                 lu[t] = lam * up[t];
-                {   // did the block move?  one ballot per slot (exact no-op otherwise)
-                    const unsigned long long bal = __ballot(up[t] != 0.0);
-                    const unsigned long long mine =
-                        (L == 64) ? bal : ((bal >> (32 * (grp & 1))) & 0xffffffffull);
-                    mv[t] = (mine != 0ull) ? 1.0 : 0.0;
-                }
+                // did the block move?  one ballot per slot (exact no-op otherwise)
+                mv[t] = (group_bits(__ballot(up[t] != 0.0)) != 0ull) ? 1.0 : 0.0;
                 vav[t] = fabs(up[t]);
                 if (g == 0 && vq && kl) P[(size_t)j0[t] * k + lane] = pn[t];
             }
@@ -1023,46 +952,82 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             }
         }
         {
-            // per slot (static registers po / up / lu), per entry: the new record -- cache values
-            // in the component lanes, the prediction minus sum_s lam_s Delta_s dA_s (one DPP
-            // all-reduce) in lane L-2, the target in lane L-1, zeros in the padding -- written
-            // back as whole slices (slice 0 of float storage, k <= 30: one full 128-byte line)
+            // per entry: the new record -- cache values in the component lanes, the prediction
+            // minus sum_s lam_s Delta_s dA_s in lane L-2, the target in lane L-1, zeros in the
+            // padding -- written back as whole slices (slice 0 of float storage, k <= 30: one full
+            // 128-byte line).  CH entries at a time: independent dependency chains for the
+            // compiler to interleave, and ONE transposing butterfly for the CH prediction
+            // decrements instead of an all-reduce each.  An entry whose row the next step touches
+            // (efwd) also writes its record into that step's LDS row buffer.
+            constexpr int CH = (AS == 1) ? 4 : 2;
+            for (int ub = 0; ub < nfast; ub += CH) {
+                double adv[CH][AS], nvv[CH][AS], cdec[CH], cnew[CH];
+                int rowv[CH], fwv[CH];
+                bool act[CH];
 #pragma unroll
-            for (int t = 0; t < QM; ++t) {
-                if (mv[t] == 0.0) continue;  // block did not move: exact no-op (group-uniform)
-                const double pol = po[t], upl = up[t], lul = lu[t], pnl = pn[t];
-                for (int u = seg[t]; u < seg[t + 1]; ++u) {
-                    const double x = sh_xd[gb + u].x;
-                    const size_t base = (size_t)srm[u].x * rowlen + lane;
-                    double ad[AS];
+                for (int c = 0; c < CH; ++c) {
+                    const int u = min(ub + c, nfast - 1);
+                    const int2 rm = srm[u];
+                    const int qi = rm.y & 7;
+                    act[c] = ub + c < nfast && pb_sel(mv, qi) != 0.0;  // block did not move: no-op
+                    rowv[c] = rm.x;
+                    fwv[c] = rm.y >> 8;
+                    const double x = sxd[u].x;
+                    const double pol = pb_sel(po, qi), upl = pb_sel(up, qi);
 #pragma unroll
-                    for (int tt = 0; tt < AS; ++tt) ad[tt] = (double)rows_at(par, u, tt)[wlane];
-                    // lane L-2 holds yhat_old in ad[0], lane L-1 the target
+                    for (int tt = 0; tt < AS; ++tt) adv[c][tt] = (double)rows_at(par, u, tt)[wlane];
+                    // lane L-2 holds yhat_old in adv[.][0], lane L-1 the target
                     if constexpr (M == 0) {  // pbcd_all.py:121-127
-                        const double a0 = kl ? ad[0] : 0.0;
+                        const double pnl = pb_sel(pn, qi);
+                        const double a0 = kl ? adv[c][0] : 0.0;
                         double a1 = a0 / (1.0 + x * pol);
                         a1 *= 1.0 + x * pnl;
-                        const double d_old = pb_group_allsum<L>(kl ? lam * a0 : 0.0);
-                        const double d_new = pb_group_allsum<L>(kl ? lam * a1 : 0.0);
-                        double outv = kl ? a1 : 0.0;
-                        if (lane == L - 2) outv = (ad[0] - d_old) + d_new;
-                        if (lane == L - 1) outv = ad[0];
-                        R[base] = (T)outv;
+                        nvv[c][0] = kl ? a1 : 0.0;
+                        cdec[c] = (kl && act[c]) ? lam * a0 : 0.0;
+                        cnew[c] = (kl && act[c]) ? lam * a1 : 0.0;
                     } else {
-                        double nv[AS];
+                        const double lul = pb_sel(lu, qi);
                         double dprev = x;
 #pragma unroll
                         for (int tt = 1; tt < M; ++tt) {
-                            const double avv = kl ? ad[tt - 1] : 0.0;
+                            const double avv = kl ? adv[c][tt - 1] : 0.0;
                             const double dcur = x * (avv - pol * dprev);
-                            nv[tt - 1] = kl ? avv - upl * dprev : 0.0;
+                            nvv[c][tt - 1] = kl ? avv - upl * dprev : 0.0;
                             dprev = dcur;
                         }
-                        const double dec = pb_group_allsum<L>(kl ? lul * dprev : 0.0);
-                        if (lane == L - 2) nv[0] = ad[0] - dec;
-                        if (lane == L - 1) nv[0] = ad[0];
+                        cdec[c] = (kl && act[c]) ? lul * dprev : 0.0;
+                        cnew[c] = 0.0;
+                    }
+                }
+                // lane l of the group ends with the sum of entry (l & (CH-1))
+                const double rdec = pb_multi_reduce<CH, L>(cdec, lane);
+                double rnew = 0.0;
+                if constexpr (M == 0) rnew = pb_multi_reduce<CH, L>(cnew, lane);
 #pragma unroll
-                        for (int tt = 0; tt < AS; ++tt) R[base + (size_t)tt * L] = (T)nv[tt];
+                for (int c = 0; c < CH; ++c) {
+                    const double dec = pb_bcast<L>(rdec, c, grp);
+                    if constexpr (M == 0) {
+                        const double dnw = pb_bcast<L>(rnew, c, grp);
+                        if (lane == L - 2) nvv[c][0] = (adv[c][0] - dec) + dnw;
+                    } else {
+                        if (lane == L - 2) nvv[c][0] = adv[c][0] - dec;
+                    }
+                    if (lane == L - 1) nvv[c][0] = adv[c][0];
+                    if (act[c]) {
+                        const size_t base = (size_t)rowv[c] * rowlen + lane;
+#pragma unroll
+                        for (int tt = 0; tt < AS; ++tt) R[base + (size_t)tt * L] = (T)nvv[c][tt];
+                    }
+                    if (ub + c < nfast && (fwv[c] & 0x100)) {
+                        // the next step's copy of the row: group (fw >> 4) & 15, entry fw & 15 of
+                        // the other parity's buffer (an unmoved block forwards the old record)
+                        const int fg = (fwv[c] >> 4) & 15, fu = fwv[c] & 15;
+                        const int fwave = (L == 64) ? fg : (fg >> 1);
+                        const int foff = (L == 64) ? lane : ((fg & 1) * 32 + lane);
+                        T* dst = sh_rows + ((((size_t)(par ^ 1) * NW + fwave) * ER + fu) * AS) * 64 + foff;
+#pragma unroll
+                        for (int tt = 0; tt < AS; ++tt)
+                            dst[(size_t)tt * 64] = act[c] ? (T)nvv[c][tt] : (T)adv[c][tt];
                     }
                 }
             }
@@ -1130,7 +1095,14 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         c1 = c2;
         c2 = c3;
         c3 = c4;
-        __syncthreads();  // rows move between groups from step to step (stores drained)
+        // rows move between groups from step to step: through LDS (forwarded records; an LDS-only
+        // barrier) -- or, when the next step reads one of them from global memory, with this
+        // step's stores drained first
+        if (drain_now) {
+            __syncthreads();
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         PB_STAMP(8)
     }
 #undef PB_STAMP
@@ -1147,14 +1119,15 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
 }
 
 // dynamic LDS the kernel needs (bytes)
-template <typename T, int M, int L>
+template <typename T, int M, int L, bool EARLY = false>
 constexpr size_t pbcd_prb_lds_bytes() {
     constexpr int NG = kPbPrbThreads / L;
+    constexpr int QM = 64 / NG;
     constexpr int AS = Kind<M>::AS;
-    constexpr int ER0 = (int)(16 * 4 / sizeof(T)) / AS;
-    constexpr int ER = ER0 >= 8 ? (ER0 / 8) * 8 : (ER0 >= 4 ? 4 : (ER0 >= 2 ? 2 : 1));
-    return sizeof(double) * (2 * NG * L + 64 * L + 256 + 2 * NG * L + 2 * (kMaxDegree + 2)) +
+    constexpr int ER = pbprb_er<T, M>();
+    return sizeof(double) * (2 * NG * L + 64 * L + 256 + 4 * NG * L + 2 * (kMaxDegree + 2)) +
            sizeof(int) * (4 * NG * L + 4) +
+           sizeof(double) * (EARLY ? (size_t)2 * QM * kPbPrbThreads : 0) +
            sizeof(T) * (size_t)2 * (kPbPrbThreads / 64) * ER * AS * 64;
 }
 

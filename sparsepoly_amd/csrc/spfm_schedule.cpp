@@ -612,10 +612,17 @@ void build_rowblock_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
 // group (q / NG, < 8) | 0x80 if the entry's row was touched by the previous step (its row
 // state must be read after that step's scatter, not prefetched).  Batches of <= 64 columns,
 // nnz < 2^31.
+// Forwarding (round 4): the kernel keeps the rows of a group's first ER entries in LDS.  When
+// a row is touched by two consecutive steps and both entries are among those (the rule but for
+// very frequent features), the first step's scatter writes the new record straight into the
+// second step's LDS slot: fwd[e] = 0x100 | group << 4 | entry for the FIRST step's entry, meta
+// |= 0x40 for the second's; otherwise drain[g * nb + b] = 1 for the first step b (its end
+// barrier must drain the stores, the second step reads global memory).
 void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
                      const std::vector<int32_t>& order, const std::vector<int32_t>& batch_ptr,
-                     int G, int NG, std::vector<int32_t>& gsp, std::vector<int32_t>& src,
-                     std::vector<uint8_t>& meta) {
+                     int G, int NG, int ER, std::vector<int32_t>& gsp, std::vector<int32_t>& src,
+                     std::vector<uint8_t>& meta, std::vector<uint16_t>& fwd,
+                     std::vector<uint8_t>& drain) {
     const int nb = (int)batch_ptr.size() - 1;
     const int64_t rows_per = (n + G - 1) / G > 0 ? (n + G - 1) / G : 1;
     const size_t stride = (size_t)NG + 1;
@@ -644,8 +651,11 @@ void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
     }
     src.resize((size_t)run);
     meta.resize((size_t)run);
+    fwd.assign((size_t)run, 0);
+    drain.assign((size_t)G * (size_t)std::max(nb, 1), 0);
     std::vector<int32_t> fill(gsp.begin(), gsp.end());
     std::vector<int32_t> last((size_t)n, -2);  // last step that touched the row (own rows only)
+    std::vector<int32_t> last_e((size_t)n, -1);  // ... and the entry that did
     // slots of one group in ascending order: q = grp, grp + NG, ... -> walking q ascending, the
     // per-group fill pointers keep (slot, row) order inside each group
     run_threads(T, [&](int tid) {
@@ -661,8 +671,30 @@ void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
                     const size_t e = (size_t)fill[((size_t)(i / rows_per) * nb + b) * stride +
                                                   (size_t)(q % NG)]++;
                     src[e] = (int32_t)ii;
-                    meta[e] = (uint8_t)(qi | (last[(size_t)i] == b - 1 ? 0x80 : 0));
+                    uint8_t m = qi;
+                    if (last[(size_t)i] == b - 1) {
+                        m |= 0x80;
+                        // position of both entries inside their groups: entries of a group are
+                        // filled in order, so e - (group's first entry) is the lane index u
+                        const size_t gi = (size_t)(i / rows_per);
+                        const int grp_d = q % NG;
+                        const int u_d = (int)(e - (size_t)gsp[(gi * nb + b) * stride + (size_t)grp_d]);
+                        const size_t ep = (size_t)last_e[(size_t)i];
+                        // the source entry's group: the one whose range in step b-1 holds ep
+                        const int32_t* gp = &gsp[(gi * nb + (size_t)(b - 1)) * stride];
+                        int grp_s = 0;
+                        while (grp_s + 1 < NG && (size_t)gp[grp_s + 1] <= ep) ++grp_s;
+                        const int u_s = (int)(ep - (size_t)gp[grp_s]);
+                        if (u_d < ER && u_s < ER) {
+                            m |= 0x40;
+                            fwd[ep] = (uint16_t)(0x100 | (grp_d << 4) | u_d);
+                        } else {
+                            drain[gi * (size_t)nb + (size_t)(b - 1)] = 1;
+                        }
+                    }
+                    meta[e] = m;
                     last[(size_t)i] = b;  // columns of one step share no row: no read-after-write
+                    last_e[(size_t)i] = (int32_t)e;
                 }
             }
         }

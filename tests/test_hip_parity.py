@@ -244,11 +244,7 @@ def test_engine_options_do_not_change_results(oracle, case, options):
 
 @pytest.mark.parametrize("options", [{"pbprb_groups": 1}, {"pbprb_groups": 3},
                                      {"pbprb_groups": 64}, {"pbprb_groups": 100},
-                                     {"pbprb_groups": 256},
-                                     # dedicated owner workgroups: most of them idle in most
-                                     # steps of this small problem (pacing), two slots per owner
-                                     {"pbprb_groups": 256, "pbprb_owners": 48},
-                                     {"pbprb_groups": 130, "pbprb_owners": 2}])
+                                     {"pbprb_groups": 256}, {"pbprb_groups": 130}])
 @pytest.mark.parametrize("case", ["c4|squared", "c4|logistic", "c4d3|squared_hinge",
                                   "l21|logistic", "sql21|squared", "l1b|squared_hinge"])
 def test_persistent_pbcd_pass_equals_multi_kernel_engine(oracle, case, options):

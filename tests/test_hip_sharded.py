@@ -57,11 +57,10 @@ def _run(case, world, rank, shm_name, precision, engine="multi_kernel", hq=None)
     eng = HipEngine(0, precision)
     if engine == "multi_kernel":
         eng.set_option("persistent", 0)   # the multi-kernel engine in both runs
-    elif engine == "persistent_peer_owners":
-        # persistent pbcd pass with DEDICATED owner workgroups (48 owners + 80 row workgroups
-        # per rank; two co-resident kernels fill the 256 CUs), cross-GPU stage in the owners
+    elif engine == "persistent_peer_128":
+        # persistent pbcd pass with 128 row workgroups per rank: two co-resident kernels fill the
+        # 256 CUs; half of the workgroups own a slot (cross-GPU stage in the owners)
         eng.set_option("pbprb_groups", 128)
-        eng.set_option("pbprb_owners", 48)
         eng.set_option("pcdw_groups", 64)
     else:
         eng.set_option("pbprb_groups", 64)  # two co-resident persistent kernels: 2 x 64 CUs
@@ -97,7 +96,7 @@ def _run(case, world, rank, shm_name, precision, engine="multi_kernel", hq=None)
     P, w = eng.get_params()
     yp = eng.get_y_pred()
     active = (eng.get_option("persistent_active"), eng.get_option("pbprb_active"))
-    extra = (eng.get_option("pbprb_owners"), eng.get_option("persistent_fallbacks"))
+    extra = (eng.get_option("pbprb_groups"), eng.get_option("persistent_fallbacks"))
     eng.close()
     return dict(P=P, w=w, viol=np.array(viol), loss=np.array(losses), y_pred=yp, order=order,
                 rows=(lo, hi), active=active, extra=extra)
@@ -112,7 +111,7 @@ def _worker(case, world, rank, shm_name, precision, q, engine, hq):
 
 @pytest.mark.parametrize("case,engine",
                          [(c, e) for c in sorted(CASES) for e in ("multi_kernel", "persistent_peer")]
-                         + [("pbcd_cs", "persistent_peer_owners")])
+                         + [("pbcd_cs", "persistent_peer_128")])
 def test_two_row_shards_on_one_gpu(oracle, case, engine):
     solver, reg, degree, k, loss, beta, gamma = CASES[case]
     shm_name = "/spfm_test_%d_%s_%s" % (os.getpid(), case, engine)
@@ -149,8 +148,6 @@ def test_two_row_shards_on_one_gpu(oracle, case, engine):
     if engine.startswith("persistent_peer"):  # the persistent passes really ran, with two ranks
         assert a["active"] == ((1, 0) if solver == "pcd" else (1, 1)), a["active"]
         assert a["extra"][1] == 0, a["extra"]       # no fallback to the multi-kernel engine
-        if engine == "persistent_peer_owners":
-            assert a["extra"][0] == 48, a["extra"]  # dedicated owner workgroups
     assert np.array_equal(one["order"], a["order"])
     np.testing.assert_allclose(a["P"], one["P"], rtol=0, atol=1e-10)
     np.testing.assert_allclose(a["w"], one["w"], rtol=0, atol=1e-10)

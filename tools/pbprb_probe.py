@@ -21,15 +21,15 @@ X, y = make_problem(n, d, 50, 0)
 Xc = X.tocsc()
 Xc.sort_indices()
 k = 30
-PHASES = ["p0 hazard+wait", "p1 sums+publish", "p2 owner poll", "p2 barrier+step+publish", "prefetch issue",
-          "p3 collect poll", "p4 chain+barrier", "p5 scatter", "rotate+end barrier", "p3 barrier"]
+PHASES = ["p0 shared rows+wait", "p1 late sums+publish", "p2 owner poll", "p2 barrier+step+publish",
+          "prefetch issue", "p3 collect poll", "p4 chain+barrier", "p5 scatter", "rotate+end barrier",
+          "p3 barrier", "early phase (next step's unshared rows)"]
 for G in groups:
     for stamps in (0, 1):
         eng = HipEngine(0, "f32")
         eng.set_option("pbprb_groups", G)
-        if "PB_OWNERS" in os.environ:
-            eng.set_option("pbprb_owners", int(os.environ["PB_OWNERS"]))
         eng.set_option("pbprb_stamps", stamps)
+        eng.set_option("pbprb_early", int(os.environ.get("PB_EARLY", 0)))
         eng.set_option("pbprb_dbg", int(os.environ.get("PB_DBG", 0)))
         eng.set_data(Xc, y)
         eng.set_params(0.01 * np.random.RandomState(0).randn(1, k, d), np.zeros(d), np.ones(k))
@@ -42,26 +42,19 @@ for G in groups:
         for _ in range(reps):
             v.append(eng.pbcd_epoch(0, 2, 1.0, 1e-3, 1.0))
         dt = (time.perf_counter() - t0) / reps
-        out = dict(G=G, owners=eng.get_option("pbprb_owners"), stamps=stamps, reg=reg,
+        out = dict(G=G, stamps=stamps, reg=reg, early=int(os.environ.get("PB_EARLY", 0)),
                    ms_per_pbcd_epoch=round(dt * 1e3, 2),
                    steps=eng.n_batches, us_per_step=round(dt * 1e6 / eng.n_batches, 3),
                    active=eng.get_option("pbprb_active"), viol=[round(float(x), 3) for x in v])
         if int(os.environ.get("PB_DBG", 0)) & 8:
             out["dbg"] = [int(x) for x in eng.debug_prb_stamps().ravel()[:16]]
         elif stamps:
-            st_all = eng.debug_prb_stamps()[:, :10].astype(np.float64) / eng.n_batches
-            n_own = out["owners"]
-            st = st_all[:len(st_all) - n_own] if n_own else st_all   # row workgroups
-            own = st_all[len(st_all) - n_own:] if n_own else None
+            st = eng.debug_prb_stamps()[:, :11].astype(np.float64) / eng.n_batches
             scale = (dt * 1e9 / eng.n_batches) / st[0].sum()  # cycles -> ns via the wall time
             out["cycles_per_step_wg0"] = round(float(st[0].sum()))
             out["phase_ns_wg0"] = dict(zip(PHASES, [round(float(x * scale)) for x in st[0]]))
             out["phase_ns_wg1"] = dict(zip(PHASES, [round(float(x * scale)) for x in st[min(1, len(st) - 1)]]))
             out["phase_ns_mean"] = dict(zip(PHASES, [round(float(x * scale)) for x in st.mean(0)]))
             out["phase_ns_max"] = dict(zip(PHASES, [round(float(x * scale)) for x in st.max(0)]))
-            if own is not None:  # dedicated owners: poll (col 2), reduce + step + publish (col 3)
-                busy = own[own[:, 2] > 0]
-                out["owner_ns_mean"] = {"poll": round(float(busy[:, 2].mean() * scale)),
-                                        "reduce+step+publish": round(float(busy[:, 3].mean() * scale))}
         print(json.dumps(out), flush=True)
         eng.close()

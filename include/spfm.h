@@ -92,6 +92,16 @@ int spfm_set_data_csc(spfm_handle h, int64_t n, int32_t d, const int64_t* indptr
 int spfm_set_data_csr(spfm_handle h, int64_t n, int32_t d, const int64_t* indptr,
                       const int32_t* indices, const double* data, const double* y);
 
+/* Several handles on ONE training matrix (round 4): the fits of a regularisation path or a
+ * parameter grid -- the use-case the reference serves with warm_start chains
+ * (sparse_factorization_machines.py:380-391) -- and one-vs-rest targets (base.py:130-136).  `dst`
+ * refers to the device image `src` holds (CSC, CSR, column norms) instead of uploading and
+ * transposing its own copy, and the two share the entry streams of the persistent passes either
+ * of them builds later.  Same device and storage type, no communicator.  `y` (n doubles): dst's
+ * own targets, or NULL = src's.  The image is freed with its last holder; a later
+ * spfm_set_data_* on either handle detaches that handle only. */
+int spfm_share_data(spfm_handle dst, spfm_handle src, const double* y);
+
 /* -- parameters -------------------------------------------------------------
  * P is (n_orders, k, d) row-major as self.P_ (sparse_factorization_machines.py
  * :383-389), w (d), lams (k, each +-1: :403-404).  d must equal the data's

@@ -82,7 +82,7 @@ SCHEDULES = {"exact": 0, "colored": 1}
 
 # every symbol include/spfm.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "spfm_create", "spfm_destroy", "spfm_last_error", "spfm_device_name", "spfm_build_tag", "spfm_set_data_csc", "spfm_set_data_csr",
+    "spfm_create", "spfm_destroy", "spfm_last_error", "spfm_device_name", "spfm_build_tag", "spfm_set_data_csc", "spfm_set_data_csr", "spfm_share_data",
     "spfm_set_params", "spfm_get_params", "spfm_configure", "spfm_init_pred", "spfm_get_y_pred",
     "spfm_loss_sum", "spfm_predict_csr", "spfm_set_schedule", "spfm_set_schedule_raw",
     "spfm_get_schedule", "spfm_schedule_build",
@@ -124,6 +124,7 @@ def load():
     L.spfm_build_tag.restype = C.c_char_p
     L.spfm_set_data_csc.argtypes = [_h, C.c_int64, C.c_int32, _lp, _ip, _dp, _dp]
     L.spfm_set_data_csr.argtypes = [_h, C.c_int64, C.c_int32, _lp, _ip, _dp, _dp]
+    L.spfm_share_data.argtypes = [_h, _h, _dp]
     L.spfm_set_params.argtypes = [_h, C.c_int, C.c_int, C.c_int32, _dp, _dp, _dp]
     L.spfm_get_params.argtypes = [_h, _dp, _dp]
     L.spfm_configure.argtypes = [_h, C.c_int, C.c_int, C.c_int, C.c_int]

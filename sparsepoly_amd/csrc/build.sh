@@ -28,13 +28,19 @@ compile() {
         want="$want-$TAG"
     fi
     if [ -f "$OBJ/$u.o" ] && [ "$(cat "$OBJ/$u.stamp" 2>/dev/null)" = "$want" ]; then return 0; fi
-    rm -f "$OBJ/$u.stamp"
+    rm -f "$OBJ/$u.stamp" "$OBJ/$u.o"  # a failed compile must not leave a stale object behind
     "$HIPCC" $flags -c "$HERE/$u.hip" -o "$OBJ/$u.o"
     echo "$want" > "$OBJ/$u.stamp"
 }
 export -f compile
 export HERE OBJ HIPCC FLAGS TAG HDRHASH
-printf '%s\n' $UNITS | xargs -P "$JOBS" -I{} bash -c 'compile {}'
+if ! printf '%s\n' $UNITS | xargs -P "$JOBS" -I{} bash -c 'compile {}'; then
+    echo "build failed" >&2
+    exit 1
+fi
+for u in $UNITS; do
+    [ -f "$OBJ/$u.o" ] || { echo "build failed: $u" >&2; exit 1; }
+done
 if [ ! -f "$OBJ/spfm_schedule.o" ] || [ "$HERE/spfm_schedule.cpp" -nt "$OBJ/spfm_schedule.o" ]; then
     g++ -O2 -std=c++17 -fPIC -Wall -pthread -c "$HERE/spfm_schedule.cpp" -o "$OBJ/spfm_schedule.o"
 fi

@@ -17,7 +17,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <thread>
@@ -43,9 +46,8 @@ void build_wide_stream(int64_t, const int64_t*, const int32_t*, const std::vecto
                        const std::vector<int32_t>&, int, std::vector<int32_t>&,
                        std::vector<int32_t>&, std::vector<int32_t>&, std::vector<uint8_t>&);
 void build_pb_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
-                     const std::vector<int32_t>&, int, int, int, std::vector<int32_t>&,
-                     std::vector<int32_t>&, std::vector<uint8_t>&, std::vector<uint16_t>&,
-                     std::vector<uint8_t>&);
+                     const std::vector<int32_t>&, int, int, bool, std::vector<int32_t>&,
+                     std::vector<int32_t>&, std::vector<uint8_t>&, std::vector<uint8_t>&);
 void build_rowblock_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
                            const std::vector<int32_t>&, int, int, std::vector<int32_t>&,
                            std::vector<int32_t>&, std::vector<uint32_t>&, const uint8_t*);
@@ -77,22 +79,52 @@ using namespace spfm;
 typedef struct ncclComm* ncclComm_t;
 
 // --------------------------------------------------------------------- buffers
+// A device allocation.  Several DevBufs (of different handles) may refer to ONE allocation
+// (`share`: the matrix image and the entry streams of co-tenant fits, spfm_share_data); the
+// memory is freed with its last holder.  `alloc` on a shared buffer detaches first, so a handle
+// can never write into -- or resize under -- memory that another handle reads.
 struct DevBuf {
+    struct Block {
+        void* p;
+        std::atomic<int> refs;
+    };
+    Block* blk = nullptr;
     void* p = nullptr;
     size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (blk && blk->refs.fetch_sub(1) == 1) {
+            (void)hipFree(blk->p);
+            delete blk;
+        }
+        blk = nullptr;
         p = nullptr;
         bytes = 0;
     }
+    bool shared() const { return blk && blk->refs.load() > 1; }
     hipError_t alloc(size_t b) {
-        if (b <= bytes && p) return hipSuccess;
+        if (b <= bytes && p && !shared()) return hipSuccess;
         release();
         if (b == 0) b = 16;
-        hipError_t e = hipMalloc(&p, b);
-        if (e == hipSuccess) bytes = b;
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, b);
+        if (e != hipSuccess) return e;
+        blk = new Block{q, {1}};
+        p = q;
+        bytes = b;
         return e;
+    }
+    void share(const DevBuf& o) {  // refer to o's allocation (read-only by convention)
+        if (o.blk == blk) return;
+        release();
+        if (!o.blk) return;
+        o.blk->refs.fetch_add(1);
+        blk = o.blk;
+        p = o.p;
+        bytes = o.bytes;
     }
     template <typename U>
     U* as() const {
@@ -117,6 +149,26 @@ struct DevBuf {
 
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// Entry streams of the persistent passes, shared by the handles that share one data image
+// (spfm_share_data): whoever needs a stream first builds it (under the lock: co-tenant fits of
+// one schedule do not build it twice), the others refer to the same device buffers.  The two
+// most recent streams of each kind are kept (shuffle=True makes a new one per iteration).
+struct StreamCache {
+    std::mutex mu;
+    struct Prb {
+        std::string key;
+        DevBuf sp, erow, eval, lmask;
+        int has_long = 0;
+    };
+    struct Pb {
+        std::string key;
+        DevBuf sp, erow, eval, meta, tab;
+    };
+    std::vector<std::unique_ptr<Prb>> prb;
+    std::vector<std::unique_ptr<Pb>> pb;
+    static constexpr size_t kKeep = 2;
+};
+
 struct ProfSlot {
     std::vector<hipEvent_t> ev;  // pairs
     size_t used = 0;
@@ -138,6 +190,11 @@ struct spfm_engine {
     std::vector<int64_t> h_cptr;
     std::vector<int32_t> h_cidx;
     bool col_norm_reduced = false;
+    // several handles on one matrix (concurrent fits, spfm_share_data): the image buffers above
+    // are then shared allocations, and so are the entry streams the handles build
+    std::shared_ptr<StreamCache> scache;
+    uint64_t sched_hash = 0;  // of (order, batch_ptr): names a schedule in `scache`
+    int share_data_from(spfm_engine* src, const double* y);
 
     // params
     int n_orders = 0, k = 0;
@@ -189,6 +246,7 @@ struct spfm_engine {
     std::string pers_reason;
     unsigned spin_max = 1u << 21;  // polls of one in-kernel wait before the pass gives up
     int debug_drop = 0;            // test hook: the next N persistent launches lack a workgroup
+    bool keep_last_error = false;  // test hook (spfm_comm_init)
     bool have_pred_args = false;
     int pa_degree = 0, pa_lin = 0, pa_lower = 0;
     DevBuf snapP, snapW, snapC;
@@ -235,11 +293,11 @@ struct spfm_engine {
     int pbprb_G = 256;
     int probe_xcd = 0, probe_lds = 60 * 1024;  // diagnostics (spfm_debug_exchange_cost)
     bool pb_stream_ready = false;
-    int pb_stream_G = 0, pb_stream_NG = 0, pb_stream_ER = 0;
-    DevBuf pb_fwd, pb_drain;  // forwarding table of the persistent pbcd pass (efwd / edrain)
+    int pb_stream_G = 0, pb_stream_NG = 0;
+    DevBuf pb_tab;            // its (workgroup, step) -> slot groups map (gtab)
+    bool pb_balance = true;   // balanced slot groups (0: the fixed map slot q -> group q % NG)
     DevBuf pb_sp, pb_erow, pb_eval, pb_meta, pb_slabA, pb_slabB, pb_slabC, pb_stamps, pb_rec;
     bool pb_stamp_on = false;
-    bool pb_early = false;  // early phase of the persistent pbcd pass (measured slower; off)
     int pbprb_active = 0;  // what the last pbcd epoch used
     int pb_dbg = 0;
     DevBuf pb_dbgbuf;
@@ -557,6 +615,8 @@ struct spfm_engine {
 
     template <typename T>
     int ensure_prb();
+    template <typename T>
+    int build_prb_stream(int nb_);
 
     PrbArgs prb_args();
 
@@ -634,10 +694,11 @@ struct spfm_engine {
 
     const char* validate_pb_stream(int G, int NG, const std::vector<int32_t>& gsp,
                                    const std::vector<int32_t>& src,
-                                   const std::vector<uint8_t>& meta) const;
+                                   const std::vector<uint8_t>& meta,
+                                   const std::vector<uint8_t>& tab) const;
 
     template <typename T>
-    int ensure_pb_stream(int NG, int ER);
+    int ensure_pb_stream(int NG);
 
     template <typename T, int M, int L>
     int pbcd_prb_l(int order_idx, double beta, double gamma, double eta);

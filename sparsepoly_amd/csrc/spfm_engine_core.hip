@@ -25,6 +25,9 @@ struct Rccl {
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    const char* (*GetLastError)(ncclComm_t) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    std::string path;  // the file the symbols came from (torch's bundled copy, or ROCm's)
     bool load(std::string& err) {
         if (lib) return true;
         // 1) a copy the process already holds (PyTorch maps its own librccl.so): share it;
@@ -51,6 +54,10 @@ struct Rccl {
         AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
         CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        GetLastError = (decltype(GetLastError))dlsym(lib, "ncclGetLastError");
+        GetVersion = (decltype(GetVersion))dlsym(lib, "ncclGetVersion");
+        Dl_info info;
+        if (CommInitRank && dladdr((void*)CommInitRank, &info) && info.dli_fname) path = info.dli_fname;
         if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) {
             err = "librccl lacks a required symbol";
             return false;
@@ -242,12 +249,14 @@ int spfm_engine::set_data_t(const int64_t* indptr, const int32_t* indices, const
 
 // after the images are on the device: state shared by both ingest forms
 int spfm_engine::data_installed(const double* y) {
-    y_pm1 = true;
-    for (int64_t i = 0; i < n; ++i)
-        if (std::fabs(y[i]) != 1.0) {
-            y_pm1 = false;
-            break;
-        }
+    if (y) {  // (nullptr: the targets came from another handle, and y_pm1 with them)
+        y_pm1 = true;
+        for (int64_t i = 0; i < n; ++i)
+            if (std::fabs(y[i]) != 1.0) {
+                y_pm1 = false;
+                break;
+            }
+    }
     have_data = true;
     have_schedule = false;
     configured = false;
@@ -330,6 +339,7 @@ int spfm_engine::set_data_csr_device(const int64_t* indptr, const int32_t* indic
 // is built on the device (above) or by host threads; the CSR image is the input itself
 int spfm_engine::set_data_csr(int64_t n_, int32_t d_, const int64_t* indptr, const int32_t* indices,
                  const double* data, const double* y) {
+    scache.reset();  // a new image: nothing to share streams with (the allocations detach)
     if (n_ < 0 || d_ <= 0 || !indptr || !y) FAIL(SPFM_ERR_INVALID, "set_data: bad arguments");
     if (n_ >= (int64_t)1 << 31) FAIL(SPFM_ERR_UNSUPPORTED, "n_samples must be < 2^31");
     if (indptr[0] != 0) FAIL(SPFM_ERR_INVALID, "set_data: indptr[0] != 0");
@@ -374,6 +384,7 @@ int spfm_engine::set_data_csr(int64_t n_, int32_t d_, const int64_t* indptr, con
 
 int spfm_engine::set_data(int64_t n_, int32_t d_, const int64_t* indptr, const int32_t* indices,
              const double* data, const double* y) {
+    scache.reset();
     if (n_ < 0 || d_ <= 0 || !indptr || !y) FAIL(SPFM_ERR_INVALID, "set_data: bad arguments");
     if (n_ >= (int64_t)1 << 31) FAIL(SPFM_ERR_UNSUPPORTED, "n_samples must be < 2^31");
     if (indptr[0] != 0) FAIL(SPFM_ERR_INVALID, "set_data: indptr[0] != 0");
@@ -399,6 +410,74 @@ int spfm_engine::set_data(int64_t n_, int32_t d_, const int64_t* indptr, const i
                                  : set_data_t<double>(indptr, indices, data, y);
     if (rc) return rc;
     return data_installed(y);
+}
+
+// Several handles on ONE matrix (concurrent fits of a regularisation path, one-vs-rest targets):
+// `this` refers to src's device image -- CSC, CSR, column norms -- instead of uploading and
+// transposing its own (3 GB less per tenant on BASELINE config 2), keeps its own (yhat, y), and
+// joins src's stream cache.  The image is freed with its last holder.
+static std::mutex g_share_mu;
+int spfm_engine::share_data_from(spfm_engine* src, const double* y_) {
+    if (!src || src == this) FAIL(SPFM_ERR_INVALID, "share_data: bad source handle");
+    if (!src->have_data) FAIL(SPFM_ERR_INVALID, "share_data: the source handle has no data");
+    if (src->dtype != dtype || src->device != device)
+        FAIL(SPFM_ERR_INVALID, "share_data: both handles need the same device and storage type");
+    if (dist() || src->dist())
+        FAIL(SPFM_ERR_UNSUPPORTED, "share_data: not with a communicator attached");
+    if (have_params && src->d != d) have_params = false;
+    n = src->n;
+    d = src->d;
+    nnz = src->nnz;
+    cptr.share(src->cptr);
+    cidx.share(src->cidx);
+    cval.share(src->cval);
+    rptr.share(src->rptr);
+    ridx.share(src->ridx);
+    rval.share(src->rval);
+    col_norm.share(src->col_norm);
+    h_cptr = src->h_cptr;
+    h_cidx = src->h_cidx;
+    ingest_device_used = src->ingest_device_used;
+    HIPC(yy.alloc(tsize() * 2 * (size_t)(n > 0 ? n : 1)));
+    if (y_ && n > 0) {
+        if (dtype == SPFM_F32) {
+            std::vector<float> hy((size_t)n * 2);
+            for (int64_t i = 0; i < n; ++i) {
+                hy[(size_t)2 * i] = 0.f;
+                hy[(size_t)2 * i + 1] = (float)y_[i];
+            }
+            HIPC(hipMemcpyAsync(yy.p, hy.data(), sizeof(float) * 2 * (size_t)n,
+                                hipMemcpyHostToDevice, stream));
+            HIPC(hipStreamSynchronize(stream));
+        } else {
+            std::vector<double> hy((size_t)n * 2);
+            for (int64_t i = 0; i < n; ++i) {
+                hy[(size_t)2 * i] = 0.0;
+                hy[(size_t)2 * i + 1] = y_[i];
+            }
+            HIPC(hipMemcpyAsync(yy.p, hy.data(), sizeof(double) * 2 * (size_t)n,
+                                hipMemcpyHostToDevice, stream));
+            HIPC(hipStreamSynchronize(stream));
+        }
+    } else if (n > 0) {
+        // the source's targets; its stream may still be writing predictions next to them
+        HIPC(hipStreamSynchronize(src->stream));
+        if (dtype == SPFM_F32)
+            hipLaunchKernelGGL((copy_targets_kernel<float>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                               n, src->yy.as<float>(), yy.as<float>());
+        else
+            hipLaunchKernelGGL((copy_targets_kernel<double>), dim3(cdiv(n, 256)), dim3(256), 0,
+                               stream, n, src->yy.as<double>(), yy.as<double>());
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(stream));
+        y_pm1 = src->y_pm1;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_share_mu);
+        if (!src->scache) src->scache = std::make_shared<StreamCache>();
+        scache = src->scache;
+    }
+    return data_installed(y_);
 }
 
 // ================================================================= params
@@ -646,6 +725,18 @@ int spfm_engine::install_schedule() {
     HIPC(hipMemcpyAsync(d_bptr.p, hb.data(), sizeof(int32_t) * hb.size(),
                         hipMemcpyHostToDevice, stream));
     HIPC(hipStreamSynchronize(stream));
+    {   // FNV-1a over (order, batch_ptr): the schedule's name in a shared stream cache
+        uint64_t hsh = 1469598103934665603ull;
+        auto mix = [&](const int32_t* v, size_t cnt) {
+            for (size_t i = 0; i < cnt; ++i) {
+                hsh ^= (uint64_t)(uint32_t)v[i];
+                hsh *= 1099511628211ull;
+            }
+        };
+        mix(order.data(), order.size());
+        mix(batch_ptr.data(), batch_ptr.size());
+        sched_hash = hsh;
+    }
     have_schedule = true;
     prb_ready = false;
     pb_stream_ready = false;
@@ -1030,6 +1121,11 @@ int spfm_set_data_csr(spfm_handle h, int64_t n, int32_t d, const int64_t* indptr
     return h->set_data_csr(n, d, indptr, indices, data, y);
 }
 
+int spfm_share_data(spfm_handle dst, spfm_handle src, const double* y) {
+    GUARD(dst);
+    return dst->share_data_from(src, y);
+}
+
 int spfm_set_params(spfm_handle h, int n_orders, int k, int32_t d, const double* P,
                     const double* w, const double* lams) {
     GUARD(h);
@@ -1210,10 +1306,27 @@ int spfm_comm_init(spfm_handle h, const char* id128, int n_ranks, int rank) {
     if (!g_rccl.load(h->err)) return SPFM_ERR_RUNTIME;
     ncclUniqueId_ id;
     std::memcpy(id.internal, id128, 128);
+    // RCCL checks the HIP runtime's per-thread "last error" at several points of its set-up: an
+    // error that an EARLIER, tolerated call of this thread left there (hipFree of a foreign
+    // pointer, an occupancy query that was refused, ...) would surface as "unhandled cuda error"
+    // from ncclCommInitRank although nothing is wrong now (round 3, gpurun_out/r3_t9.log: the
+    // second communicator of a long-lived process, once).  Make sure the stream is idle and the
+    // slate is clean before handing over; report what RCCL itself recorded if it still fails.
+    (void)hipStreamSynchronize(h->stream);
+    const hipError_t stale = h->keep_last_error ? hipSuccess : hipGetLastError();
     int rc = g_rccl.CommInitRank(&h->comm, n_ranks, id, rank);
     if (rc != 0) {
+        int ver = 0;
+        if (g_rccl.GetVersion) (void)g_rccl.GetVersion(&ver);
+        const char* detail = g_rccl.GetLastError ? g_rccl.GetLastError(nullptr) : nullptr;
         h->err = std::string("ncclCommInitRank: ") +
                  (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+        if (detail && *detail) h->err += std::string(" [") + detail + "]";
+        h->err += " (librccl " + std::to_string(ver) + " from " + g_rccl.path;
+        h->err += std::string("; HIP last error now: ") + hipGetErrorString(hipPeekAtLastError());
+        if (stale != hipSuccess)
+            h->err += std::string("; cleared before the call: ") + hipGetErrorString(stale);
+        h->err += "; set NCCL_DEBUG=INFO for RCCL's own log)";
         h->comm = nullptr;
         return SPFM_ERR_RUNTIME;
     }
@@ -1463,6 +1576,8 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
             return SPFM_ERR_INVALID;
         }
         h->spin_max = (unsigned)value;
+    } else if (k == "debug_keep_last_error") {  // test hook: spfm_comm_init does not clear the
+        h->keep_last_error = value != 0;        // thread's stale HIP error before calling RCCL
     } else if (k == "debug_drop_group") {  // test hook: the next `value` persistent launches
         h->debug_drop = value;             // lack their last workgroup (they time out)
     } else if (k == "persistent_failed") {  // 0: try the persistent passes again
@@ -1512,8 +1627,9 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->wide_stamp_on = value != 0;
     } else if (k == "pbprb_stamps") {
         h->pb_stamp_on = value != 0;
-    } else if (k == "pbprb_early") {  // next step's unshared-row sums in the collect wait
-        h->pb_early = value != 0;
+    } else if (k == "pbprb_balance") {  // balanced slot groups of the persistent pbcd pass
+        h->pb_balance = value != 0;
+        h->pb_stream_ready = false;
     } else if (k == "pbprb_owners") {
         // round 3's dedicated owner workgroups: measured, no gain, removed in round 4 (their
         // pacing rule does not survive the early publish of the partial vectors)

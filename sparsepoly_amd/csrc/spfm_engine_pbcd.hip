@@ -70,12 +70,14 @@ int spfm_engine::pbcd_body_lc(int order_idx, double beta, double gamma, double e
 // slot; at most 64 columns per step.  Returns nullptr or what is wrong.
 const char* spfm_engine::validate_pb_stream(int G, int NG, const std::vector<int32_t>& gsp,
                                const std::vector<int32_t>& src,
-                               const std::vector<uint8_t>& meta) const {
+                               const std::vector<uint8_t>& meta,
+                               const std::vector<uint8_t>& tab) const {
     const int nb = n_batches();
     const size_t stride = (size_t)NG + 1;
     const int64_t rows_per = std::max<int64_t>((n + G - 1) / G, 1);
     const int qm = 64 / NG;
     if (gsp.size() != (size_t)G * nb * stride + 1) return "boundary table has the wrong size";
+    if (tab.size() != (size_t)G * (size_t)std::max(nb, 1) * 64) return "slot table has the wrong size";
     if ((int64_t)src.size() != nnz || (int64_t)meta.size() != nnz) return "entry count != nnz";
     for (int b = 0; b < nb; ++b)
         if (batch_ptr[b + 1] - batch_ptr[b] > 64) return "a step has more than 64 columns";
@@ -83,7 +85,21 @@ const char* spfm_engine::validate_pb_stream(int G, int NG, const std::vector<int
         if (gsp[t] > gsp[t + 1] || gsp[t] < 0) return "group boundaries not monotone";
     if (gsp.back() != (int32_t)nnz) return "group boundaries do not end at nnz";
     for (int g = 0; g < G; ++g)
-        for (int b = 0; b < nb; ++b)
+        for (int b = 0; b < nb; ++b) {
+            // the slot table of (g, b): every slot the kernel writes (this step's columns and
+            // those of the exchange buffer's next use) belongs to exactly one (group, t)
+            const int nc = batch_ptr[b + 1] - batch_ptr[b];
+            const int nc2 = b + 2 < nb ? batch_ptr[b + 3] - batch_ptr[b + 2] : 0;
+            const int nw = std::max(nc, nc2);
+            const uint8_t* tb = &tab[((size_t)g * nb + b) * 64];
+            int seen[64] = {0};
+            for (int z = 0; z < 64; ++z)
+                if (tb[z] != 0xFF) {
+                    if (tb[z] >= nw) return "slot table names a slot nobody reads";
+                    if (seen[tb[z]]++) return "slot table names a slot twice";
+                }
+            for (int q = 0; q < nw; ++q)
+                if (!seen[q]) return "slot table misses a slot";
             for (int grp = 0; grp < NG; ++grp) {
                 const size_t at = ((size_t)g * nb + b) * stride + (size_t)grp;
                 int prev_slot = 0;
@@ -97,10 +113,15 @@ const char* spfm_engine::validate_pb_stream(int G, int NG, const std::vector<int
                     if (slot >= qm) return "slot index >= slots per group";
                     if (slot < prev_slot) return "a group's entries are not sorted by slot";
                     prev_slot = slot;
-                    if (grp + slot * NG >= batch_ptr[b + 1] - batch_ptr[b])
-                        return "slot beyond the step's columns";
+                    const int q = tb[grp * qm + slot];
+                    if (q >= nc) return "slot beyond the step's columns";
+                    // ... and the entry really belongs to that column
+                    const int32_t j = order[(size_t)batch_ptr[b] + (size_t)q];
+                    if (pos < h_cptr[(size_t)j] || pos >= h_cptr[(size_t)j + 1])
+                        return "entry filed under another column's slot";
                 }
             }
+        }
     return nullptr;
 }
 

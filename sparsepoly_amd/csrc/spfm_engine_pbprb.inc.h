@@ -8,28 +8,48 @@ using namespace spfm;
 // entry stream (workgroup, step, slot, row) for G row blocks; shares the pcd pass's when
 // the workgroup counts agree
 template <typename T>
-int spfm_engine::ensure_pb_stream(int NG, int ER) {
+int spfm_engine::ensure_pb_stream(int NG) {
     int ncu = 0;
     HIPC(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
     const int G = std::max(1, std::min(pbprb_G, ncu));
-    if (pb_stream_ready && pb_stream_G == G && pb_stream_NG == NG && pb_stream_ER == ER)
-        return SPFM_OK;
+    if (pb_stream_ready && pb_stream_G == G && pb_stream_NG == NG) return SPFM_OK;
+    // handles that share a data image share this stream too (see ensure_prb)
+    std::unique_lock<std::mutex> cache_lock;
+    std::string ckey;
+    if (scache) {
+        ckey = fkey("pb", {}, {(int64_t)sched_hash, G, NG, (int64_t)pb_balance, (int64_t)sizeof(T),
+                               n_batches()});
+        cache_lock = std::unique_lock<std::mutex>(scache->mu);
+        for (auto& e : scache->pb)
+            if (e->key == ckey) {
+                pb_sp.share(e->sp);
+                pb_erow.share(e->erow);
+                pb_eval.share(e->eval);
+                pb_meta.share(e->meta);
+                pb_tab.share(e->tab);
+                cache_lock.unlock();
+                HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
+                HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
+                HIPC(pb_stamps.alloc(sizeof(long long) * 16 * (size_t)G));
+                HIPC(hipMemsetAsync(pb_stamps.p, 0, pb_stamps.bytes, stream));
+                HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
+                HIPC(hipStreamSynchronize(stream));
+                pb_stream_G = G;
+                pb_stream_NG = NG;
+                pb_stream_ready = true;
+                return SPFM_OK;
+            }
+    }
     std::vector<int32_t> gsp, src;
-    std::vector<uint8_t> meta, drain;
-    std::vector<uint16_t> fwd;
-    build_pb_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, G, NG, ER, gsp, src, meta,
-                    fwd, drain);
+    std::vector<uint8_t> meta, tab;
+    build_pb_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, G, NG, pb_balance, gsp, src,
+                    meta, tab);
     // every bound pbcd_prb_kernel indexes with, checked on the host for problems where that
     // is free (and on request, SPFM_VALIDATE=1): an out-of-range row or slot index would be
     // a device memory fault, i.e. a dead process
     if (nnz < ((int64_t)1 << 22) || getenv("SPFM_VALIDATE")) {
-        const char* bad = validate_pb_stream(G, NG, gsp, src, meta);
+        const char* bad = validate_pb_stream(G, NG, gsp, src, meta, tab);
         if (bad) FAIL(SPFM_ERR_RUNTIME, std::string("internal: pbcd entry stream: ") + bad);
-        // forwarding targets index the kernel's LDS row buffers
-        for (size_t e = 0; e < fwd.size(); ++e)
-            if (fwd[e] != 0 && ((fwd[e] & 0x100) == 0 || ((fwd[e] >> 4) & 15) >= NG ||
-                                (fwd[e] & 15) >= ER || (fwd[e] >> 9) != 0))
-                FAIL(SPFM_ERR_RUNTIME, "internal: pbcd entry stream: forwarding target out of range");
     }
     DevBuf d_src;
     HIPC(d_src.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
@@ -37,9 +57,8 @@ int spfm_engine::ensure_pb_stream(int NG, int ER) {
     HIPC(pb_erow.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1) + 256));
     HIPC(pb_eval.alloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1) + 256));
     HIPC(pb_meta.alloc((size_t)(nnz > 0 ? nnz : 1) + 256));
-    HIPC(pb_fwd.alloc(sizeof(uint16_t) * ((size_t)(nnz > 0 ? nnz : 1) + 256)));
-    HIPC(pb_drain.alloc(drain.size() + 16));
-    HIPC(hipMemcpyAsync(pb_drain.p, drain.data(), drain.size(), hipMemcpyHostToDevice, stream));
+    HIPC(pb_tab.alloc(tab.size() + 16));
+    HIPC(hipMemcpyAsync(pb_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice, stream));
     HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
     HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
     HIPC(pb_stamps.alloc(sizeof(long long) * 16 * (size_t)G));
@@ -52,17 +71,25 @@ int spfm_engine::ensure_pb_stream(int NG, int ER) {
                             hipMemcpyHostToDevice, stream));
         HIPC(hipMemcpyAsync(pb_meta.p, meta.data(), (size_t)nnz, hipMemcpyHostToDevice,
                             stream));
-        HIPC(hipMemcpyAsync(pb_fwd.p, fwd.data(), sizeof(uint16_t) * (size_t)nnz,
-                            hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL((prb_gather_kernel<T>), dim3(cdiv(nnz, 256)), dim3(256), 0, stream,
                            nnz, d_src.as<int32_t>(), cidx.as<int32_t>(), cval.as<T>(),
                            pb_erow.as<int32_t>(), pb_eval.as<T>());
         HIPC(hipGetLastError());
     }
     HIPC(hipStreamSynchronize(stream));
+    if (scache) {
+        auto e = std::make_unique<StreamCache::Pb>();
+        e->key = ckey;
+        e->sp.share(pb_sp);
+        e->erow.share(pb_erow);
+        e->eval.share(pb_eval);
+        e->meta.share(pb_meta);
+        e->tab.share(pb_tab);
+        scache->pb.insert(scache->pb.begin(), std::move(e));
+        if (scache->pb.size() > StreamCache::kKeep) scache->pb.pop_back();
+    }
     pb_stream_G = G;
     pb_stream_NG = NG;
-    pb_stream_ER = ER;
     pb_stream_ready = true;
     return SPFM_OK;
 }
@@ -72,7 +99,7 @@ int spfm_engine::pbcd_prb_l(int order_idx, double beta, double gamma, double eta
     const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
     double* Po = Pt.as<double>() + (size_t)order_idx * k * d;  // (d,k)
     RegState rs = regstate();
-    int rc = ensure_pb_stream<T>(kPbPrbThreads / L, pbprb_er<T, M>());
+    int rc = ensure_pb_stream<T>(kPbPrbThreads / L);
     if (rc) return rc;
     const int G = pb_stream_G;
     // the rows' state as packed records (cache values, yhat, y: one line per row at k <= 30,
@@ -90,9 +117,9 @@ int spfm_engine::pbcd_prb_l(int order_idx, double beta, double gamma, double eta
                            reg, rs);
     }
     HIPC(pb_slabA.alloc(sizeof(double) * 2 * 64 * (size_t)G * L));
-    HIPC(pb_slabB.alloc(sizeof(double) * 3 * 64 * L));  // triple-buffered (early publish)
+    HIPC(pb_slabB.alloc(sizeof(double) * 2 * 64 * L));
     HIPC(hipMemsetAsync(pb_slabA.p, 0, sizeof(double) * 2 * 64 * (size_t)G * L, stream));
-    HIPC(hipMemsetAsync(pb_slabB.p, 0, sizeof(double) * 3 * 64 * L, stream));
+    HIPC(hipMemsetAsync(pb_slabB.p, 0, sizeof(double) * 2 * 64 * L, stream));
     {
         int prc = peer_clear(kPeerPbOff, kPeerProbeOff - kPeerPbOff);
         if (prc) return prc;
@@ -105,8 +132,7 @@ int spfm_engine::pbcd_prb_l(int order_idx, double beta, double gamma, double eta
     a.gsp = pb_sp.as<int32_t>();
     a.erow = pb_erow.as<int32_t>();
     a.emeta = pb_meta.as<uint8_t>();
-    a.efwd = pb_fwd.as<uint16_t>();
-    a.edrain = pb_drain.as<uint8_t>();
+    a.gtab = pb_tab.as<uint8_t>();
     a.slabA = pb_slabA.as<double>();
     a.slabB = pb_slabB.as<double>();
     a.rows_per = (int)std::max<int64_t>((n + G - 1) / G, 1);
@@ -129,37 +155,32 @@ int spfm_engine::pbcd_prb_l(int order_idx, double beta, double gamma, double eta
     a.dbg_out = pb_dbgbuf.as<unsigned>();
     const int ncache = top_degree > 0 ? top_degree + 1 : 1;
     prof_begin(2, nnz);
-    auto go = [&](auto stamp_tag, auto early_tag) -> int {
+    auto go = [&](auto stamp_tag) -> int {
         constexpr bool STc = decltype(stamp_tag)::value;
-        constexpr bool EAc = decltype(early_tag)::value;
-        const size_t lds = std::max(kPrbLds, pbcd_prb_lds_bytes<T, M, L, EAc>());
-        HIPC(hipFuncSetAttribute((const void*)pbcd_prb_kernel<T, M, L, STc, EAc>,
+        const size_t lds = std::max(kPrbLds, pbcd_prb_lds_bytes<T, M, L>());
+        HIPC(hipFuncSetAttribute((const void*)pbcd_prb_kernel<T, M, L, STc>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (!resident_ok((const void*)pbcd_prb_kernel<T, M, L, STc, EAc>, kPbPrbThreads, lds, G))
+        if (!resident_ok((const void*)pbcd_prb_kernel<T, M, L, STc>, kPbPrbThreads, lds, G))
             return kNotResident;
-        hipLaunchKernelGGL((pbcd_prb_kernel<T, M, L, STc, EAc>), dim3(launch_groups(G)),
+        hipLaunchKernelGGL((pbcd_prb_kernel<T, M, L, STc>), dim3(launch_groups(G)),
                            dim3(kPbPrbThreads), lds, stream, a, pb_eval.as<T>(), pb_rec.as<T>(), Po,
                            k, d, lams.as<double>(), loss, reg, rs, ncache, mu, beta, gamma, eta,
                            prb_viol.as<double>());
         return SPFM_OK;
     };
-    // the diagnostic (timer) instantiations and the early-phase variant (option "pbprb_early":
-    // measured slower on one GPU) exist for float storage, degree 2, k <= 30
+    // the diagnostic (timer) instantiation exists for float storage, degree 2, k <= 30
     constexpr bool can_stamp = std::is_same<T, float>::value && M == 2 && L == 32;
-    if ((pb_stamp_on || pb_early) && !can_stamp)
-        FAIL(SPFM_ERR_UNSUPPORTED,
-             "pbprb_stamps / pbprb_early: built for float storage, degree 2, k <= 30");
+    if (pb_stamp_on && !can_stamp)
+        FAIL(SPFM_ERR_UNSUPPORTED, "pbprb_stamps: built for float storage, degree 2, k <= 30");
     rc = SPFM_OK;
     bool fired = false;
     if constexpr (can_stamp) {
-        if (pb_stamp_on || pb_early) {
-            rc = pb_early ? (pb_stamp_on ? go(std::true_type{}, std::true_type{})
-                                         : go(std::false_type{}, std::true_type{}))
-                          : go(std::true_type{}, std::false_type{});
+        if (pb_stamp_on) {
+            rc = go(std::true_type{});
             fired = true;
         }
     }
-    if (!fired) rc = go(std::false_type{}, std::false_type{});
+    if (!fired) rc = go(std::false_type{});
     if (rc == kNotResident) prof_cancel(2, nnz);
     if (rc) return rc;
     prof_end(2);

@@ -120,10 +120,67 @@ int spfm_engine::ensure_prb() {
     HIPC(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
     if (prb_G > ncu) prb_G = ncu;
     if (prb_G < 1) prb_G = 1;
-    // the entry stream: on the device (spfm_ingest.hip device_rowblock_stream: two binary
-    // searches per (column, row block), a scan, a fill -- the host builder's sp / src / lmask
-    // exactly, tests/test_hip_stream.py), or by the host threads (stream_device=0, no room)
     const int nb_ = n_batches();
+    // handles that share a data image (spfm_share_data) share this stream too: the first one to
+    // need it builds it under the cache's lock, the others refer to its buffers
+    std::unique_lock<std::mutex> cache_lock;
+    std::string ckey;
+    bool hit = false;
+    if (scache) {
+        ckey = fkey("prb", {}, {(int64_t)sched_hash, prb_G, prb_long, (int64_t)sizeof(T), nb_});
+        cache_lock = std::unique_lock<std::mutex>(scache->mu);
+        for (auto& e : scache->prb)
+            if (e->key == ckey) {
+                prb_sp.share(e->sp);
+                prb_erow.share(e->erow);
+                prb_eval.share(e->eval);
+                prb_lmask.share(e->lmask);
+                prb_has_long = e->has_long;
+                stream_device_used = 2;  // = taken from a co-tenant
+                hit = true;
+                break;
+            }
+    }
+    if (!hit) {
+        int rc = build_prb_stream<T>(nb_);
+        if (rc) return rc;
+        if (scache) {
+            auto e = std::make_unique<StreamCache::Prb>();
+            e->key = ckey;
+            e->sp.share(prb_sp);
+            e->erow.share(prb_erow);
+            e->eval.share(prb_eval);
+            e->lmask.share(prb_lmask);
+            e->has_long = prb_has_long;
+            scache->prb.insert(scache->prb.begin(), std::move(e));
+            if (scache->prb.size() > StreamCache::kKeep) scache->prb.pop_back();
+        }
+    }
+    if (cache_lock.owns_lock()) cache_lock.unlock();
+    // the handle's own buffers
+    HIPC(prb_slab.alloc(sizeof(double) * 2 * ((size_t)prb_G + 1) * 64 * 2));
+    HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
+    HIPC(prow_old.alloc(sizeof(double) * (size_t)d));
+    HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
+    HIPC(prb_cn.alloc(sizeof(double) * (size_t)d));
+    HIPC(prb_stamps.alloc(sizeof(long long) * 16 * (size_t)prb_G));
+    HIPC(hipMemsetAsync(prb_stamps.p, 0, prb_stamps.bytes, stream));
+    HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
+    HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));
+    hipLaunchKernelGGL(gather_sched_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
+                       d_desc.as<ColDesc>(), col_norm.as<double>(), prb_cn.as<double>());
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(stream));
+    prb_ready = true;
+    return SPFM_OK;
+}
+
+// the entry stream of the 64-column passes (sp, erow, eval, lmask): on the device
+// (spfm_ingest.hip device_rowblock_stream: two binary searches per (column, row block), a scan,
+// a fill -- the host builder's sp / src / lmask exactly, tests/test_hip_stream.py), or by the
+// host threads (stream_device=0, no room)
+template <typename T>
+int spfm_engine::build_prb_stream(int nb_) {
     const size_t nsp = (size_t)prb_G * nb_ * 65 + 1;
     DevBuf d_src;
     HIPC(d_src.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
@@ -155,15 +212,6 @@ int spfm_engine::ensure_prb() {
     }
     HIPC(prb_erow.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
     HIPC(prb_eval.alloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1)));
-    HIPC(prb_slab.alloc(sizeof(double) * 2 * ((size_t)prb_G + 1) * 64 * 2));
-    HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
-    HIPC(prow_old.alloc(sizeof(double) * (size_t)d));
-    HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
-    HIPC(prb_cn.alloc(sizeof(double) * (size_t)d));
-    HIPC(prb_stamps.alloc(sizeof(long long) * 16 * (size_t)prb_G));
-    HIPC(hipMemsetAsync(prb_stamps.p, 0, prb_stamps.bytes, stream));
-    HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
-    HIPC(hipMemsetAsync(prb_slab.p, 0, prb_slab.bytes, stream));
     if (!stream_device_used)
         HIPC(hipMemcpyAsync(prb_sp.p, sp.data(), sizeof(int32_t) * sp.size(),
                             hipMemcpyHostToDevice, stream));
@@ -176,11 +224,7 @@ int spfm_engine::ensure_prb() {
                            prb_erow.as<int32_t>(), prb_eval.as<T>());
         HIPC(hipGetLastError());
     }
-    hipLaunchKernelGGL(gather_sched_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, d,
-                       d_desc.as<ColDesc>(), col_norm.as<double>(), prb_cn.as<double>());
-    HIPC(hipGetLastError());
-    HIPC(hipStreamSynchronize(stream));
-    prb_ready = true;
+    HIPC(hipStreamSynchronize(stream));  // the host staging vectors and d_src die here
     return SPFM_OK;
 }
 

@@ -50,8 +50,13 @@ namespace spfm {
 // and the identical update; nothing else crosses GPUs.
 //
 // Threads.  512 = NG groups of L lanes (L = 32 for k <= 30, 64 for k <= 62; lane =
-// component).  Slot q belongs to group q % NG; the host sorts a (workgroup, step)'s entries by
-// (group, slot, row), so a group's entries are one contiguous run (`gsp`).
+// component).  Which group handles which slot is the host's choice per (workgroup, step)
+// (`gtab`, round 4: columns dealt to the groups by their entry counts, so that no group has
+// many more entries than the others -- every step waits for the busiest group of the busiest
+// workgroup: 14.9 entries on BASELINE config 4 with the fixed map "slot q -> group q % NG", 6.5
+// with the balanced one, against a mean of 4.4); the host sorts a (workgroup, step)'s entries
+// by (group, slot position in the group, row), so a group's entries are one contiguous run
+// (`gsp`).
 //
 // Software pipeline (everything a step needs is in registers when it starts):
 //   entries    lane-parallel (lane u <-> entry u of the group: row, x, slot, yhat_i, y_i),
@@ -75,15 +80,11 @@ struct PbPrbArgs {
     const int32_t* jsched; // [d] column ids in visiting order
     const int32_t* gsp;    // [G][nb][NG+1] group boundaries into the entry stream
     const int32_t* erow;   // entry rows, sorted by (workgroup, step, group, slot, row)
-    const uint8_t* emeta;  // slot index inside the group | 0x80 (row touched by previous step)
-                           // | 0x40 (... and its new record arrives through LDS, see efwd)
-    const uint16_t* efwd;  // 0x100 | group << 4 | entry: where the NEXT step has this entry's row
-                           // in its LDS row buffer (the scatter writes the new record there too);
-                           // 0: the next step does not touch the row (or not on its fast path)
-    const uint8_t* edrain; // [G][nb] 1: the step's end barrier must drain the scatter stores (the
-                           // next step reads one of its rows from global memory)
+    const uint8_t* emeta;  // slot position t inside the group | 0x80 (row touched by previous step)
+    const uint8_t* gtab;   // [G][nb][64] slot of (group, t) = gtab[.. + group * QM + t], 0xFF: none --
+                           // the host's balanced map of a (workgroup, step)'s columns to groups
     double* slabA;         // [2][64][G][L] partial vectors
-    double* slabB;         // [3][64][L]    published block updates (triple-buffered by step)
+    double* slabB;         // [2][64][L]    published block updates
     int rows_per, n_rows;
     unsigned* abort_flag;
     unsigned spin_max;     // polls of one wait before the pass gives up (default 2^21)
@@ -96,8 +97,7 @@ struct PbPrbArgs {
 
 constexpr int kPbPrbThreads = 512;
 
-// entries of a slot group whose rows are staged in LDS (64 KB for the two row buffers); the
-// host's stream builder needs it for the forwarding table (efwd / edrain)
+// entries of a slot group whose rows are staged in LDS (64 KB for the two row buffers)
 template <typename T, int M>
 constexpr int pbprb_er() {
     constexpr int ER0 = (int)(16 * 4 / sizeof(T)) / Kind<M>::AS;
@@ -337,38 +337,21 @@ __global__ void pbprb_unpack_kernel(int64_t n, const T* __restrict__ R, T* __res
     if (i < n) yy[2 * (size_t)i] = R[(size_t)i * AS * L + (L - 2)];
 }
 
+// (Round 4, measured and not kept -- docs/HISTORY.md: an "early phase" that formed the next
+// step's sums for the unshared rows during the collect wait, 35.0 vs 27.6 ms per epoch: the
+// slot owners have no wait to fill, and they set the pace; the new records of rows shared by
+// consecutive steps forwarded through LDS instead of a global round trip: phase 0 0.77 -> 0.48
+// us, but the kernel is bound by its instruction count and the table look-ups cost more in the
+// scatter and the prefetch than the round trip; a scatter that took four entries at a time with
+// one butterfly for their prediction decrements; round 3's dedicated owner workgroups.)
 template <typename T>
 struct PbESet {  // lane u <-> entry e0 + u of the group (u < min(cnt, L))
     int e0, cnt;
-    int row, meta;  // meta: emeta | efwd << 8
+    int row, meta;
     T x;
 };
 
-// tag of a slabB word: the published block updates are TRIPLE-buffered by step (see "early
-// publish" below), consecutive uses of one buffer (b, b+3, b+6) carry different tags
-__device__ __forceinline__ unsigned long long pb_tag3(int b) {
-    return (unsigned long long)(((b / 3) % 3) + 1);
-}
-
-// EARLY (round 4; L = 32, i.e. k <= 30: LDS has room for the parked accumulators).  A step's
-// critical path used to be: scatter -> rows this step shares with the last one -> partial sums of
-// ALL entries -> publish -> owners -> collect -> chain -> scatter, with every workgroup idle in
-// the collect poll for ~3.5 us.  98 % of a step's entries sit on rows the previous step does not
-// touch: their rows are staged in LDS one step ahead anyway, so their part of the sums
-// (pbcd.py:56-67) is formed DURING the previous step's collect wait ("early phase"), and
-//   * a slot group none of whose entries is on a shared row publishes its vectors right then --
-//     one step ahead, off the critical path, and spread out in time instead of one burst of 2 MB;
-//   * a group that does have shared rows (or more entries than LDS row slots) parks its
-//     accumulators in LDS, adds the shared rows after the scatter and publishes then.
-// Early publishing lets a workgroup run one step further ahead of the slowest one than before
-// (it publishes step b+1 before it has collected step b), so slabB -- written by owners, read
-// by everybody -- is triple-buffered: the buffer of step b+1 was last used by step b-2, which
-// every workgroup has collected once all partial vectors of step b+1's slot are in.  slabA (and
-// the cross-GPU slabC) stay double-buffered: a workgroup writes step b+1's partial vectors
-// after it has collected step b-1, by when the owners are done with that parity's buffer.
-// The sums are formed in a fixed order (unshared rows in row order, then shared rows in row
-// order): deterministic, association differs from the row-order sum by rounding only.
-template <typename T, int M, int L, bool STAMP = false, bool EARLY = false>
+template <typename T, int M, int L, bool STAMP = false>
 __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     PbPrbArgs a, const T* __restrict__ eval, T* __restrict__ R /* packed row records */,
     double* __restrict__ P /* (d,k) */, int k, int d, const double* __restrict__ lams, int loss,
@@ -378,22 +361,18 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     constexpr int QM = 64 / NG;            // slots per group (<= 64 slots per step)
     constexpr int AS = Kind<M>::AS;
     constexpr int NW = kPbPrbThreads / 64;  // waves
-    static_assert(!EARLY || L == 32, "the early phase parks its accumulators in LDS: k <= 30 only");
     constexpr int ER = pbprb_er<T, M>();
-    static_assert(ER <= 16 && NG <= 16, "efwd packs (group, entry) into 4 + 4 bits");
     using ESet = PbESet<T>;
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
     double* sh_red = dyn_lds;                    // [2][NG][L] owner part sums
     double* sh_pt = dyn_lds + 2 * NG * L;        // [64][L] published vectors of the step
     double* sh_scal = sh_pt + 64 * L;            // [64][4] l2, st0, f, -
-    double2* sh_xd = reinterpret_cast<double2*>(sh_scal + 256);  // [2][NG][L] (x, dloss) per entry
-    double* sh_cache = sh_scal + 256 + 4 * NG * L;  // [2][kMaxDegree+2] regularizer cache, dcache
+    double2* sh_xd = reinterpret_cast<double2*>(sh_scal + 256);  // [NG][L] (x, dloss) per entry
+    double* sh_cache = sh_scal + 256 + 2 * NG * L;  // [2][kMaxDegree+2] regularizer cache, dcache
     int2* sh_rm = reinterpret_cast<int2*>(sh_cache + 2 * (kMaxDegree + 2));  // [2][NG][L] (row, meta)
     int* sh_ok = reinterpret_cast<int*>(sh_rm + 2 * NG * L);
-    // parked accumulators [2 * QM][threads] (EARLY), then the row buffers [2][NW][ER][AS][64]: a
-    // wave's slice is written lane-linearly by LDS-DMA
-    double* sh_acc = reinterpret_cast<double*>(sh_ok + 4);
-    T* sh_rows = reinterpret_cast<T*>(sh_acc + (EARLY ? 2 * QM * kPbPrbThreads : 0));
+    // row buffers [2][NW][ER][AS][64]: a wave's slice is written lane-linearly by LDS-DMA
+    T* sh_rows = reinterpret_cast<T*>(sh_ok + 4);
     const int g = (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid % L, grp = tid / L;
     const int wlane = tid & 63, wave = tid >> 6;
@@ -437,16 +416,15 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         s.cnt = e1 - e0;
         const bool v = lane < s.cnt;
         s.row = v ? a.erow[e0 + lane] : 0;
-        s.meta = v ? ((int)a.emeta[e0 + lane] | ((int)a.efwd[e0 + lane] << 8)) : 0;
+        s.meta = v ? (int)a.emeta[e0 + lane] : 0;
         s.x = v ? eval[e0 + lane] : (T)0;
     };
     auto rows_at = [&](int par, int u, int t) __attribute__((always_inline)) -> T* {
         return sh_rows + ((((size_t)par * NW + wave) * ER + u) * AS + t) * 64;
     };
     // packed rows of a set (-> LDS buffer `par`); hz = 0: the entries not flagged, 1: the flagged
-    // ones whose record does not come through LDS (0x80 without 0x40; after the barrier that ends
-    // the step which updated them).  Every lane fetches its own element of the record: the
-    // group's L lanes take one contiguous, aligned slice.
+    // ones (after the barrier that ends the step which updated them).  Every lane fetches its own
+    // element of the record: the group's L lanes take one contiguous, aligned slice.
     auto fetch_rows = [&](ESet& s, int par, int hz) __attribute__((always_inline)) {
         const int2* rm_ = sh_rm + par * NG * L + gb;
         const int nf = min(s.cnt, ER);
@@ -463,7 +441,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
 #pragma unroll
             for (int uu = 0; uu < 4; ++uu) {
                 const int u = ub + uu;
-                if (u < nf && (rm[uu].y & 0xC0) == (hz ? 0x80 : 0x00)) {
+                if (u < nf && ((rm[uu].y >> 7) & 1) == hz) {
                     const size_t base = (size_t)rm[uu].x * rowlen + lane;
 #pragma unroll
                     for (int t = 0; t < AS; ++t) {
@@ -492,91 +470,24 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     auto col_id = [&](int c, int ncols_of, int q) __attribute__((always_inline)) -> int {
         return (q >= 0 && q < ncols_of) ? a.jsched[c + q] : -1;
     };
-    // the group's lanes' bits of a ballot (lane u of the group <-> bit u)
-    auto group_bits = [&](unsigned long long bal) __attribute__((always_inline)) -> unsigned long long {
-        return (L == 64) ? bal : ((bal >> (32 * (grp & 1))) & 0xffffffffull);
+    // the slots of the group's QM positions at a step: QM bytes, 0xFF = none (PbPrbArgs::gtab)
+    struct SlotIds {
+        unsigned w[QM / 4];
     };
-    // the group's fast entries are sorted by slot: segment t = [seg[t], seg[t+1]) (one ballot per
-    // slot on the lane-parallel slot indices), so the slot's p_j is a static register
-    auto segments = [&](const ESet& s, int nfast, int (&seg)[QM + 1]) __attribute__((always_inline)) {
-        seg[0] = 0;
+    auto load_slots = [&](int b) __attribute__((always_inline)) -> SlotIds {
+        SlotIds r;
 #pragma unroll
-        for (int t = 0; t < QM; ++t)
-            seg[t + 1] = __builtin_popcountll(
-                group_bits(__ballot(lane < nfast && (s.meta & 7) <= t)));
-    };
-    // fast entries of the set that sit on a row the previous step updates (host flag 0x80)
-    auto hazard_bits = [&](const ESet& s, int nfast) __attribute__((always_inline)) -> unsigned long long {
-        return group_bits(__ballot(lane < nfast && (s.meta & 0x80) != 0));
-    };
-    // (sum dloss * dA, sum dA^2) contribution of the group's fast entry u (buffers of parity q)
-    auto entry_sums = [&](int q, int u, double p, double& gacc, double& hacc)
-                          __attribute__((always_inline)) {
-        const double2 xd = sh_xd[q * NG * L + gb + u];
-        double ad[AS];
+        for (int i = 0; i < QM / 4; ++i) r.w[i] = 0xFFFFFFFFu;
+        if (b < a.nb) {
+            const unsigned* p =
+                reinterpret_cast<const unsigned*>(a.gtab + ((size_t)g * a.nb + b) * 64 + grp * QM);
 #pragma unroll
-        for (int tt = 0; tt < AS; ++tt) ad[tt] = (double)rows_at(q, u, tt)[wlane];
-        const double dprev = kl ? grad_factor<M>(ad, xd.x, p) : 0.0;
-        gacc += xd.y * dprev;
-        hacc += dprev * dprev;
-    };
-    // the group's QM vectors (slots grp + t * NG) -> slabA: sum_s inv_step_sizes[s]
-    // (pbcd.py:68-70) of the QM slots by one butterfly: lane l ends with the sum of slot
-    // (l & (QM-1)); lane L-2 of slot t's vector needs slot t.  Slots beyond the step's columns
-    // but below `nw_` are rewritten with zeros (stale-tag rule).
-    auto publish_vectors = [&](const double (&gs)[QM], const double (&hs)[QM], double* slabA_,
-                               int nw_, unsigned long long tag_) __attribute__((always_inline)) {
-        double hv[QM];
-#pragma unroll
-        for (int t = 0; t < QM; ++t) hv[t] = hs[t];
-        const double hr = pb_multi_reduce<QM, L>(hv, lane);
-#pragma unroll
-        for (int t = 0; t < QM; ++t) {
-            const int q = grp + t * NG;
-            const double hsum = pb_bcast<L>(hr, t, grp);
-            if (q < nw_) {
-                const double v = (lane == L - 2) ? hsum : (kl ? gs[t] : 0.0);
-                prb_store_granule(slabA_ + ((size_t)q * a.G + g) * L + lane, v, tag_);
-            }
+            for (int i = 0; i < QM / 4; ++i) r.w[i] = p[i];
         }
+        return r;
     };
-    // EARLY phase for the entry set `s` of a step (buffers of parity q, the slots' blocks pp[]):
-    // dloss of the entries on unshared rows, their part of the sums; published if the group has
-    // no shared row (and no entry beyond the LDS row slots), else parked
-    auto early_phase = [&](const ESet& s, int q, const double (&pp)[QM], double* slabA_, int nw_,
-                           unsigned long long tag_) __attribute__((always_inline)) {
-        const int nf = min(s.cnt, ER);
-        {
-            double dl = 0.0;
-            if (lane < nf && (s.meta & 0x80) == 0) {
-                const T* r0 = rows_at(q, lane, 0) + (wlane - lane);
-                dl = dloss_dev(loss, (double)r0[L - 2], (double)r0[L - 1]);
-            }
-            sh_xd[q * NG * L + gb + lane] = make_double2((double)s.x, dl);
-        }
-        wave_lds_sync();
-        int seg[QM + 1];
-        segments(s, nf, seg);
-        const unsigned long long hzb = hazard_bits(s, nf);
-        double gs[QM], hs[QM];
-#pragma unroll
-        for (int t = 0; t < QM; ++t) {
-            double gacc = 0.0, hacc = 0.0;
-            const double p = pp[t];
-            for (int u = seg[t]; u < seg[t + 1]; ++u)
-                if (((hzb >> u) & 1ull) == 0) entry_sums(q, u, p, gacc, hacc);
-            gs[t] = gacc;
-            hs[t] = hacc;
-        }
-        if (hzb == 0ull && s.cnt <= ER) {
-            publish_vectors(gs, hs, slabA_, nw_, tag_);
-        } else {
-#pragma unroll
-            for (int t = 0; t < QM; ++t) {
-                sh_acc[(2 * t) * kPbPrbThreads + tid] = gs[t];
-                sh_acc[(2 * t + 1) * kPbPrbThreads + tid] = hs[t];
-            }
-        }
+    auto slot_of = [&](const SlotIds& sl, int t) __attribute__((always_inline)) -> int {
+        return (int)((sl.w[t >> 2] >> (8 * (t & 3))) & 0xFFu);
     };
 
     int c0 = a.bptr[0], c1 = a.bptr[min(1, a.nb)];
@@ -596,13 +507,15 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         wave_lds_sync();
         fetch_rows(cur, 0, 0);  // step 0: nothing is flagged
     }
-    // slot data: column ids of steps b, b+1 (b+2 loaded inside the loop); P rows of step b
+    // slot data: the group's slots of steps b .. b+2 (b+3 loaded inside the loop), their column
+    // ids of steps b, b+1 (b+2 loaded inside the loop); P rows of step b
+    SlotIds qs0 = load_slots(0), qs1 = load_slots(1), qs2 = load_slots(2);
     int j0[QM], j1[QM];
     double po[QM], pon[QM];
 #pragma unroll
     for (int t = 0; t < QM; ++t) {
-        j0[t] = col_id(c0, c1 - c0, grp + t * NG);
-        j1[t] = col_id(c1, c2 - c1, grp + t * NG);
+        j0[t] = col_id(c0, c1 - c0, slot_of(qs0, t));
+        j1[t] = col_id(c1, c2 - c1, slot_of(qs1, t));
         po[t] = (j0[t] >= 0 && kl) ? P[(size_t)j0[t] * k + lane] : 0.0;
         pon[t] = 0.0;
     }
@@ -617,107 +530,105 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     double cn0 = (cj0 >= 0 && chained) ? rs.norms[cj0] : 0.0, cn1 = 0.0;
     int cjp = -1;           // chain: column of the previous step held by this lane ...
     double l2n_prev = 0.0;  // ... and its new block norm, stored one step late
-    if constexpr (EARLY) {
-        // step 0's early phase (no step in front of it: nothing is flagged)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_lds_sync();
-        early_phase(cur, 0, po, a.slabA, max(c1 - c0, c3 - c2), prb_tag(0));
-    }
     __syncthreads();
 
     for (int b = 0; b < a.nb; ++b) {
         const int ncols = c1 - c0;
-        const int c4 = a.bptr[min(b + 4, a.nb)];
+        const int c4 = a.bptr[min(b + 4, a.nb)];  // used from the next iteration on
         // slots written this step: this step's and those of the buffer's next use, so that a
-        // word read at the next use was rewritten now (its tag is never that use's): slabA /
-        // slabC are double-buffered (next use b+2), slabB is triple-buffered (next use b+3)
+        // word read at step b+2 was rewritten at step b (its tag is never tag(b+2))
         const int nw = max(ncols, c3 - c2);
-        const int nwB = max(ncols, c4 - c3);
         const unsigned long long tag = prb_tag(b);
-        const unsigned long long tagB = pb_tag3(b);
         const int par = b & 1;
         double* slabA = a.slabA + (size_t)par * 64 * a.G * L;
-        double* slabB = a.slabB + (size_t)(b % 3) * 64 * L;
-        const bool drain_now = a.edrain[(size_t)g * a.nb + b] != 0;  // (workgroup-uniform)
+        double* slabB = a.slabB + (size_t)par * 64 * L;
         const int2* srm = sh_rm + par * NG * L + gb;  // (row, meta) of the group's entries
-        const double2* sxd = sh_xd + par * NG * L + gb;
         const int nfast = min(cur.cnt, ER);
 
-        // ---- phase 0: rows this step shares with the previous one (after its barrier): their
-        // new records were written into this step's row buffer by the previous step's scatter
-        // (efwd); the rare ones that were not (an entry beyond the LDS row slots on either side)
-        // come from global memory -- the previous step's end barrier drained its stores (edrain)
-        if (__ballot(lane < nfast && (cur.meta & 0xC0) == 0x80) != 0ull) {
-            fetch_rows(cur, par, 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed in LDS
-        }
+        // ---- phase 0: rows this step shares with the previous one (after its barrier)
+        fetch_rows(cur, par, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed in LDS
         wave_lds_sync();
         {   // lane u <-> entry u: dloss from the record's (yhat, y) (lanes L-2, L-1 of slice 0),
-            // with x -> LDS for the group's broadcast reads.  EARLY: only the shared rows are
-            // new, the other entries' values are there since the early phase.
-            if (lane < nfast && (!EARLY || (cur.meta & 0x80) != 0)) {
+            // with x -> LDS for the group's broadcast reads
+            double dl = 0.0;
+            if (lane < nfast) {
                 const T* r0 = rows_at(par, lane, 0) + (wlane - lane);
-                const double dl = dloss_dev(loss, (double)r0[L - 2], (double)r0[L - 1]);
-                sh_xd[par * NG * L + gb + lane] = make_double2((double)cur.x, dl);
-            } else if (!EARLY) {
-                sh_xd[par * NG * L + gb + lane] = make_double2((double)cur.x, 0.0);
+                dl = dloss_dev(loss, (double)r0[L - 2], (double)r0[L - 1]);
             }
+            sh_xd[gb + lane] = make_double2((double)cur.x, dl);
         }
         wave_lds_sync();
         PB_STAMP(0)
         // ---- phase 1: partial sums of the own rows (pbcd.py:56-67), published per slot
+        double gs[QM], hs[QM];
+#pragma unroll
+        for (int t = 0; t < QM; ++t) {
+            gs[t] = 0.0;
+            hs[t] = 0.0;
+        }
+        // the group's fast entries are sorted by slot: segment t = [seg[t], seg[t+1]) (one ballot
+        // per slot on the lane-parallel slot indices), so the slot's p_j is a static register
         int seg[QM + 1];
-        segments(cur, nfast, seg);
-        const unsigned long long hzb = EARLY ? hazard_bits(cur, nfast) : 0ull;
-        if (!EARLY || hzb != 0ull || cur.cnt > ER) {
-            double gs[QM], hs[QM];
-            if constexpr (EARLY) {
+        seg[0] = 0;
 #pragma unroll
-                for (int t = 0; t < QM; ++t) {
-                    gs[t] = sh_acc[(2 * t) * kPbPrbThreads + tid];
-                    hs[t] = sh_acc[(2 * t + 1) * kPbPrbThreads + tid];
-                }
-                // the entries on shared rows, in row order inside their slot
+        for (int t = 0; t < QM; ++t) {
+            const unsigned long long bal = __ballot(lane < nfast && (cur.meta & 7) <= t);
+            seg[t + 1] = (L == 64) ? __builtin_popcountll(bal)
+                                   : __builtin_popcount((unsigned)(bal >> (32 * (grp & 1))));
+        }
 #pragma unroll
-                for (int t = 0; t < QM; ++t) {
-                    double gacc = 0.0, hacc = 0.0;
-                    const double p = po[t];
-                    for (int u = seg[t]; u < seg[t + 1]; ++u)
-                        if (((hzb >> u) & 1ull) != 0) entry_sums(par, u, p, gacc, hacc);
-                    gs[t] += gacc;
-                    hs[t] += hacc;
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < QM; ++t) {
-                    double gacc = 0.0, hacc = 0.0;
-                    const double p = po[t];
-                    for (int u = seg[t]; u < seg[t + 1]; ++u) entry_sums(par, u, p, gacc, hacc);
-                    gs[t] = gacc;
-                    hs[t] = hacc;
-                }
-            }
-            for (int u = ER; u < cur.cnt; ++u) {  // slow path: beyond the LDS-staged rows
-                const int e = cur.e0 + u;
-                const int i = a.erow[e];
-                const int qi = (int)a.emeta[e] & 7;
-                const double x = (double)eval[e];
-                const T* ri = R + (size_t)i * rowlen;
-                const double dl = dloss_dev(loss, (double)ri[L - 2], (double)ri[L - 1]);
+        for (int t = 0; t < QM; ++t) {
+            double gacc = 0.0, hacc = 0.0;
+            const double p = po[t];
+            for (int u = seg[t]; u < seg[t + 1]; ++u) {
+                const double2 xd = sh_xd[gb + u];
                 double ad[AS];
 #pragma unroll
-                for (int t = 0; t < AS; ++t) ad[t] = kl ? (double)ri[(size_t)t * L + lane] : 0.0;
-                const double p = pb_sel(po, qi);
-                const double dprev = kl ? grad_factor<M>(ad, x, p) : 0.0;
-                pb_acc<QM>(gs, qi, dl * dprev);
-                pb_acc<QM>(hs, qi, dprev * dprev);
+                for (int tt = 0; tt < AS; ++tt) ad[tt] = (double)rows_at(par, u, tt)[wlane];
+                const double dprev = kl ? grad_factor<M>(ad, xd.x, p) : 0.0;
+                gacc += xd.y * dprev;
+                hacc += dprev * dprev;
             }
-            publish_vectors(gs, hs, slabA, nw, tag);
+            gs[t] = gacc;
+            hs[t] = hacc;
+        }
+        for (int u = ER; u < cur.cnt; ++u) {  // slow path: beyond the LDS-staged rows
+            const int e = cur.e0 + u;
+            const int i = a.erow[e];
+            const int qi = (int)a.emeta[e] & 7;
+            const double x = (double)eval[e];
+            const T* ri = R + (size_t)i * rowlen;
+            const double dl = dloss_dev(loss, (double)ri[L - 2], (double)ri[L - 1]);
+            double ad[AS];
+#pragma unroll
+            for (int t = 0; t < AS; ++t) ad[t] = kl ? (double)ri[(size_t)t * L + lane] : 0.0;
+            const double p = pb_sel(po, qi);
+            const double dprev = kl ? grad_factor<M>(ad, x, p) : 0.0;
+            pb_acc<QM>(gs, qi, dl * dprev);
+            pb_acc<QM>(hs, qi, dprev * dprev);
+        }
+        {
+            // sum_s inv_step_sizes[s] (pbcd.py:68-70) of the QM slots by one butterfly: lane l
+            // ends with the sum of slot (l & (QM-1)); lane L-2 of slot t's vector needs slot t
+            double hv[QM];
+#pragma unroll
+            for (int t = 0; t < QM; ++t) hv[t] = hs[t];
+            const double hr = pb_multi_reduce<QM, L>(hv, lane);
+#pragma unroll
+            for (int t = 0; t < QM; ++t) {
+                const int q = slot_of(qs0, t);
+                const double hsum = pb_bcast<L>(hr, t, grp);
+                if (q < nw) {
+                    const double v = (lane == L - 2) ? hsum : (kl ? gs[t] : 0.0);
+                    prb_store_granule(slabA + ((size_t)q * a.G + g) * L + lane, v, tag);
+                }
+            }
         }
         PB_STAMP(1)
 
         // ---- phase 2: owners reduce their slot over the workgroups and take the step
-        const int n_rounds = fixed_owner ? 1 : max(1, (max(nw, nwB) + a.G - 1) / a.G);
+        const int n_rounds = fixed_owner ? 1 : (nw + a.G - 1) / a.G;
         for (int r = 0; r < n_rounds; ++r) {
             const int q = fixed_owner ? oq : pbprb_owned_slot(a.G, g, r);
             const bool own = q >= 0 && q < ncols;
@@ -758,15 +669,11 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 red[grp * L + lane] = tot;
             }
             PB_STAMP(2)
-            // part sums in LDS.  vmcnt(0): the previous step's scatter stores of this wave are
-            // complete (an owner's poll loads have returned behind them; everybody else waits a
-            // store's round trip here, in the shadow of the exchange), so that after the barrier
-            // the prefetch below may read any row of the block
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (q >= 0 && q >= ncols && grp == 0) {
-                // slot unused in this step but read at a buffer's next use: rewritten now
-                if (q < nwB) prb_store_granule(slabB + (size_t)q * L + lane, 0.0, tagB);
-                if (a.n_ranks > 1 && q < nw) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // part sums in LDS
+            if (q >= ncols && q < nw && grp == 0) {
+                // slot unused in this step but read at the buffer's next use: rewritten now
+                prb_store_granule(slabB + (size_t)q * L + lane, 0.0, tag);
+                if (a.n_ranks > 1) {
                     const size_t off = ((size_t)par * 64 + q) * a.n_ranks * L;
                     for (int rr = 0; rr < a.n_ranks; ++rr)
                         prb_store_granule_sys(a.slabC[rr] + off + (size_t)a.rank * L + lane, 0.0, tag);
@@ -827,7 +734,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 }
                 const double l2 = sqrt(pb_group_allsum<L>(v * v));
                 const double outv = (lane == L - 2) ? l2 : ((lane == L - 1) ? st0 : v);
-                prb_store_granule(slabB + (size_t)q * L + lane, outv, tagB);
+                prb_store_granule(slabB + (size_t)q * L + lane, outv, tag);
             }
         }
         PB_STAMP(3)
@@ -837,15 +744,20 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         // in front of the collect poll: vmcnt retires in order, so the first tag check waits for
         // these loads too -- but everybody waits about that long for the owners anyway.  (In
         // front of the owner poll it delays the owners themselves: 13.1 vs 12.4 us per step;
-        // behind the collect poll its issue time sits on the critical path: 14.1.)
+        // behind the collect poll its issue time sits on the critical path: 14.1.  Round 3:
+        // waves 1..7 polling at once with an empty load queue and prefetching during wave 0's
+        // chain instead: 12.1 vs 11.0 -- the totals arrive ~5 us after the publish whoever polls
+        // and however early; the exchange is bound by the burst of 2 MB of partial vectors that
+        // all workgroups write, and the owners read, at the same instant.)
         int b3e0, b3e1;
         bounds(b + 3, b3e0, b3e1);
+        const SlotIds qs3 = load_slots(b + 3);
         load_entries(nn, b2e0, b2e1);
         fetch_rows(nxt, par ^ 1, 0);
         int j2[QM];
 #pragma unroll
         for (int t = 0; t < QM; ++t) {
-            j2[t] = col_id(c2, c3 - c2, grp + t * NG);
+            j2[t] = col_id(c2, c3 - c2, slot_of(qs2, t));
             pon[t] = (j1[t] >= 0 && kl) ? P[(size_t)j1[t] * k + lane] : 0.0;
         }
         const int oj2 = col_id(c2, c3 - c2, oq);
@@ -853,14 +765,6 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         const int cj2 = (wave == 0) ? col_id(c2, c3 - c2, wlane) : -1;
         cn1 = (cj1 >= 0 && chained) ? rs.norms[cj1] : 0.0;
         PB_STAMP(4)
-        // ---- early phase of step b+1 (in the shadow of the exchange): see the header
-        if constexpr (EARLY) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its rows have landed in LDS
-            wave_lds_sync();
-            early_phase(nxt, par ^ 1, pon, a.slabA + (size_t)(par ^ 1) * 64 * a.G * L,
-                        max(c2 - c1, c4 - c3), prb_tag(b + 1));
-        }
-        PB_STAMP(10)
         // ---- phase 3: every workgroup collects the published vectors of all slots
         {
             const int total = ncols * L;
@@ -873,8 +777,8 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
                     const int idx = tid + u * kPbPrbThreads;
-                    t[u] = (idx < total) ? prb_load_granule(slabB + idx) : tagB;
-                    all = all && ((t[u] & 3ull) == tagB);
+                    t[u] = (idx < total) ? prb_load_granule(slabB + idx) : tag;
+                    all = all && ((t[u] & 3ull) == tag);
                 }
                 if (all) break;
                 if (pbprb_poll_fail(a, spins)) {
@@ -933,101 +837,71 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             double vav[QM];
 #pragma unroll
             for (int t = 0; t < QM; ++t) {
-                const int q = min(grp + t * NG, 63);
-                const bool vq = grp + t * NG < ncols;
+                const int qq = slot_of(qs0, t);
+                const int q = min(qq, 63);
+                const bool vq = qq < ncols;
                 const double f = sh_scal[4 * q + 2];
                 const double pt = sh_pt[q * L + lane];
                 pn[t] = (vq && kl) ? pt * f : 0.0;
                 up[t] = (vq && kl) ? po[t] - pn[t] : 0.0;
                 lu[t] = lam * up[t];
-                // did the block move?  one ballot per slot (exact no-op otherwise)
-                mv[t] = (group_bits(__ballot(up[t] != 0.0)) != 0ull) ? 1.0 : 0.0;
+                {   // did the block move?  one ballot per slot (exact no-op otherwise)
+                    const unsigned long long bal = __ballot(up[t] != 0.0);
+                    const unsigned long long mine =
+                        (L == 64) ? bal : ((bal >> (32 * (grp & 1))) & 0xffffffffull);
+                    mv[t] = (mine != 0ull) ? 1.0 : 0.0;
+                }
                 vav[t] = fabs(up[t]);
                 if (g == 0 && vq && kl) P[(size_t)j0[t] * k + lane] = pn[t];
             }
             // ||Delta||_1 per slot by one butterfly: lane t of the group ends with slot t's sum
             if (g == 0) {
                 const double vr = pb_multi_reduce<QM, L>(vav, lane);
-                if (lane < QM && grp + lane * NG < ncols) viol_pos[c0 + grp + lane * NG] = vr;
+                const int ql = slot_of(qs0, lane & (QM - 1));
+                if (lane < QM && ql < ncols) viol_pos[c0 + ql] = vr;
             }
         }
         {
-            // per entry: the new record -- cache values in the component lanes, the prediction
-            // minus sum_s lam_s Delta_s dA_s in lane L-2, the target in lane L-1, zeros in the
-            // padding -- written back as whole slices (slice 0 of float storage, k <= 30: one full
-            // 128-byte line).  CH entries at a time: independent dependency chains for the
-            // compiler to interleave, and ONE transposing butterfly for the CH prediction
-            // decrements instead of an all-reduce each.  An entry whose row the next step touches
-            // (efwd) also writes its record into that step's LDS row buffer.
-            constexpr int CH = (AS == 1) ? 4 : 2;
-            for (int ub = 0; ub < nfast; ub += CH) {
-                double adv[CH][AS], nvv[CH][AS], cdec[CH], cnew[CH];
-                int rowv[CH], fwv[CH];
-                bool act[CH];
+            // per slot (static registers po / up / lu), per entry: the new record -- cache values
+            // in the component lanes, the prediction minus sum_s lam_s Delta_s dA_s (one DPP
+            // all-reduce) in lane L-2, the target in lane L-1, zeros in the padding -- written
+            // back as whole slices (slice 0 of float storage, k <= 30: one full 128-byte line)
 #pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const int u = min(ub + c, nfast - 1);
-                    const int2 rm = srm[u];
-                    const int qi = rm.y & 7;
-                    act[c] = ub + c < nfast && pb_sel(mv, qi) != 0.0;  // block did not move: no-op
-                    rowv[c] = rm.x;
-                    fwv[c] = rm.y >> 8;
-                    const double x = sxd[u].x;
-                    const double pol = pb_sel(po, qi), upl = pb_sel(up, qi);
+            for (int t = 0; t < QM; ++t) {
+                if (mv[t] == 0.0) continue;  // block did not move: exact no-op (group-uniform)
+                const double pol = po[t], upl = up[t], lul = lu[t], pnl = pn[t];
+                for (int u = seg[t]; u < seg[t + 1]; ++u) {
+                    const double x = sh_xd[gb + u].x;
+                    const size_t base = (size_t)srm[u].x * rowlen + lane;
+                    double ad[AS];
 #pragma unroll
-                    for (int tt = 0; tt < AS; ++tt) adv[c][tt] = (double)rows_at(par, u, tt)[wlane];
-                    // lane L-2 holds yhat_old in adv[.][0], lane L-1 the target
+                    for (int tt = 0; tt < AS; ++tt) ad[tt] = (double)rows_at(par, u, tt)[wlane];
+                    // lane L-2 holds yhat_old in ad[0], lane L-1 the target
                     if constexpr (M == 0) {  // pbcd_all.py:121-127
-                        const double pnl = pb_sel(pn, qi);
-                        const double a0 = kl ? adv[c][0] : 0.0;
+                        const double a0 = kl ? ad[0] : 0.0;
                         double a1 = a0 / (1.0 + x * pol);
                         a1 *= 1.0 + x * pnl;
-                        nvv[c][0] = kl ? a1 : 0.0;
-                        cdec[c] = (kl && act[c]) ? lam * a0 : 0.0;
-                        cnew[c] = (kl && act[c]) ? lam * a1 : 0.0;
+                        const double d_old = pb_group_allsum<L>(kl ? lam * a0 : 0.0);
+                        const double d_new = pb_group_allsum<L>(kl ? lam * a1 : 0.0);
+                        double outv = kl ? a1 : 0.0;
+                        if (lane == L - 2) outv = (ad[0] - d_old) + d_new;
+                        if (lane == L - 1) outv = ad[0];
+                        R[base] = (T)outv;
                     } else {
-                        const double lul = pb_sel(lu, qi);
+                        double nv[AS];
                         double dprev = x;
 #pragma unroll
                         for (int tt = 1; tt < M; ++tt) {
-                            const double avv = kl ? adv[c][tt - 1] : 0.0;
+                            const double avv = kl ? ad[tt - 1] : 0.0;
                             const double dcur = x * (avv - pol * dprev);
-                            nvv[c][tt - 1] = kl ? avv - upl * dprev : 0.0;
+                            nv[tt - 1] = kl ? avv - upl * dprev : 0.0;
                             dprev = dcur;
                         }
-                        cdec[c] = (kl && act[c]) ? lul * dprev : 0.0;
-                        cnew[c] = 0.0;
-                    }
-                }
-                // lane l of the group ends with the sum of entry (l & (CH-1))
-                const double rdec = pb_multi_reduce<CH, L>(cdec, lane);
-                double rnew = 0.0;
-                if constexpr (M == 0) rnew = pb_multi_reduce<CH, L>(cnew, lane);
+                        const double dec = pb_group_allsum<L>(kl ? lul * dprev : 0.0);
+                        if (lane == L - 2) nv[0] = ad[0] - dec;
+                        if (lane == L - 1) nv[0] = ad[0];
 #pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const double dec = pb_bcast<L>(rdec, c, grp);
-                    if constexpr (M == 0) {
-                        const double dnw = pb_bcast<L>(rnew, c, grp);
-                        if (lane == L - 2) nvv[c][0] = (adv[c][0] - dec) + dnw;
-                    } else {
-                        if (lane == L - 2) nvv[c][0] = adv[c][0] - dec;
-                    }
-                    if (lane == L - 1) nvv[c][0] = adv[c][0];
-                    if (act[c]) {
-                        const size_t base = (size_t)rowv[c] * rowlen + lane;
-#pragma unroll
-                        for (int tt = 0; tt < AS; ++tt) R[base + (size_t)tt * L] = (T)nvv[c][tt];
-                    }
-                    if (ub + c < nfast && (fwv[c] & 0x100)) {
-                        // the next step's copy of the row: group (fw >> 4) & 15, entry fw & 15 of
-                        // the other parity's buffer (an unmoved block forwards the old record)
-                        const int fg = (fwv[c] >> 4) & 15, fu = fwv[c] & 15;
-                        const int fwave = (L == 64) ? fg : (fg >> 1);
-                        const int foff = (L == 64) ? lane : ((fg & 1) * 32 + lane);
-                        T* dst = sh_rows + ((((size_t)(par ^ 1) * NW + fwave) * ER + fu) * AS) * 64 + foff;
-#pragma unroll
-                        for (int tt = 0; tt < AS; ++tt)
-                            dst[(size_t)tt * 64] = act[c] ? (T)nvv[c][tt] : (T)adv[c][tt];
+                        for (int tt = 0; tt < AS; ++tt) R[base + (size_t)tt * L] = (T)nv[tt];
                     }
                 }
             }
@@ -1080,6 +954,9 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         publish_meta(nxt, par);  // step b+2's slice (parity b&1): step b is done with it
         b2e0 = b3e0;
         b2e1 = b3e1;
+        qs0 = qs1;
+        qs1 = qs2;
+        qs2 = qs3;
 #pragma unroll
         for (int t = 0; t < QM; ++t) {
             j0[t] = j1[t];
@@ -1095,14 +972,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         c1 = c2;
         c2 = c3;
         c3 = c4;
-        // rows move between groups from step to step: through LDS (forwarded records; an LDS-only
-        // barrier) -- or, when the next step reads one of them from global memory, with this
-        // step's stores drained first
-        if (drain_now) {
-            __syncthreads();
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
+        __syncthreads();  // rows move between groups from step to step (stores drained)
         PB_STAMP(8)
     }
 #undef PB_STAMP
@@ -1119,15 +989,13 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
 }
 
 // dynamic LDS the kernel needs (bytes)
-template <typename T, int M, int L, bool EARLY = false>
+template <typename T, int M, int L>
 constexpr size_t pbcd_prb_lds_bytes() {
     constexpr int NG = kPbPrbThreads / L;
-    constexpr int QM = 64 / NG;
     constexpr int AS = Kind<M>::AS;
     constexpr int ER = pbprb_er<T, M>();
-    return sizeof(double) * (2 * NG * L + 64 * L + 256 + 4 * NG * L + 2 * (kMaxDegree + 2)) +
+    return sizeof(double) * (2 * NG * L + 64 * L + 256 + 2 * NG * L + 2 * (kMaxDegree + 2)) +
            sizeof(int) * (4 * NG * L + 4) +
-           sizeof(double) * (EARLY ? (size_t)2 * QM * kPbPrbThreads : 0) +
            sizeof(T) * (size_t)2 * (kPbPrbThreads / 64) * ER * AS * 64;
 }
 

@@ -72,6 +72,16 @@ __global__ void store_pred_kernel(int64_t n, const double* __restrict__ pred, T*
     if (i < n) yy[2 * i] = (T)pred[i];
 }
 
+// (yhat, y) of a handle that shares another's data image: predictions zero, targets copied
+template <typename T>
+__global__ void copy_targets_kernel(int64_t n, const T* __restrict__ src_yy, T* __restrict__ yy) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        yy[2 * i] = (T)0;
+        yy[2 * i + 1] = src_yy[2 * i + 1];
+    }
+}
+
 template <typename T>
 __global__ void load_pred_kernel(int64_t n, const T* __restrict__ yy, double* __restrict__ pred) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

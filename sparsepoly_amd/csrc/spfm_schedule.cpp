@@ -606,42 +606,88 @@ void build_rowblock_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
     });
 }
 
-// Entry stream of the persistent pbcd pass: entries sorted by (row block g, batch b, slot
-// group q % NG, slot, row).  gsp[(g*nb + b)*(NG+1) + grp] = first entry of group grp (NG+1
-// boundaries per (g, b)), src[e] = position in the CSC arrays, meta[e] = slot index inside the
-// group (q / NG, < 8) | 0x80 if the entry's row was touched by the previous step (its row
-// state must be read after that step's scatter, not prefetched).  Batches of <= 64 columns,
-// nnz < 2^31.
-// Forwarding (round 4): the kernel keeps the rows of a group's first ER entries in LDS.  When
-// a row is touched by two consecutive steps and both entries are among those (the rule but for
-// very frequent features), the first step's scatter writes the new record straight into the
-// second step's LDS slot: fwd[e] = 0x100 | group << 4 | entry for the FIRST step's entry, meta
-// |= 0x40 for the second's; otherwise drain[g * nb + b] = 1 for the first step b (its end
-// barrier must drain the stores, the second step reads global memory).
+// Entry stream of the persistent pbcd pass: entries sorted by (row block g, step b, slot group,
+// slot index t inside the group, row).  gsp[(g*nb + b)*(NG+1) + grp] = first entry of group grp
+// (NG+1 boundaries per (g, b)), src[e] = position in the CSC arrays, meta[e] = t (< 8) | 0x80 if
+// the entry's row was touched by the previous step (its row state must be read after that
+// step's scatter, not prefetched).  Steps of <= 64 columns, nnz < 2^31.
+//
+// Balanced slot groups (round 4).  A group of L lanes walks its entries one after the other and
+// every step waits for the slowest group of the slowest workgroup.  With the fixed map
+// "slot q -> group q % NG" the busiest of the 4096 groups of BASELINE config 4 holds 14.9
+// entries per step against a mean of 4.4 (groups 0..4 carry three columns, the others two, plus
+// the Poisson spread of ~2 entries per column and row block).  Here every (row block, step)
+// gets its own map, chosen for its entry counts: columns in descending order of their entries in
+// the block go to the group with the fewest entries so far (at most QM = 64 / NG columns per
+// group) -- 6.5 entries in the busiest group.  tab[(g*nb + b)*64 + grp*QM + t] = the step's slot
+// (column index inside the step) that group grp handles as its t-th, 0xFF = none; every slot
+// below `max(ncols(b), ncols(b+2))` is assigned (the kernel rewrites the unused ones with zeros).
 void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
                      const std::vector<int32_t>& order, const std::vector<int32_t>& batch_ptr,
-                     int G, int NG, int ER, std::vector<int32_t>& gsp, std::vector<int32_t>& src,
-                     std::vector<uint8_t>& meta, std::vector<uint16_t>& fwd,
-                     std::vector<uint8_t>& drain) {
+                     int G, int NG, bool balance, std::vector<int32_t>& gsp,
+                     std::vector<int32_t>& src, std::vector<uint8_t>& meta,
+                     std::vector<uint8_t>& tab) {
     const int nb = (int)batch_ptr.size() - 1;
+    const int QM = 64 / NG;
     const int64_t rows_per = (n + G - 1) / G > 0 ? (n + G - 1) / G : 1;
     const size_t stride = (size_t)NG + 1;
     gsp.assign((size_t)G * nb * stride + 1, 0);
+    tab.assign((size_t)G * (size_t)std::max(nb, 1) * 64, 0xFF);
     const int64_t nnz = cptr[order.size()];
     const int T = std::min(G, (nnz >= (1 << 20)) ? schedule_threads() : 1);
     const int gper = (G + T - 1) / T;
+    auto ncols_of = [&](int b) { return (b >= 0 && b < nb) ? batch_ptr[b + 1] - batch_ptr[b] : 0; };
+    // the part of column j that lies in the row range [rlo, rhi): rows ascend inside a column
+    auto sub_range = [&](int32_t j, int64_t rlo, int64_t rhi, int64_t& lo, int64_t& hi) {
+        const int32_t* first = cidx + cptr[j];
+        const int32_t* last = cidx + cptr[j + 1];
+        lo = cptr[j] + (std::lower_bound(first, last, (int32_t)std::min<int64_t>(rlo, INT32_MAX)) - first);
+        hi = cptr[j] + (std::lower_bound(first, last, (int32_t)std::min<int64_t>(rhi, INT32_MAX)) - first);
+    };
+    // pass 1: per (row block, step) the entries of every slot; the slot -> (group, t) map; the
+    // groups' entry counts
     run_threads(T, [&](int tid) {
         const int g0 = gper * tid, g1 = std::min(G, g0 + gper);
-        const int64_t rlo = (int64_t)g0 * rows_per, rhi = (int64_t)g1 * rows_per;
-        for (int b = 0; b < nb; ++b)
-            for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
-                const int32_t j = order[(size_t)batch_ptr[b] + q];
-                for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
-                    const int64_t i = cidx[ii];
-                    if (i < rlo || i >= rhi) continue;
-                    gsp[((size_t)(i / rows_per) * nb + b) * stride + (size_t)(q % NG)]++;
-                }
+        if (g0 >= g1) return;
+        const int64_t rlo = (int64_t)g0 * rows_per, rhi = std::min<int64_t>(n, (int64_t)g1 * rows_per);
+        std::vector<int32_t> cnt((size_t)(g1 - g0) * 64);
+        int idx[64], load[64], used[64];
+        for (int b = 0; b < nb; ++b) {
+            const int nc = ncols_of(b);
+            const int nw = std::min(64, std::max(nc, ncols_of(b + 2)));
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int q = 0; q < nc; ++q) {
+                int64_t lo, hi;
+                sub_range(order[(size_t)batch_ptr[b] + q], rlo, rhi, lo, hi);
+                for (int64_t ii = lo; ii < hi; ++ii)
+                    cnt[(size_t)(cidx[ii] / rows_per - g0) * 64 + (size_t)q]++;
             }
+            for (int g = g0; g < g1; ++g) {
+                const int32_t* c = &cnt[(size_t)(g - g0) * 64];
+                uint8_t* tb = &tab[((size_t)g * nb + b) * 64];
+                int32_t* gs = &gsp[((size_t)g * nb + b) * stride];
+                if (!balance) {  // the fixed map: slot q -> group q % NG, t = q / NG
+                    for (int q = 0; q < nw; ++q) {
+                        tb[(q % NG) * QM + q / NG] = (uint8_t)q;
+                        gs[q % NG] += c[q];
+                    }
+                    continue;
+                }
+                for (int q = 0; q < nw; ++q) idx[q] = q;
+                std::stable_sort(idx, idx + nw, [&](int x, int y) { return c[x] > c[y]; });
+                for (int r = 0; r < NG; ++r) load[r] = used[r] = 0;
+                for (int z = 0; z < nw; ++z) {
+                    const int q = idx[z];
+                    int best = -1;
+                    for (int r = 0; r < NG; ++r)
+                        if (used[r] < QM && (best < 0 || load[r] < load[best])) best = r;
+                    tb[best * QM + used[best]] = (uint8_t)q;
+                    used[best]++;
+                    load[best] += c[q];
+                }
+                for (int r = 0; r < NG; ++r) gs[r] = load[r];
+            }
+        }
     });
     int64_t run = 0;
     for (size_t t = 0; t < gsp.size(); ++t) {  // exclusive prefix sum; the pad word of each
@@ -651,52 +697,51 @@ void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
     }
     src.resize((size_t)run);
     meta.resize((size_t)run);
-    fwd.assign((size_t)run, 0);
-    drain.assign((size_t)G * (size_t)std::max(nb, 1), 0);
-    std::vector<int32_t> fill(gsp.begin(), gsp.end());
-    std::vector<int32_t> last((size_t)n, -2);  // last step that touched the row (own rows only)
-    std::vector<int32_t> last_e((size_t)n, -1);  // ... and the entry that did
-    // slots of one group in ascending order: q = grp, grp + NG, ... -> walking q ascending, the
-    // per-group fill pointers keep (slot, row) order inside each group
+    std::vector<int32_t> last((size_t)n, -2);    // last step that touched the row (own rows only)
+    // pass 2: fill.  Inside a group the entries are ordered by (t, row): the fill position of a
+    // slot = the group's first entry + the entries of the group's earlier slots
     run_threads(T, [&](int tid) {
         const int g0 = gper * tid, g1 = std::min(G, g0 + gper);
-        const int64_t rlo = (int64_t)g0 * rows_per, rhi = (int64_t)g1 * rows_per;
+        if (g0 >= g1) return;
+        const int64_t rlo = (int64_t)g0 * rows_per, rhi = std::min<int64_t>(n, (int64_t)g1 * rows_per);
+        std::vector<int32_t> pos((size_t)(g1 - g0) * 64);   // next fill position per (block, slot)
+        std::vector<uint8_t> where((size_t)(g1 - g0) * 64);  // grp << 3 | t per (block, slot)
+        std::vector<int64_t> lo_q(64), hi_q(64);
         for (int b = 0; b < nb; ++b) {
-            for (int q = 0; q < batch_ptr[b + 1] - batch_ptr[b]; ++q) {
-                const int32_t j = order[(size_t)batch_ptr[b] + q];
-                const uint8_t qi = (uint8_t)(q / NG);
-                for (int64_t ii = cptr[j]; ii < cptr[j + 1]; ++ii) {
-                    const int64_t i = cidx[ii];
-                    if (i < rlo || i >= rhi) continue;
-                    const size_t e = (size_t)fill[((size_t)(i / rows_per) * nb + b) * stride +
-                                                  (size_t)(q % NG)]++;
-                    src[e] = (int32_t)ii;
-                    uint8_t m = qi;
-                    if (last[(size_t)i] == b - 1) {
-                        m |= 0x80;
-                        // position of both entries inside their groups: entries of a group are
-                        // filled in order, so e - (group's first entry) is the lane index u
-                        const size_t gi = (size_t)(i / rows_per);
-                        const int grp_d = q % NG;
-                        const int u_d = (int)(e - (size_t)gsp[(gi * nb + b) * stride + (size_t)grp_d]);
-                        const size_t ep = (size_t)last_e[(size_t)i];
-                        // the source entry's group: the one whose range in step b-1 holds ep
-                        const int32_t* gp = &gsp[(gi * nb + (size_t)(b - 1)) * stride];
-                        int grp_s = 0;
-                        while (grp_s + 1 < NG && (size_t)gp[grp_s + 1] <= ep) ++grp_s;
-                        const int u_s = (int)(ep - (size_t)gp[grp_s]);
-                        if (u_d < ER && u_s < ER) {
-                            m |= 0x40;
-                            fwd[ep] = (uint16_t)(0x100 | (grp_d << 4) | u_d);
-                        } else {
-                            drain[gi * (size_t)nb + (size_t)(b - 1)] = 1;
-                        }
+            const int nc = ncols_of(b);
+            std::fill(pos.begin(), pos.end(), 0);
+            for (int q = 0; q < nc; ++q) {
+                sub_range(order[(size_t)batch_ptr[b] + q], rlo, rhi, lo_q[(size_t)q], hi_q[(size_t)q]);
+                for (int64_t ii = lo_q[(size_t)q]; ii < hi_q[(size_t)q]; ++ii)
+                    pos[(size_t)(cidx[ii] / rows_per - g0) * 64 + (size_t)q]++;  // counts first
+            }
+            for (int g = g0; g < g1; ++g) {
+                int32_t* pc = &pos[(size_t)(g - g0) * 64];
+                uint8_t* wh = &where[(size_t)(g - g0) * 64];
+                const uint8_t* tb = &tab[((size_t)g * nb + b) * 64];
+                const int32_t* gs = &gsp[((size_t)g * nb + b) * stride];
+                for (int r = 0; r < NG; ++r) {
+                    int32_t at = gs[r];
+                    for (int t = 0; t < QM; ++t) {
+                        const int q = tb[r * QM + t];
+                        if (q == 0xFF) continue;
+                        wh[q] = (uint8_t)((r << 3) | t);
+                        const int32_t c = q < nc ? pc[q] : 0;
+                        pc[q] = at;
+                        at += c;
                     }
-                    meta[e] = m;
-                    last[(size_t)i] = b;  // columns of one step share no row: no read-after-write
-                    last_e[(size_t)i] = (int32_t)e;
                 }
             }
+            for (int q = 0; q < nc; ++q)
+                for (int64_t ii = lo_q[(size_t)q]; ii < hi_q[(size_t)q]; ++ii) {
+                    const int64_t i = cidx[ii];
+                    const size_t gi = (size_t)(i / rows_per);
+                    const size_t lq = (gi - (size_t)g0) * 64 + (size_t)q;
+                    const size_t e = (size_t)pos[lq]++;
+                    src[e] = (int32_t)ii;
+                    meta[e] = (uint8_t)((where[lq] & 7) | (last[(size_t)i] == b - 1 ? 0x80 : 0));
+                    last[(size_t)i] = b;  // columns of one step share no row: no read-after-write
+                }
         }
     });
 }

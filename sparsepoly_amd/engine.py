@@ -169,6 +169,53 @@ def shared_schedule(key, compute, install):
     return install(entry["sched"])
 
 
+def data_key(X, precision, device):
+    """Content hash of a sparse matrix (structure AND values) + what else decides its device
+    image."""
+    try:
+        import xxhash
+
+        h = xxhash.xxh3_64()
+    except Exception:  # pragma: no cover - xxhash is optional
+        import hashlib
+
+        h = hashlib.blake2b(digest_size=8)
+    for a in (X.indptr, X.indices, X.data):
+        h.update(memoryview(np.ascontiguousarray(a)).cast("B"))
+    return (X.format, X.shape, int(X.nnz), h.hexdigest(), precision, int(device))
+
+
+def shared_set_data(engine, X, y):
+    """``engine.set_data(X, y)`` -- or, inside a concurrent call on ONE data set, attach to the
+    device image the first fit of that call uploaded (Tenancy.images; kept alive by a keeper
+    handle until the call ends)."""
+    ten = current_tenancy()
+    if ten is None or ten.images is None or not sp.issparse(X):
+        engine.set_data(X, y)
+        return False
+    key = data_key(X, engine.precision, engine.device)
+    with ten.lock:
+        entry = ten.images.get(key)
+        leader = entry is None
+        if leader:
+            entry = ten.images[key] = {"done": threading.Event(), "keeper": None}
+    if leader:
+        try:
+            engine.set_data(X, y)
+            keeper = HipEngine(engine.device, engine.precision)
+            keeper.share_data(engine)
+            entry["keeper"] = keeper
+        finally:
+            entry["done"].set()  # on an error the followers upload for themselves
+        return False
+    entry["done"].wait()
+    if entry["keeper"] is None:
+        engine.set_data(X, y)
+        return False
+    engine.share_data(entry["keeper"], y)
+    return True
+
+
 def hw_queue_report():
     """How many hardware queues the HIP runtime of this process maps streams onto, as far as the
     environment tells (GPU_MAX_HW_QUEUES is read when the runtime initialises; default 4).  More
@@ -254,6 +301,18 @@ class HipEngine(object):
             self._keep[3][1]))
         self._keep = None
         self.n, self.d = n, d
+
+    def share_data(self, src, y=None):
+        """Train on the device image of the matrix that engine ``src`` holds (no upload, no
+        second copy in HBM); ``y``: this engine's own targets, default ``src``'s."""
+        if y is None:
+            yp = None
+        else:
+            ya, yp = _capi.f64(y)
+            if ya.shape[0] != src.n:
+                raise ValueError("y has %d entries, X has %d rows" % (ya.shape[0], src.n))
+        self._check(self._lib.spfm_share_data(self._h, src._h, yp))
+        self.n, self.d = src.n, src.d
 
     def set_params(self, P, w, lams):
         P = np.ascontiguousarray(P, dtype=np.float64)

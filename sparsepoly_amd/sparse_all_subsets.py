@@ -102,7 +102,9 @@ class _BaseSparseAllSubsets(BaseSparsePoly, metaclass=ABCMeta):
         try:
             # canonical CSR goes to the library as it is (transposed on the device)
             csr_direct = sp.isspmatrix_csr(X) and X.has_canonical_format
-            engine.set_data(X if csr_direct else canonical_csc(X), y)
+            from . import engine as _engine_mod
+
+            _engine_mod.shared_set_data(engine, X if csr_direct else canonical_csc(X), y)
             engine.set_params(self.P_[None], np.zeros(n_features), self.lams_)
             engine.configure(self.solver, self.loss, self.regularizer, -1)
             engine.init_pred(-1, False, False)  # y_pred = self._get_output(X) (:241)

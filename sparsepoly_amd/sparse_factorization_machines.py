@@ -466,7 +466,8 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 _dist.connect_peers(engine)  # in-kernel exchange for the persistent passes
                 engine.set_data(Xl, y[lo:hi])
             else:
-                engine.set_data(X if csr_direct else Xc, y)
+                # (concurrent fits on one data set attach to ONE device image of it)
+                self.shared_image_ = _engine_mod.shared_set_data(engine, X if csr_direct else Xc, y)
             self.P_ = np.ascontiguousarray(self.P_, dtype=np.double)
             self.w_ = np.ascontiguousarray(self.w_, dtype=np.double)
             engine.set_params(self.P_, self.w_, self.lams_)

@@ -29,7 +29,7 @@ for G in groups:
         eng = HipEngine(0, "f32")
         eng.set_option("pbprb_groups", G)
         eng.set_option("pbprb_stamps", stamps)
-        eng.set_option("pbprb_early", int(os.environ.get("PB_EARLY", 0)))
+        eng.set_option("pbprb_balance", int(os.environ.get("PB_BALANCE", 1)))
         eng.set_option("pbprb_dbg", int(os.environ.get("PB_DBG", 0)))
         eng.set_data(Xc, y)
         eng.set_params(0.01 * np.random.RandomState(0).randn(1, k, d), np.zeros(d), np.ones(k))
@@ -42,7 +42,7 @@ for G in groups:
         for _ in range(reps):
             v.append(eng.pbcd_epoch(0, 2, 1.0, 1e-3, 1.0))
         dt = (time.perf_counter() - t0) / reps
-        out = dict(G=G, stamps=stamps, reg=reg, early=int(os.environ.get("PB_EARLY", 0)),
+        out = dict(G=G, stamps=stamps, reg=reg, balance=int(os.environ.get("PB_BALANCE", 1)),
                    ms_per_pbcd_epoch=round(dt * 1e3, 2),
                    steps=eng.n_batches, us_per_step=round(dt * 1e6 / eng.n_batches, 3),
                    active=eng.get_option("pbprb_active"), viol=[round(float(x), 3) for x in v])

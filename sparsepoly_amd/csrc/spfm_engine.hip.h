@@ -69,6 +69,14 @@ extern template hipError_t device_csr_to_csc<double>(int64_t, int32_t, int64_t, 
 hipError_t device_rowblock_stream(int64_t, int32_t, int64_t, int, int, int, const int32_t*,
                                   const int32_t*, const int64_t*, const int32_t*, const uint8_t*,
                                   int32_t*, int32_t*, uint32_t*, int*, int64_t*, hipStream_t);
+// spfm_ingest.hip: the pbcd and wide entry streams on the device (same tables as build_pb_stream /
+// build_wide_stream)
+hipError_t device_pb_stream(int64_t, int32_t, int64_t, int, int, int, int, const int32_t*,
+                            const int32_t*, const int64_t*, const int32_t*, const int64_t*,
+                            const int32_t*, int32_t*, int32_t*, uint8_t*, uint8_t*, hipStream_t);
+hipError_t device_wide_stream(int64_t, int32_t, int64_t, int, int, const int32_t*, const int32_t*,
+                              const int64_t*, const int32_t*, const int64_t*, const int32_t*,
+                              int32_t*, int32_t*, uint8_t*, hipStream_t);
 // spfm_colour.hip: the first-fit colouring on the device (same result as schedule_colored)
 hipError_t device_first_fit(int64_t, int32_t, int64_t, const int64_t*, const int32_t*, const int64_t*,
                             const int32_t*, int, int32_t*, int*, int*, hipStream_t);
@@ -514,6 +522,7 @@ struct spfm_engine {
     int colour_device_used = 0;
     bool stream_device = true;   // the 64-column pass's entry stream built on the device
     int stream_device_used = 0;
+    int pb_stream_device_used = 0, wide_stream_device_used = 0;  // the pbcd / wide entry streams
     int colour_columns(int64_t rows, const int64_t* cp, const int32_t* ci, bool own,
                        const int32_t* jf, int max_batch);
 

@@ -1558,9 +1558,11 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
             h->pb_stream_ready = false;
         }
         h->wide_ready = false;  // the wide pass caps itself (wide_groups)
-    } else if (k == "stream_device") {  // entry stream of the 64-column passes: device or host threads
+    } else if (k == "stream_device") {  // entry streams of the persistent passes: device or host threads
         h->stream_device = value != 0;
         h->prb_ready = false;
+        h->pb_stream_ready = false;
+        h->wide_ready = false;
     } else if (k == "colour_device") {  // first-fit colouring on the device (default) or by host threads
         h->colour_device = value != 0;
     } else if (k == "ingest_device") {  // CSR -> CSC on the device (default) or by host threads
@@ -1695,6 +1697,8 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "colour_device_used") *value = h->colour_device_used;
     else if (k == "stream_device") *value = h->stream_device;
     else if (k == "stream_device_used") *value = h->stream_device_used;
+    else if (k == "pb_stream_device_used") *value = h->pb_stream_device_used;
+    else if (k == "wide_stream_device_used") *value = h->wide_stream_device_used;
     else if (k == "co_tenants") *value = h->co_tenants;
     else if (k == "ingest_device_used") *value = h->ingest_device_used;
     else if (k == "prb_pack_active") *value = h->prb_pack_active;

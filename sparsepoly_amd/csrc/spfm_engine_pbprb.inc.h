@@ -40,37 +40,58 @@ int spfm_engine::ensure_pb_stream(int NG) {
                 return SPFM_OK;
             }
     }
-    std::vector<int32_t> gsp, src;
-    std::vector<uint8_t> meta, tab;
-    build_pb_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, G, NG, pb_balance, gsp, src,
-                    meta, tab);
-    // every bound pbcd_prb_kernel indexes with, checked on the host for problems where that
-    // is free (and on request, SPFM_VALIDATE=1): an out-of-range row or slot index would be
-    // a device memory fault, i.e. a dead process
-    if (nnz < ((int64_t)1 << 22) || getenv("SPFM_VALIDATE")) {
-        const char* bad = validate_pb_stream(G, NG, gsp, src, meta, tab);
-        if (bad) FAIL(SPFM_ERR_RUNTIME, std::string("internal: pbcd entry stream: ") + bad);
-    }
+    const int nb_ = n_batches();
+    const size_t ngsp = (size_t)G * nb_ * ((size_t)NG + 1) + 1;
+    const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
     DevBuf d_src;
-    HIPC(d_src.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
-    HIPC(pb_sp.alloc(sizeof(int32_t) * gsp.size()));
-    HIPC(pb_erow.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1) + 256));
-    HIPC(pb_eval.alloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1) + 256));
-    HIPC(pb_meta.alloc((size_t)(nnz > 0 ? nnz : 1) + 256));
-    HIPC(pb_tab.alloc(tab.size() + 16));
-    HIPC(hipMemcpyAsync(pb_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice, stream));
+    HIPC(d_src.alloc(sizeof(int32_t) * nz));
+    HIPC(pb_sp.alloc(sizeof(int32_t) * ngsp));
+    HIPC(pb_erow.alloc(sizeof(int32_t) * nz + 256));
+    HIPC(pb_eval.alloc(sizeof(T) * nz + 256));
+    HIPC(pb_meta.alloc(nz + 256));
+    HIPC(pb_tab.alloc((size_t)G * (size_t)std::max(nb_, 1) * 64 + 16));
     HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
     HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
     HIPC(pb_stamps.alloc(sizeof(long long) * 16 * (size_t)G));
     HIPC(hipMemsetAsync(pb_stamps.p, 0, pb_stamps.bytes, stream));
     HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
-    HIPC(hipMemcpyAsync(pb_sp.p, gsp.data(), sizeof(int32_t) * gsp.size(),
-                        hipMemcpyHostToDevice, stream));
-    if (nnz > 0) {
-        HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * (size_t)nnz,
+    // the stream: on the device (spfm_ingest.hip device_pb_stream: the host builder's tables
+    // exactly, tests/test_hip_stream.py), or by the host threads (small problems -- which are
+    // audited --, stream_device=0, no room for the scratch)
+    pb_stream_device_used = 0;
+    if (stream_device && nnz >= (1 << 20) && !getenv("SPFM_VALIDATE")) {
+        const hipError_t e = device_pb_stream(
+            n, d, nnz, G, nb_, NG, pb_balance ? 1 : 0, d_order.as<int32_t>(), d_bptr.as<int32_t>(),
+            cptr.as<int64_t>(), cidx.as<int32_t>(), rptr.as<int64_t>(), ridx.as<int32_t>(),
+            pb_sp.as<int32_t>(), d_src.as<int32_t>(), pb_meta.as<uint8_t>(), pb_tab.as<uint8_t>(),
+            stream);
+        if (e == hipSuccess) pb_stream_device_used = 1;
+        else (void)hipGetLastError();
+    }
+    if (!pb_stream_device_used) {
+        std::vector<int32_t> gsp, src;
+        std::vector<uint8_t> meta, tab;
+        build_pb_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, G, NG, pb_balance, gsp,
+                        src, meta, tab);
+        // every bound pbcd_prb_kernel indexes with, checked on the host for problems where that
+        // is free (and on request, SPFM_VALIDATE=1): an out-of-range row or slot index would be
+        // a device memory fault, i.e. a dead process
+        if (nnz < ((int64_t)1 << 22) || getenv("SPFM_VALIDATE")) {
+            const char* bad = validate_pb_stream(G, NG, gsp, src, meta, tab);
+            if (bad) FAIL(SPFM_ERR_RUNTIME, std::string("internal: pbcd entry stream: ") + bad);
+        }
+        HIPC(hipMemcpyAsync(pb_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(pb_sp.p, gsp.data(), sizeof(int32_t) * gsp.size(),
                             hipMemcpyHostToDevice, stream));
-        HIPC(hipMemcpyAsync(pb_meta.p, meta.data(), (size_t)nnz, hipMemcpyHostToDevice,
-                            stream));
+        if (nnz > 0) {
+            HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * (size_t)nnz,
+                                hipMemcpyHostToDevice, stream));
+            HIPC(hipMemcpyAsync(pb_meta.p, meta.data(), (size_t)nnz, hipMemcpyHostToDevice,
+                                stream));
+        }
+        HIPC(hipStreamSynchronize(stream));  // the host staging vectors die here
+    }
+    if (nnz > 0) {
         hipLaunchKernelGGL((prb_gather_kernel<T>), dim3(cdiv(nnz, 256)), dim3(256), 0, stream,
                            nnz, d_src.as<int32_t>(), cidx.as<int32_t>(), cval.as<T>(),
                            pb_erow.as<int32_t>(), pb_eval.as<T>());

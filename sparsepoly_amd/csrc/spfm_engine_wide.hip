@@ -35,16 +35,20 @@ int spfm_engine::ensure_wide() {
     HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
     const int G = wide_groups(ncu, (size_t)lds_max);
     if (wide_ready && wide_G == G) return SPFM_OK;
-    std::vector<int32_t> wbase, wsp, src;
-    std::vector<uint8_t> hz;
-    build_wide_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, G, wbase, wsp, src, hz);
+    const int nb_ = n_batches();
+    const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
+    // wbase[b] = columns + steps in front of step b (ncols + 1 boundaries per step)
+    std::vector<int32_t> wbase((size_t)nb_ + 1, 0);
+    for (int b = 0; b < nb_; ++b)
+        wbase[(size_t)b + 1] = wbase[(size_t)b] + (batch_ptr[b + 1] - batch_ptr[b]) + 1;
+    const size_t tot = (size_t)wbase[(size_t)nb_];
     DevBuf d_src, d_hz;
-    HIPC(d_src.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
-    HIPC(d_hz.alloc((size_t)(nnz > 0 ? nnz : 1)));
+    HIPC(d_src.alloc(sizeof(int32_t) * nz));
+    HIPC(d_hz.alloc(nz));
     HIPC(w_wbase.alloc(sizeof(int32_t) * wbase.size()));
-    HIPC(w_wsp.alloc(sizeof(int32_t) * wsp.size()));
-    HIPC(w_erow.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1) + 64));
-    HIPC(w_eval.alloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1) + 64));
+    HIPC(w_wsp.alloc(sizeof(int32_t) * ((size_t)G * tot + 1)));
+    HIPC(w_erow.alloc(sizeof(int32_t) * nz + 64));
+    HIPC(w_eval.alloc(sizeof(T) * nz + 64));
     HIPC(w_slabA.alloc(sizeof(double) * 2 * 32 * (size_t)G * 32));
     HIPC(w_slabB.alloc(sizeof(double) * 2 * 32 * 32));
     HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
@@ -54,12 +58,31 @@ int spfm_engine::ensure_wide() {
     HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
     HIPC(hipMemcpyAsync(w_wbase.p, wbase.data(), sizeof(int32_t) * wbase.size(),
                         hipMemcpyHostToDevice, stream));
-    HIPC(hipMemcpyAsync(w_wsp.p, wsp.data(), sizeof(int32_t) * wsp.size(),
-                        hipMemcpyHostToDevice, stream));
-    if (nnz > 0) {
-        HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * (size_t)nnz,
+    // the stream: on the device (spfm_ingest.hip device_wide_stream: the host builder's tables
+    // exactly, tests/test_hip_stream.py) or by the host threads
+    wide_stream_device_used = 0;
+    if (stream_device && nnz >= (1 << 20) && (int64_t)d + nb_ < ((int64_t)1 << 31) / std::max(G, 1)) {
+        const hipError_t e = device_wide_stream(
+            n, d, nnz, G, nb_, d_order.as<int32_t>(), d_bptr.as<int32_t>(), cptr.as<int64_t>(),
+            cidx.as<int32_t>(), rptr.as<int64_t>(), ridx.as<int32_t>(), w_wsp.as<int32_t>(),
+            d_src.as<int32_t>(), d_hz.as<uint8_t>(), stream);
+        if (e == hipSuccess) wide_stream_device_used = 1;
+        else (void)hipGetLastError();
+    }
+    if (!wide_stream_device_used) {
+        std::vector<int32_t> wb2, wsp, src;
+        std::vector<uint8_t> hz;
+        build_wide_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, G, wb2, wsp, src, hz);
+        HIPC(hipMemcpyAsync(w_wsp.p, wsp.data(), sizeof(int32_t) * wsp.size(),
                             hipMemcpyHostToDevice, stream));
-        HIPC(hipMemcpyAsync(d_hz.p, hz.data(), (size_t)nnz, hipMemcpyHostToDevice, stream));
+        if (nnz > 0) {
+            HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * (size_t)nnz,
+                                hipMemcpyHostToDevice, stream));
+            HIPC(hipMemcpyAsync(d_hz.p, hz.data(), (size_t)nnz, hipMemcpyHostToDevice, stream));
+        }
+        HIPC(hipStreamSynchronize(stream));  // the host staging vectors die here
+    }
+    if (nnz > 0) {
         hipLaunchKernelGGL((pcdw_gather_kernel<T>), dim3(cdiv(nnz, 256)), dim3(256), 0, stream,
                            nnz, d_src.as<int32_t>(), d_hz.as<uint8_t>(), cidx.as<int32_t>(),
                            cval.as<T>(), w_erow.as<int32_t>(), w_eval.as<T>());
@@ -70,7 +93,7 @@ int spfm_engine::ensure_wide() {
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(stream));
     wide_G = G;
-    wide_tot = (int)wbase.back();
+    wide_tot = (int)tot;
     wide_ready = true;
     return SPFM_OK;
 }

@@ -296,4 +296,314 @@ hipError_t device_rowblock_stream(int64_t n, int32_t d, int64_t nnz, int G, int 
     return done(hipSuccess);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Entry streams of the persistent pbcd pass and of the wide passes on the device (round 4; host
+// forms: spfm_schedule.cpp build_pb_stream / build_wide_stream; bitwise the same tables).
+// Both sort a (row block, step)'s entries by (slot order, row) and flag the entries whose row
+// the previous step touched.  Counts and positions come from the two binary searches per
+// (column, row block) of the row-block stream above.  "Touched by the previous step" is a
+// property of the ROW: some other column of the row sits in step b-1 -- read off the CSR image
+// (a row's ~50 columns) with step_of[column].
+// ---------------------------------------------------------------------------------------------
+
+// step_of[column] = its step in the schedule
+__global__ void sb_step_of_kernel(int32_t d, int nb, const int32_t* __restrict__ order,
+                                  const int32_t* __restrict__ bptr, int32_t* __restrict__ step_of) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= d) return;
+    int blo = 0, bhi = nb;
+    while (bhi - blo > 1) {
+        const int mid = (blo + bhi) >> 1;
+        if (bptr[mid] <= pos) blo = mid;
+        else bhi = mid;
+    }
+    step_of[order[pos]] = blo;
+}
+
+__device__ __forceinline__ int sb_row_in_step(const int64_t* __restrict__ rptr,
+                                              const int32_t* __restrict__ ridx,
+                                              const int32_t* __restrict__ step_of, int32_t row,
+                                              int step) {
+    if (step < 0) return 0;
+    int hit = 0;
+    for (int64_t c = rptr[row]; c < rptr[row + 1]; ++c) hit |= (step_of[ridx[c]] == step);
+    return hit;
+}
+
+// ---- pbcd stream.  thread <-> (visiting position pos, row block g), g fastest: entries of the
+// column in the block
+__global__ void pbs_count_kernel(int32_t d, int G, int nb, int64_t rows_per,
+                                 const int32_t* __restrict__ order, const int32_t* __restrict__ bptr,
+                                 const int64_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
+                                 int32_t* __restrict__ cnt /* [G][nb][64] */,
+                                 int32_t* __restrict__ first) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)d * G) return;
+    const int pos = (int)(t / G), g = (int)(t % G);
+    int blo = 0, bhi = nb;
+    while (bhi - blo > 1) {
+        const int mid = (blo + bhi) >> 1;
+        if (bptr[mid] <= pos) blo = mid;
+        else bhi = mid;
+    }
+    const int b = blo, q = pos - bptr[b];
+    const int32_t j = order[pos];
+    const int64_t cb = cptr[j], ce = cptr[j + 1];
+    const int64_t lo = rbs_lower_bound(cidx, cb, ce, (int64_t)g * rows_per);
+    const int64_t hi = rbs_lower_bound(cidx, lo, ce, (int64_t)(g + 1) * rows_per);
+    first[t] = (int32_t)lo;
+    cnt[((size_t)g * nb + b) * 64 + q] = (int32_t)(hi - lo);
+}
+
+// thread <-> (g, b): the slot -> (group, t) map (build_pb_stream's rule: columns in descending
+// order of their entries, ties by slot, each to the group with the fewest entries so far that
+// still has room, ties by group), the groups' entry counts, every slot's offset inside its group
+__global__ void pbs_assign_kernel(int G, int nb, int NG, int balance,
+                                  const int32_t* __restrict__ bptr, const int32_t* __restrict__ cnt,
+                                  uint8_t* __restrict__ tab /* [G][nb][64] */,
+                                  int32_t* __restrict__ gcnt /* [G][nb][NG+1] */,
+                                  int32_t* __restrict__ soff /* [G][nb][64] */,
+                                  uint8_t* __restrict__ where /* [G][nb][64] */) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)G * nb) return;
+    const int b = (int)(t % nb);
+    const int QM = 64 / NG;
+    const int nc = bptr[b + 1] - bptr[b];
+    const int nc2 = b + 2 < nb ? bptr[b + 3] - bptr[b + 2] : 0;
+    const int nw = min(64, max(nc, nc2));
+    const int32_t* c = cnt + (size_t)t * 64;
+    uint8_t* tb = tab + (size_t)t * 64;
+    int32_t* gc = gcnt + (size_t)t * (NG + 1);
+    int32_t* so = soff + (size_t)t * 64;
+    uint8_t* wh = where + (size_t)t * 64;
+    int load[16], used[16];
+    for (int r = 0; r < NG; ++r) load[r] = used[r] = 0;
+    for (int z = 0; z < 64; ++z) tb[z] = 0xFF;
+    if (!balance) {
+        for (int q = 0; q < nw; ++q) {
+            const int r = q % NG, tt = q / NG;
+            tb[r * QM + tt] = (uint8_t)q;
+            wh[q] = (uint8_t)((r << 3) | tt);
+            load[r] += q < nc ? c[q] : 0;
+        }
+    } else {
+        uint8_t idx[64];
+        for (int q = 0; q < nw; ++q) {  // stable insertion sort, descending by count
+            const int cq = q < nc ? c[q] : 0;
+            int z = q;
+            while (z > 0) {
+                const int pz = idx[z - 1];
+                if ((pz < nc ? c[pz] : 0) >= cq) break;
+                idx[z] = idx[z - 1];
+                --z;
+            }
+            idx[z] = (uint8_t)q;
+        }
+        for (int z = 0; z < nw; ++z) {
+            const int q = idx[z];
+            int best = -1;
+            for (int r = 0; r < NG; ++r)
+                if (used[r] < QM && (best < 0 || load[r] < load[best])) best = r;
+            tb[best * QM + used[best]] = (uint8_t)q;
+            wh[q] = (uint8_t)((best << 3) | used[best]);
+            used[best]++;
+            load[best] += q < nc ? c[q] : 0;
+        }
+    }
+    for (int r = 0; r < NG; ++r) {
+        gc[r] = load[r];
+        int at = 0;
+        for (int tt = 0; tt < QM; ++tt) {
+            const int q = tb[r * QM + tt];
+            if (q == 0xFF) continue;
+            so[q] = at;
+            at += q < nc ? c[q] : 0;
+        }
+    }
+    gc[NG] = 0;
+}
+
+// thread <-> (pos, g): the column's entries in the block go to their slot's place; meta = t |
+// 0x80 (row touched by the previous step)
+__global__ void pbs_fill_kernel(int32_t d, int G, int nb, int NG, const int32_t* __restrict__ bptr,
+                                const int32_t* __restrict__ cidx, const int32_t* __restrict__ cnt,
+                                const int32_t* __restrict__ gsp, const int32_t* __restrict__ soff,
+                                const uint8_t* __restrict__ where,
+                                const int32_t* __restrict__ first, const int64_t* __restrict__ rptr,
+                                const int32_t* __restrict__ ridx,
+                                const int32_t* __restrict__ step_of, int32_t* __restrict__ src,
+                                uint8_t* __restrict__ meta) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)d * G) return;
+    const int pos = (int)(t / G), g = (int)(t % G);
+    int blo = 0, bhi = nb;
+    while (bhi - blo > 1) {
+        const int mid = (blo + bhi) >> 1;
+        if (bptr[mid] <= pos) blo = mid;
+        else bhi = mid;
+    }
+    const int b = blo, q = pos - bptr[b];
+    const size_t gb = (size_t)g * nb + b;
+    const int32_t m = cnt[gb * 64 + q], lo = first[t];
+    const int w = where[gb * 64 + q];
+    const int32_t dst = gsp[gb * (NG + 1) + (w >> 3)] + soff[gb * 64 + q];
+    for (int32_t u = 0; u < m; ++u) {
+        src[(size_t)dst + u] = lo + u;
+        const int hz = sb_row_in_step(rptr, ridx, step_of, cidx[lo + u], b - 1);
+        meta[(size_t)dst + u] = (uint8_t)((w & 7) | (hz ? 0x80 : 0));
+    }
+}
+
+// Device pointers in: order[d], bptr[nb+1], cptr / cidx (CSC), rptr / ridx (CSR of the same
+// matrix).  Out (device, allocated by the caller): gsp[G*nb*(NG+1) + 1], src[nnz], meta[nnz],
+// tab[G*nb*64].  Scratch (step_of, counts, offsets) is allocated and freed inside.
+hipError_t device_pb_stream(int64_t n, int32_t d, int64_t nnz, int G, int nb, int NG, int balance,
+                            const int32_t* order, const int32_t* bptr, const int64_t* cptr,
+                            const int32_t* cidx, const int64_t* rptr, const int32_t* ridx,
+                            int32_t* gsp, int32_t* src, uint8_t* meta, uint8_t* tab,
+                            hipStream_t stream) {
+    hipError_t e;
+    int32_t *cnt = nullptr, *first = nullptr, *gcnt = nullptr, *soff = nullptr, *step_of = nullptr;
+    uint8_t* where = nullptr;
+    void* temp = nullptr;
+    auto done = [&](hipError_t rc) {
+        (void)hipFree(cnt);
+        (void)hipFree(first);
+        (void)hipFree(gcnt);
+        (void)hipFree(soff);
+        (void)hipFree(step_of);
+        (void)hipFree(where);
+        (void)hipFree(temp);
+        return rc;
+    };
+    if (NG > 16 || NG < 1 || nb < 1) return hipErrorInvalidValue;
+    const int64_t rows_per = (n + G - 1) / G > 0 ? (n + G - 1) / G : 1;
+    const size_t gbn = (size_t)G * nb;
+    const size_t ngsp = gbn * (size_t)(NG + 1) + 1;
+    const int64_t pairs = (int64_t)d * G;
+    if ((e = hipMalloc(&cnt, sizeof(int32_t) * gbn * 64)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&first, sizeof(int32_t) * (size_t)(pairs > 0 ? pairs : 1))) != hipSuccess)
+        return done(e);
+    if ((e = hipMalloc(&gcnt, sizeof(int32_t) * ngsp)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&soff, sizeof(int32_t) * gbn * 64)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&where, gbn * 64)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&step_of, sizeof(int32_t) * (size_t)d)) != hipSuccess) return done(e);
+    if ((e = hipMemsetAsync(cnt, 0, sizeof(int32_t) * gbn * 64, stream)) != hipSuccess) return done(e);
+    if ((e = hipMemsetAsync(gcnt, 0, sizeof(int32_t) * ngsp, stream)) != hipSuccess) return done(e);
+    hipLaunchKernelGGL(sb_step_of_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, stream, d,
+                       nb, order, bptr, step_of);
+    const unsigned blocks = (unsigned)((pairs + 255) / 256);
+    hipLaunchKernelGGL(pbs_count_kernel, dim3(blocks), dim3(256), 0, stream, d, G, nb, rows_per, order,
+                       bptr, cptr, cidx, cnt, first);
+    hipLaunchKernelGGL(pbs_assign_kernel, dim3((unsigned)((gbn + 127) / 128)), dim3(128), 0, stream, G,
+                       nb, NG, balance, bptr, cnt, tab, gcnt, soff, where);
+    size_t temp_bytes = 0;
+    if ((e = rocprim::exclusive_scan(nullptr, temp_bytes, gcnt, gsp, (int32_t)0, ngsp,
+                                     rocprim::plus<int32_t>(), stream)) != hipSuccess)
+        return done(e);
+    if ((e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16)) != hipSuccess) return done(e);
+    if ((e = rocprim::exclusive_scan(temp, temp_bytes, gcnt, gsp, (int32_t)0, ngsp,
+                                     rocprim::plus<int32_t>(), stream)) != hipSuccess)
+        return done(e);
+    hipLaunchKernelGGL(pbs_fill_kernel, dim3(blocks), dim3(256), 0, stream, d, G, nb, NG, bptr, cidx,
+                       cnt, gsp, soff, where, first, rptr, ridx, step_of, src, meta);
+    if ((e = hipGetLastError()) != hipSuccess) return done(e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e);
+    (void)nnz;
+    return done(hipSuccess);
+}
+
+// ---- wide stream: entries sorted by (row block g, step b, slot q, row); wsp[g*tot + wbase[b] + q]
+// (ncols + 1 boundaries per step, tot = d + nb); hz[e] = row touched by the previous step
+__global__ void wds_count_kernel(int32_t d, int G, int nb, int64_t rows_per, int tot,
+                                 const int32_t* __restrict__ order, const int32_t* __restrict__ bptr,
+                                 const int64_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
+                                 int32_t* __restrict__ cnt, int32_t* __restrict__ first) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)d * G) return;
+    const int pos = (int)(t / G), g = (int)(t % G);
+    int blo = 0, bhi = nb;
+    while (bhi - blo > 1) {
+        const int mid = (blo + bhi) >> 1;
+        if (bptr[mid] <= pos) blo = mid;
+        else bhi = mid;
+    }
+    const int32_t j = order[pos];
+    const int64_t cb = cptr[j], ce = cptr[j + 1];
+    const int64_t lo = rbs_lower_bound(cidx, cb, ce, (int64_t)g * rows_per);
+    const int64_t hi = rbs_lower_bound(cidx, lo, ce, (int64_t)(g + 1) * rows_per);
+    first[t] = (int32_t)lo;
+    // wbase[b] + q = bptr[b] + b + (pos - bptr[b]) = pos + b
+    cnt[(size_t)g * tot + (size_t)pos + (size_t)blo] = (int32_t)(hi - lo);
+}
+
+__global__ void wds_fill_kernel(int32_t d, int G, int nb, int tot, const int32_t* __restrict__ bptr,
+                                const int32_t* __restrict__ cidx, const int32_t* __restrict__ cnt,
+                                const int32_t* __restrict__ wsp, const int32_t* __restrict__ first,
+                                const int64_t* __restrict__ rptr, const int32_t* __restrict__ ridx,
+                                const int32_t* __restrict__ step_of, int32_t* __restrict__ src,
+                                uint8_t* __restrict__ hz) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)d * G) return;
+    const int pos = (int)(t / G), g = (int)(t % G);
+    int blo = 0, bhi = nb;
+    while (bhi - blo > 1) {
+        const int mid = (blo + bhi) >> 1;
+        if (bptr[mid] <= pos) blo = mid;
+        else bhi = mid;
+    }
+    const size_t at = (size_t)g * tot + (size_t)pos + (size_t)blo;
+    const int32_t m = cnt[at], dst = wsp[at], lo = first[t];
+    for (int32_t u = 0; u < m; ++u) {
+        src[(size_t)dst + u] = lo + u;
+        hz[(size_t)dst + u] = (uint8_t)sb_row_in_step(rptr, ridx, step_of, cidx[lo + u], blo - 1);
+    }
+}
+
+// Out (device, allocated by the caller): wsp[G*tot + 1], src[nnz], hz[nnz]; tot = d + nb.
+hipError_t device_wide_stream(int64_t n, int32_t d, int64_t nnz, int G, int nb,
+                              const int32_t* order, const int32_t* bptr, const int64_t* cptr,
+                              const int32_t* cidx, const int64_t* rptr, const int32_t* ridx,
+                              int32_t* wsp, int32_t* src, uint8_t* hz, hipStream_t stream) {
+    hipError_t e;
+    int32_t *cnt = nullptr, *first = nullptr, *step_of = nullptr;
+    void* temp = nullptr;
+    auto done = [&](hipError_t rc) {
+        (void)hipFree(cnt);
+        (void)hipFree(first);
+        (void)hipFree(step_of);
+        (void)hipFree(temp);
+        return rc;
+    };
+    const int64_t rows_per = (n + G - 1) / G > 0 ? (n + G - 1) / G : 1;
+    const int tot = d + nb;
+    const size_t nw = (size_t)G * (size_t)tot + 1;
+    const int64_t pairs = (int64_t)d * G;
+    if ((e = hipMalloc(&cnt, sizeof(int32_t) * nw)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(&first, sizeof(int32_t) * (size_t)(pairs > 0 ? pairs : 1))) != hipSuccess)
+        return done(e);
+    if ((e = hipMalloc(&step_of, sizeof(int32_t) * (size_t)d)) != hipSuccess) return done(e);
+    if ((e = hipMemsetAsync(cnt, 0, sizeof(int32_t) * nw, stream)) != hipSuccess) return done(e);
+    hipLaunchKernelGGL(sb_step_of_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, stream, d,
+                       nb, order, bptr, step_of);
+    const unsigned blocks = (unsigned)((pairs + 255) / 256);
+    hipLaunchKernelGGL(wds_count_kernel, dim3(blocks), dim3(256), 0, stream, d, G, nb, rows_per, tot,
+                       order, bptr, cptr, cidx, cnt, first);
+    size_t temp_bytes = 0;
+    if ((e = rocprim::exclusive_scan(nullptr, temp_bytes, cnt, wsp, (int32_t)0, nw,
+                                     rocprim::plus<int32_t>(), stream)) != hipSuccess)
+        return done(e);
+    if ((e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16)) != hipSuccess) return done(e);
+    if ((e = rocprim::exclusive_scan(temp, temp_bytes, cnt, wsp, (int32_t)0, nw,
+                                     rocprim::plus<int32_t>(), stream)) != hipSuccess)
+        return done(e);
+    hipLaunchKernelGGL(wds_fill_kernel, dim3(blocks), dim3(256), 0, stream, d, G, nb, tot, bptr, cidx,
+                       cnt, wsp, first, rptr, ridx, step_of, src, hz);
+    if ((e = hipGetLastError()) != hipSuccess) return done(e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e);
+    (void)nnz;
+    return done(hipSuccess);
+}
+
 }  // namespace spfm

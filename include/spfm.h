@@ -367,6 +367,11 @@ int spfm_debug_exchange_cost(spfm_handle h, int groups, int ncols, int readers_m
  * pass's own access pattern) and nothing else; bytes_out receives the bytes it requested.  Run
  * under `rocprofv3 --pmc FETCH_SIZE` to see what the counter reports for that known quantity. */
 int spfm_debug_stream_probe(spfm_handle h, int64_t* bytes_out);
+/* Diagnostic (tools/write_calibration.py): one launch that stores ONE record of
+ * bytes_per_record (4, 8 or 16) bytes per matrix entry at the entry's row -- the scatter pattern of
+ * the persistent passes that keep their rows in global memory -- and writes nothing else;
+ * *bytes_out = the bytes requested (nnz * bytes_per_record).  Calibrates WRITE_SIZE. */
+int spfm_debug_write_probe(spfm_handle h, int bytes_per_record, int64_t* bytes_out);
 int spfm_debug_branch_counts(spfm_handle h, unsigned* out8, int reset);
 
 #ifdef __cplusplus

@@ -91,7 +91,7 @@ SYMBOLS = [
     "spfm_host_pass_begin", "spfm_host_step_sums", "spfm_host_step_apply", "spfm_host_epoch_end", "spfm_comm_unique_id", "spfm_comm_init", "spfm_comm_init_shm", "spfm_peer_alloc", "spfm_peer_connect",
     "spfm_profile_enable", "spfm_profile_get", "spfm_profile_reset", "spfm_set_use_graph",
     "spfm_set_option", "spfm_get_option", "spfm_debug_prb_stamps", "spfm_debug_hop_latency", "spfm_debug_exchange_cost",
-    "spfm_debug_branch_counts", "spfm_debug_stream_probe",
+    "spfm_debug_branch_counts", "spfm_debug_stream_probe", "spfm_debug_write_probe",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -165,6 +165,7 @@ def load():
     L.spfm_peer_connect.argtypes = [_h, C.c_int, C.c_int, C.c_char_p]
     L.spfm_debug_branch_counts.argtypes = [_h, C.POINTER(C.c_uint32), C.c_int]
     L.spfm_debug_stream_probe.argtypes = [_h, _lp]
+    L.spfm_debug_write_probe.argtypes = [_h, C.c_int, _lp]
     for name in SYMBOLS:
         f = getattr(L, name)
         if name not in ("spfm_destroy", "spfm_last_error", "spfm_build_tag"):

@@ -797,6 +797,7 @@ struct spfm_engine {
 
     // diagnostics that need kernels of one translation unit
     int debug_stream_probe(int64_t* bytes_out);  // spfm_engine_pcd.hip
+    int debug_write_probe(int bytes, int64_t* bytes_out);
 };
 
 // The device branch counters (spfm_common.hip.h: g_branch_count) exist once per translation

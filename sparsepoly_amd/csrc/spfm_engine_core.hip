@@ -1853,6 +1853,11 @@ int spfm_debug_stream_probe(spfm_handle h, int64_t* bytes_out) {
     return h->debug_stream_probe(bytes_out);
 }
 
+int spfm_debug_write_probe(spfm_handle h, int bytes_per_record, int64_t* bytes_out) {
+    GUARD(h);
+    return h->debug_write_probe(bytes_per_record, bytes_out);
+}
+
 int spfm_debug_branch_counts(spfm_handle h, unsigned* out8, int reset) {
     GUARD(h);
     if (!out8) return SPFM_ERR_INVALID;

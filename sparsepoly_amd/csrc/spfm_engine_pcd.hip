@@ -429,6 +429,32 @@ int spfm_engine::debug_stream_probe(int64_t* bytes_out) {
     return SPFM_OK;
 }
 
+// tools/write_calibration.py: one `bytes`-wide store per entry at the entry's row, the scatter
+// pattern of the passes that keep their rows in global memory, and nothing else written
+int spfm_engine::debug_write_probe(int bytes, int64_t* bytes_out) {
+    if (!have_schedule || !prb_usable())
+        FAIL(SPFM_ERR_INVALID, "write probe: needs a schedule the 64-column persistent pass can run");
+    if (bytes != 4 && bytes != 8 && bytes != 16) FAIL(SPFM_ERR_INVALID, "write probe: 4, 8 or 16 bytes");
+    int rc = dtype == SPFM_F32 ? ensure_prb<float>() : ensure_prb<double>();
+    if (rc) return rc;
+    DevBuf recs;
+    if (recs.alloc((size_t)16 * (size_t)(n > 0 ? n : 1)) != hipSuccess)
+        FAIL(SPFM_ERR_RUNTIME, "write probe: allocation failed");
+    const PrbArgs a = prb_args();
+    if (bytes == 4)
+        hipLaunchKernelGGL((prb_write_probe_kernel<4>), dim3(prb_G), dim3(kPrbThreads), 0, stream, a,
+                           recs.as<float>());
+    else if (bytes == 8)
+        hipLaunchKernelGGL((prb_write_probe_kernel<8>), dim3(prb_G), dim3(kPrbThreads), 0, stream, a,
+                           recs.as<float>());
+    else
+        hipLaunchKernelGGL((prb_write_probe_kernel<16>), dim3(prb_G), dim3(kPrbThreads), 0, stream,
+                           a, recs.as<float>());
+    if (hipStreamSynchronize(stream) != hipSuccess) FAIL(SPFM_ERR_RUNTIME, "write probe kernel failed");
+    if (bytes_out) *bytes_out = nnz * (int64_t)bytes;
+    return SPFM_OK;
+}
+
 SPFM_DEFINE_BRANCH_COUNTS(spfm_branch_counts_pcd)
 
 // used by the pbcd unit's host-stepped epochs

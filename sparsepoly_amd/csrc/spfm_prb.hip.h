@@ -1725,6 +1725,33 @@ __global__ __launch_bounds__(kPrbThreads) void prb_stream_probe_kernel(PrbArgs a
     sink[(size_t)g * kPrbThreads + tid] = acc;
 }
 
+// Diagnostic: the SCATTER side of a persistent pass with its rows in global memory -- every
+// worker thread stores one BYTES-wide record per entry at its row (records[row]), the store
+// pattern of pcd_prb_kernel's packed-record scatter (degree 3: 16 bytes per row; plain arrays: 4
+// or 8), and nothing else is written.  Counter calibration: its WRITE_SIZE under rocprofv3
+// against nnz * BYTES.
+template <int BYTES>
+__global__ __launch_bounds__(kPrbThreads) void prb_write_probe_kernel(PrbArgs a,
+                                                                     float* __restrict__ records) {
+    static_assert(BYTES == 4 || BYTES == 8 || BYTES == 16, "record width");
+    const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    const bool worker = wave >= 1 && wave <= 4;
+    const int wt = tid - 64, slot = worker ? (wt >> 2) : 64, sub = wt & 3;
+    for (int b = 0; b < a.nb; ++b) {
+        const int ncols = a.bptr[b + 1] - a.bptr[b];
+        int e0, e1;
+        unsigned long long lm;
+        prb_load_sp(a, g, b, slot, ncols, e0, e1, lm);
+        for (int e = e0 + sub; e < e1; e += 4) {
+            const size_t row = (size_t)a.erow[e];
+            const float v = (float)(b + e);
+            if constexpr (BYTES == 4) records[row] = v;
+            else if constexpr (BYTES == 8) reinterpret_cast<float2*>(records)[row] = make_float2(v, v);
+            else reinterpret_cast<float4*>(records)[row] = make_float4(v, v, v, v);
+        }
+    }
+}
+
 // out[pos] = v[desc[pos].j]
 static __global__ void gather_sched_kernel(int d, const ColDesc* __restrict__ desc,
                                     const double* __restrict__ v, double* __restrict__ out) {

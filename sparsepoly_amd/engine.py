@@ -636,6 +636,13 @@ class HipEngine(object):
         self._check(self._lib.spfm_debug_stream_probe(self._h, C.byref(nb)))
         return nb.value
 
+    def debug_write_probe(self, bytes_per_record):
+        """One launch that stores one record of 4, 8 or 16 bytes per matrix entry at the entry's
+        row and writes nothing else; returns the bytes it requested (WRITE_SIZE calibration)."""
+        nb = C.c_int64()
+        self._check(self._lib.spfm_debug_write_probe(self._h, int(bytes_per_record), C.byref(nb)))
+        return nb.value
+
     def get_option(self, key):
         v = C.c_int()
         self._check(self._lib.spfm_get_option(self._h, key.encode(), C.byref(v)))

@@ -46,8 +46,9 @@ void build_wide_stream(int64_t, const int64_t*, const int32_t*, const std::vecto
                        const std::vector<int32_t>&, int, std::vector<int32_t>&,
                        std::vector<int32_t>&, std::vector<int32_t>&, std::vector<uint8_t>&);
 void build_pb_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
-                     const std::vector<int32_t>&, int, int, bool, std::vector<int32_t>&,
-                     std::vector<int32_t>&, std::vector<uint8_t>&, std::vector<uint8_t>&);
+                     const std::vector<int32_t>&, int, int, bool, const uint8_t*,
+                     std::vector<int32_t>&, std::vector<int32_t>&, std::vector<uint8_t>&,
+                     std::vector<uint8_t>&);
 void build_rowblock_stream(int64_t, const int64_t*, const int32_t*, const std::vector<int32_t>&,
                            const std::vector<int32_t>&, int, int, std::vector<int32_t>&,
                            std::vector<int32_t>&, std::vector<uint32_t>&, const uint8_t*);
@@ -303,6 +304,13 @@ struct spfm_engine {
     bool pb_stream_ready = false;
     int pb_stream_G = 0, pb_stream_NG = 0;
     DevBuf pb_tab;            // its (workgroup, step) -> slot groups map (gtab)
+    // relaxed runs of the persistent pbcd pass (pbcd_prb_kernel CR): merged step boundaries,
+    // their entry stream, the conflict tables
+    int pbr_state = 0;        // 0 not tried for this schedule, 1 in use, -1 not worth it
+    int pbr_G = 0, pb_relax_active = 0;
+    std::vector<int32_t> pbr_batch_ptr;
+    DevBuf pbr_bptr, pbr_sp, pbr_erow, pbr_eval, pbr_meta, pbr_tab, pbr_cfptr, pbr_cf, pbr_clist,
+        pbr_slabR;
     bool pb_balance = true;   // balanced slot groups (0: the fixed map slot q -> group q % NG)
     DevBuf pb_sp, pb_erow, pb_eval, pb_meta, pb_slabA, pb_slabB, pb_slabC, pb_stamps, pb_rec;
     bool pb_stamp_on = false;
@@ -708,6 +716,8 @@ struct spfm_engine {
 
     template <typename T>
     int ensure_pb_stream(int NG);
+    template <typename T>
+    int ensure_pb_relax(int NG);
 
     template <typename T, int M, int L>
     int pbcd_prb_l(int order_idx, double beta, double gamma, double eta);

@@ -742,6 +742,7 @@ int spfm_engine::install_schedule() {
     pb_stream_ready = false;
     wide_ready = false;
     relax_state = 0;
+    pbr_state = 0;
     ++sched_version;
     clear_graphs();
     return alloc_work();
@@ -1567,9 +1568,10 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->colour_device = value != 0;
     } else if (k == "ingest_device") {  // CSR -> CSC on the device (default) or by host threads
         h->ingest_device = value != 0;
-    } else if (k == "relax") {  // merged steps for schedules of tiny steps (DESIGN 3f)
+    } else if (k == "relax") {  // merged steps for schedules of tiny steps (DESIGN 4b)
         h->relax_on = value != 0;
         h->relax_state = 0;
+        h->pbr_state = 0;
     } else if (k == "prb_stamps") {
         h->prb_stamp_on = value != 0;
     } else if (k == "debug_spin_max") {  // test hook: polls before a persistent pass gives up
@@ -1646,6 +1648,7 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         }
         h->pbprb_G = value;
         h->pb_stream_ready = false;
+        h->pbr_state = 0;
     } else if (k == "prb_lds") {
         h->prb_lds = value != 0;
     } else if (k == "prb_groups") {
@@ -1703,7 +1706,9 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "ingest_device_used") *value = h->ingest_device_used;
     else if (k == "prb_pack_active") *value = h->prb_pack_active;
     else if (k == "relax_steps")
-        *value = h->relax_state == 1 ? (int)h->r_batch_ptr.size() - 1 : 0;
+        *value = h->relax_state == 1 ? (int)h->r_batch_ptr.size() - 1
+                                     : (h->pbr_state == 1 ? (int)h->pbr_batch_ptr.size() - 1 : 0);
+    else if (k == "pb_relax_active") *value = h->pb_relax_active;
     else if (k == "persistent_fallbacks") *value = h->pers_fallbacks;
     else if (k == "persistent_failed") *value = h->pers_failed;
     else if (k == "n_ranks") *value = h->dist() ? h->n_ranks : 1;

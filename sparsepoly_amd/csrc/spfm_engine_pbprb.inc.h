@@ -71,8 +71,8 @@ int spfm_engine::ensure_pb_stream(int NG) {
     if (!pb_stream_device_used) {
         std::vector<int32_t> gsp, src;
         std::vector<uint8_t> meta, tab;
-        build_pb_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, G, NG, pb_balance, gsp,
-                        src, meta, tab);
+        build_pb_stream(n, h_cptr.data(), h_cidx.data(), order, batch_ptr, G, NG, pb_balance,
+                        nullptr, gsp, src, meta, tab);
         // every bound pbcd_prb_kernel indexes with, checked on the host for problems where that
         // is free (and on request, SPFM_VALIDATE=1): an out-of-range row or slot index would be
         // a device memory fault, i.e. a dead process
@@ -115,14 +115,105 @@ int spfm_engine::ensure_pb_stream(int NG) {
     return SPFM_OK;
 }
 
+// ---- relaxed runs for pbcd: a schedule of tiny strict steps -- the reference's own
+// order -- is run as merged steps whose conflict rows every workgroup replays (pbcd_prb_kernel
+// CR).  Its own step boundaries, conflict tables and entry stream (fixed slot map, the entries on
+// conflict rows left out); degree 2, k <= 30, one GPU.
+template <typename T>
+int spfm_engine::ensure_pb_relax(int NG) {
+    if (pbr_state != 0) return SPFM_OK;
+    pbr_state = -1;
+    int ncu = 0;
+    HIPC(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+    const int G = std::max(1, std::min(pbprb_G, ncu));
+    std::vector<int32_t> cf_ptr, cf_row, cf_qq;
+    std::vector<int64_t> cf_ia, cf_ib;
+    std::vector<int16_t> clist;
+    std::vector<uint8_t> skip;
+    schedule_relax(n, d, h_cptr.data(), h_cidx.data(), order.data(), 64, 64, pbr_batch_ptr, cf_ptr,
+                   cf_row, cf_qq, cf_ia, cf_ib, clist, skip);
+    const int nbr = (int)pbr_batch_ptr.size() - 1;
+    if ((double)nbr > 0.6 * (double)n_batches()) return SPFM_OK;  // not worth a second stream
+    const size_t ncf = cf_row.size();
+    std::vector<PrbConf<T>> hcf(ncf ? ncf : 1);
+    {
+        std::vector<T> hv((size_t)(nnz > 0 ? nnz : 1));
+        HIPC(hipMemcpyAsync(hv.data(), cval.p, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+        HIPC(hipStreamSynchronize(stream));
+        for (size_t c = 0; c < ncf; ++c) {
+            hcf[c].row = cf_row[c];
+            hcf[c].qq = cf_qq[c];
+            hcf[c].xa = hv[(size_t)cf_ia[c]];
+            hcf[c].xb = hv[(size_t)cf_ib[c]];
+        }
+    }
+    std::vector<int32_t> gsp, src;
+    std::vector<uint8_t> meta, tab;
+    build_pb_stream(n, h_cptr.data(), h_cidx.data(), order, pbr_batch_ptr, G, NG, false, skip.data(),
+                    gsp, src, meta, tab);
+    const size_t ne = src.size();
+    DevBuf d_src;
+    HIPC(d_src.alloc(sizeof(int32_t) * (ne ? ne : 1)));
+    HIPC(pbr_bptr.alloc(sizeof(int32_t) * pbr_batch_ptr.size()));
+    HIPC(pbr_sp.alloc(sizeof(int32_t) * gsp.size()));
+    HIPC(pbr_erow.alloc(sizeof(int32_t) * (ne ? ne : 1) + 256));
+    HIPC(pbr_eval.alloc(sizeof(T) * (ne ? ne : 1) + 256));
+    HIPC(pbr_meta.alloc((ne ? ne : 1) + 256));
+    HIPC(pbr_tab.alloc(tab.size() + 16));
+    HIPC(pbr_cfptr.alloc(sizeof(int32_t) * cf_ptr.size()));
+    HIPC(pbr_cf.alloc(sizeof(PrbConf<T>) * hcf.size()));
+    HIPC(pbr_clist.alloc(sizeof(int16_t) * clist.size() + 64));
+    HIPC(prb_abort.alloc(sizeof(unsigned) * 4));
+    HIPC(prb_viol.alloc(sizeof(double) * (size_t)d));
+    HIPC(hipMemsetAsync(prb_abort.p, 0, sizeof(unsigned) * 4, stream));
+    HIPC(hipMemcpyAsync(pbr_bptr.p, pbr_batch_ptr.data(), sizeof(int32_t) * pbr_batch_ptr.size(),
+                        hipMemcpyHostToDevice, stream));
+    HIPC(hipMemcpyAsync(pbr_sp.p, gsp.data(), sizeof(int32_t) * gsp.size(), hipMemcpyHostToDevice,
+                        stream));
+    HIPC(hipMemcpyAsync(pbr_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice, stream));
+    HIPC(hipMemcpyAsync(pbr_cfptr.p, cf_ptr.data(), sizeof(int32_t) * cf_ptr.size(),
+                        hipMemcpyHostToDevice, stream));
+    HIPC(hipMemcpyAsync(pbr_cf.p, hcf.data(), sizeof(PrbConf<T>) * hcf.size(), hipMemcpyHostToDevice,
+                        stream));
+    HIPC(hipMemcpyAsync(pbr_clist.p, clist.data(), sizeof(int16_t) * clist.size(),
+                        hipMemcpyHostToDevice, stream));
+    if (ne > 0) {
+        HIPC(hipMemcpyAsync(d_src.p, src.data(), sizeof(int32_t) * ne, hipMemcpyHostToDevice, stream));
+        HIPC(hipMemcpyAsync(pbr_meta.p, meta.data(), ne, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL((prb_gather_kernel<T>), dim3(cdiv((int64_t)ne, 256)), dim3(256), 0, stream,
+                           (int64_t)ne, d_src.as<int32_t>(), cidx.as<int32_t>(), cval.as<T>(),
+                           pbr_erow.as<int32_t>(), pbr_eval.as<T>());
+        HIPC(hipGetLastError());
+    }
+    HIPC(hipStreamSynchronize(stream));
+    pbr_G = G;
+    pbr_state = 1;
+    return SPFM_OK;
+}
+
 template <typename T, int M, int L>
 int spfm_engine::pbcd_prb_l(int order_idx, double beta, double gamma, double eta) {
     const double mu = loss == SPFM_LOSS_SQUARED ? 1.0 : (loss == SPFM_LOSS_LOGISTIC ? 0.25 : 2.0);
     double* Po = Pt.as<double>() + (size_t)order_idx * k * d;  // (d,k)
     RegState rs = regstate();
-    int rc = ensure_pb_stream<T>(kPbPrbThreads / L);
-    if (rc) return rc;
-    const int G = pb_stream_G;
+    // relaxed runs: a schedule of tiny steps (the reference order) on one GPU, degree 2, k <= 30
+    bool relaxed = false;
+    int rc = SPFM_OK;
+    constexpr bool can_cr = M == 2 && L == 32;
+    if constexpr (can_cr) {
+        if (relax_on && !dist() && !pb_stamp_on && n_batches() > 0 &&
+            (double)d / (double)n_batches() < 12.0) {
+            rc = ensure_pb_relax<T>(kPbPrbThreads / L);
+            if (rc) return rc;
+            relaxed = pbr_state == 1;
+        }
+    }
+    if (!relaxed) {
+        rc = ensure_pb_stream<T>(kPbPrbThreads / L);
+        if (rc) return rc;
+    }
+    const int G = relaxed ? pbr_G : pb_stream_G;
+    pb_relax_active = relaxed ? 1 : 0;
     // the rows' state as packed records (cache values, yhat, y: one line per row at k <= 30,
     // degree 2, float): the precompute pass of pbcd.py:18-33 writes them
     constexpr int AS = Kind<M>::AS;
@@ -163,6 +254,24 @@ int spfm_engine::pbcd_prb_l(int order_idx, double beta, double gamma, double eta
     a.n_ranks = peer_ready ? n_ranks : 1;
     a.rank = rank;
     a.slabC = peer_ready ? peer_tab_pb.as<double*>() : nullptr;
+    a.cf_ptr = nullptr;
+    a.cf = nullptr;
+    a.clist = nullptr;
+    a.slabR = nullptr;
+    if (relaxed) {
+        a.nb = (int)pbr_batch_ptr.size() - 1;
+        a.bptr = pbr_bptr.as<int32_t>();
+        a.gsp = pbr_sp.as<int32_t>();
+        a.erow = pbr_erow.as<int32_t>();
+        a.emeta = pbr_meta.as<uint8_t>();
+        a.gtab = pbr_tab.as<uint8_t>();
+        a.cf_ptr = pbr_cfptr.as<int32_t>();
+        a.cf = pbr_cf.p;
+        a.clist = pbr_clist.as<int16_t>();
+        HIPC(pbr_slabR.alloc(sizeof(double) * 2 * 64 * L));
+        HIPC(hipMemsetAsync(pbr_slabR.p, 0, sizeof(double) * 2 * 64 * L, stream));
+        a.slabR = pbr_slabR.as<double>();
+    }
     if (peer_ready && L * n_ranks > 64 * 8)
         FAIL(SPFM_ERR_UNSUPPORTED, "persistent pbcd pass: more than 8 ranks");
     a.stamps = pb_stamp_on ? pb_stamps.as<long long>() : nullptr;
@@ -195,8 +304,24 @@ int spfm_engine::pbcd_prb_l(int order_idx, double beta, double gamma, double eta
         FAIL(SPFM_ERR_UNSUPPORTED, "pbprb_stamps: built for float storage, degree 2, k <= 30");
     rc = SPFM_OK;
     bool fired = false;
+    if constexpr (can_cr) {
+        if (relaxed) {
+            auto* fn = pbcd_prb_kernel<T, M, L, false, true>;
+            const size_t lds = std::max(kPrbLds, pbcd_prb_lds_bytes<T, M, L, true>());
+            HIPC(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+            if (!resident_ok((const void*)fn, kPbPrbThreads, lds, G)) {
+                rc = kNotResident;
+            } else {
+                hipLaunchKernelGGL(fn, dim3(launch_groups(G)), dim3(kPbPrbThreads), lds, stream, a,
+                                   pbr_eval.as<T>(), pb_rec.as<T>(), Po, k, d, lams.as<double>(), loss,
+                                   reg, rs, ncache, mu, beta, gamma, eta, prb_viol.as<double>());
+            }
+            fired = true;
+        }
+    }
     if constexpr (can_stamp) {
-        if (pb_stamp_on) {
+        if (!fired && pb_stamp_on) {
             rc = go(std::true_type{});
             fired = true;
         }

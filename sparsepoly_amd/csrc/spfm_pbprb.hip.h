@@ -90,6 +90,13 @@ struct PbPrbArgs {
     unsigned spin_max;     // polls of one wait before the pass gives up (default 2^21)
     int n_ranks, rank;     // multi-GPU: ranks sharing the sweep
     double* const* slabC;  // [n_ranks] slabC[r] = GPU r's [2][64][n_ranks][L] (peer-mapped)
+    // relaxed runs (CR instantiation; spfm_schedule.cpp schedule_relax): the conflict rows of a
+    // step -- rows shared by two of its columns -- are not in the entry stream; their owners
+    // publish the row records, every workgroup replays their two updates in order
+    const int32_t* cf_ptr;  // [nb+1] conflict rows of a step
+    const void* cf;         // PrbConf<T>[]: row, slots of the two columns, their two x values
+    const int16_t* clist;   // [d][8] per column position: conflict index | role << 8, -1 none
+    double* slabR;          // [2][64][L] tagged granules: the conflict rows' packed records
     long long* stamps;     // [G][16] diagnostic phase timers or nullptr
     int dbg;               // diagnostic switches (bit 0: stage rows through registers, no LDS-DMA)
     unsigned* dbg_out;     // [16] diagnostic counters
@@ -344,6 +351,35 @@ __global__ void pbprb_unpack_kernel(int64_t n, const T* __restrict__ R, T* __res
 // us, but the kernel is bound by its instruction count and the table look-ups cost more in the
 // scatter and the prefetch than the round trip; a scatter that took four entries at a time with
 // one butterfly for their prediction decrements; round 3's dedicated owner workgroups.)
+// pbcd._update (pbcd.py:68-79) up to the cache-dependent part of prox_bcd, for the block of one
+// column: `tot` = the column's sums (lanes < k: sum dloss * dA per component, lane L-2: sum dA^2),
+// `pold` the block.  Returns p' in the component lanes; l2 = ||p'||, st0 = eta * gamma / inv.
+template <int L>
+__device__ __forceinline__ double pb_block_step(double tot, double pold, double lam, bool kl,
+                                                int grp, int reg, double mu, double beta,
+                                                double gamma, double eta, double& l2, double& st0) {
+    const double hsum = pb_bcast<L>(tot, L - 2, grp);
+    double inv = hsum * mu;
+    inv += beta;
+    st0 = eta * gamma / inv;
+    double v = 0.0;
+    if (kl) {
+        double gr = tot * lam;
+        gr += beta * pold;
+        gr /= inv;
+        v = pold - eta * gr;
+        if (reg == REG_L1) {  // l1.py:44-45, element-wise
+            const double sg = (v > 0) ? 1.0 : ((v < 0) ? -1.0 : 0.0);
+            const double m = fabs(v) - st0;
+            v = sg * (m > 0.0 ? m : 0.0);
+        } else if (reg == REG_SQL21) {
+            v /= 1 + 2 * st0;  // squaredl21.py:46
+        }
+    }
+    l2 = sqrt(pb_group_allsum<L>(v * v));
+    return v;
+}
+
 template <typename T>
 struct PbESet {  // lane u <-> entry e0 + u of the group (u < min(cnt, L))
     int e0, cnt;
@@ -351,7 +387,18 @@ struct PbESet {  // lane u <-> entry e0 + u of the group (u < min(cnt, L))
     T x;
 };
 
-template <typename T, int M, int L, bool STAMP = false>
+// CR = true: relaxed runs for pbcd, degree 2, k <= 30.  A step is a run of consecutive
+// columns of the reference's own order that may share rows (schedule_relax: a row in at most two
+// columns of the run, <= 64 such conflict rows).  The conflict rows are not in the entry stream:
+// their owner publishes the row's record, the slot owners publish the columns' TOTALS (without
+// those rows), and every workgroup redundantly replays the run: a column's sums = its totals +
+// its conflict rows' terms -- for a row's earlier column from the published record, for its
+// later column from the record after the earlier column's update (rounded to T as the scatter
+// would), which depends on that column's Delta, which depends (regularizer chain) on everything
+// in front of it.  Evaluated in rounds -- all terms from the current Deltas, all blocks' steps,
+// the chain from the step's input cache -- until no Delta changes a bit: column q depends on
+// columns < q only, so the fixed point is the sequential sweep's result (pbcd.py:110-146).
+template <typename T, int M, int L, bool STAMP = false, bool CR = false>
 __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     PbPrbArgs a, const T* __restrict__ eval, T* __restrict__ R /* packed row records */,
     double* __restrict__ P /* (d,k) */, int k, int d, const double* __restrict__ lams, int loss,
@@ -361,7 +408,10 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     constexpr int QM = 64 / NG;            // slots per group (<= 64 slots per step)
     constexpr int AS = Kind<M>::AS;
     constexpr int NW = kPbPrbThreads / 64;  // waves
-    constexpr int ER = pbprb_er<T, M>();
+    static_assert(!CR || (M == 2 && L == 32), "relaxed pbcd runs: degree 2, k <= 30");
+    // (relaxed runs hold ~35 entries per workgroup and step: 4 LDS row slots per group leave room
+    // for the replay's tables)
+    constexpr int ER = (CR && pbprb_er<T, M>() > 4) ? 4 : pbprb_er<T, M>();
     using ESet = PbESet<T>;
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
     double* sh_red = dyn_lds;                    // [2][NG][L] owner part sums
@@ -373,6 +423,18 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     int* sh_ok = reinterpret_cast<int*>(sh_rm + 2 * NG * L);
     // row buffers [2][NW][ER][AS][64]: a wave's slice is written lane-linearly by LDS-DMA
     T* sh_rows = reinterpret_cast<T*>(sh_ok + 4);
+    // CR: old blocks, Deltas, conflict terms (earlier / later column), conflict records [64][L];
+    // the saved regularizer state; per conflict (qa, qb, xa, xb); per column its conflict list
+    double* sh_po = reinterpret_cast<double*>(sh_rows + (size_t)2 * NW * ER * AS * 64);
+    double* sh_dl = sh_po + 64 * L;
+    double* sh_ta = sh_dl + 64 * L;
+    double* sh_tb = sh_ta + 64 * L;
+    double* sh_cr = sh_tb + 64 * L;
+    double* sh_csave = sh_cr + 64 * L;
+    double2* sh_cx = reinterpret_cast<double2*>(sh_csave + 2 * (kMaxDegree + 2));  // [64] (xa, xb)
+    int2* sh_cq = reinterpret_cast<int2*>(sh_cx + 64);                             // [64] (qa, qb)
+    short* sh_cl = reinterpret_cast<short*>(sh_cq + 64);                           // [64][8]
+    int* sh_chg = reinterpret_cast<int*>(sh_cl + 64 * 8);
     const int g = (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid % L, grp = tid / L;
     const int wlane = tid & 63, wave = tid >> 6;
@@ -626,6 +688,37 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             }
         }
         PB_STAMP(1)
+        int nconf = 0;
+        if constexpr (CR) {
+            // ---- relaxed runs: this step's conflict rows.  Tables -> LDS; the rows this workgroup
+            // owns -> slabR (their records as the previous step left them: its end barrier drained
+            // the scatter's stores).  Slots unused now but read at the buffer's next use are
+            // rewritten with zeros by workgroup 0 (stale-tag rule).
+            const PrbConf<T>* cfa = reinterpret_cast<const PrbConf<T>*>(a.cf);
+            const int cp0 = a.cf_ptr[b], cp1 = a.cf_ptr[b + 1];
+            const int cp2 = a.cf_ptr[min(b + 2, a.nb)], cp3 = a.cf_ptr[min(b + 3, a.nb)];
+            nconf = cp1 - cp0;
+            double* slabR = a.slabR + (size_t)par * 64 * L;
+            if (tid < nconf) {
+                const PrbConf<T> cf = cfa[cp0 + tid];
+                sh_cq[tid] = make_int2(cf.qq & 0xff, cf.qq >> 8);
+                sh_cx[tid] = make_double2((double)cf.xa, (double)cf.xb);
+            }
+            if (tid < ncols)
+                reinterpret_cast<uint4*>(sh_cl)[tid] =
+                    reinterpret_cast<const uint4*>(a.clist)[c0 + tid];
+            const int ncw = max(nconf, cp3 - cp2);
+            for (int c = grp; c < ncw; c += NG) {
+                if (c < nconf) {
+                    const int row = cfa[cp0 + c].row;
+                    if (row / a.rows_per == g)
+                        prb_store_granule(slabR + (size_t)c * L + lane,
+                                          (double)R[(size_t)row * rowlen + lane], tag);
+                } else if (g == 0) {
+                    prb_store_granule(slabR + (size_t)c * L + lane, 0.0, tag);
+                }
+            }
+        }
 
         // ---- phase 2: owners reduce their slot over the workgroups and take the step
         const int n_rounds = fixed_owner ? 1 : (nw + a.G - 1) / a.G;
@@ -714,27 +807,17 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                     const int j = a.jsched[c0 + q];
                     pold = kl ? P[(size_t)j * k + lane] : 0.0;
                 }
-                const double hsum = pb_bcast<L>(tot, L - 2, grp);  // grp == 0 here
-                double inv = hsum * mu;
-                inv += beta;
-                const double st0 = eta * gamma / inv;
-                double v = 0.0;
-                if (kl) {
-                    double gr = tot * lam;
-                    gr += beta * pold;
-                    gr /= inv;
-                    v = pold - eta * gr;
-                    if (reg == REG_L1) {  // l1.py:44-45, element-wise
-                        const double sg = (v > 0) ? 1.0 : ((v < 0) ? -1.0 : 0.0);
-                        const double m = fabs(v) - st0;
-                        v = sg * (m > 0.0 ? m : 0.0);
-                    } else if (reg == REG_SQL21) {
-                        v /= 1 + 2 * st0;  // squaredl21.py:46
-                    }
+                if constexpr (CR) {
+                    // relaxed runs: the columns' sums still lack their conflict rows -- the
+                    // totals go out as they are, every workgroup takes the steps itself
+                    prb_store_granule(slabB + (size_t)q * L + lane, tot, tag);
+                } else {
+                    double l2, st0;
+                    const double v = pb_block_step<L>(tot, pold, lam, kl, grp /* == 0 */, reg, mu,
+                                                      beta, gamma, eta, l2, st0);
+                    const double outv = (lane == L - 2) ? l2 : ((lane == L - 1) ? st0 : v);
+                    prb_store_granule(slabB + (size_t)q * L + lane, outv, tag);
                 }
-                const double l2 = sqrt(pb_group_allsum<L>(v * v));
-                const double outv = (lane == L - 2) ? l2 : ((lane == L - 1) ? st0 : v);
-                prb_store_granule(slabB + (size_t)q * L + lane, outv, tag);
             }
         }
         PB_STAMP(3)
@@ -793,9 +876,36 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 if (idx < total) {
                     const double v = __longlong_as_double((long long)(t[u] & ~3ull));
                     sh_pt[idx] = v;
-                    const int q = idx / L, l = idx % L;
-                    if (l == L - 2) sh_scal[4 * q + 0] = v;
-                    if (l == L - 1) sh_scal[4 * q + 1] = v;
+                    if constexpr (!CR) {
+                        const int q = idx / L, l = idx % L;
+                        if (l == L - 2) sh_scal[4 * q + 0] = v;
+                        if (l == L - 1) sh_scal[4 * q + 1] = v;
+                    }
+                }
+            }
+            if constexpr (CR) {  // ... and the conflict rows' records
+                const int total2 = nconf * L;
+                const double* slabR = a.slabR + (size_t)par * 64 * L;
+                spins = 0;
+                for (;;) {
+                    bool all = true;
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) {
+                        const int idx = tid + u * kPbPrbThreads;
+                        t[u] = (idx < total2) ? prb_load_granule(slabR + idx) : tag;
+                        all = all && ((t[u] & 3ull) == tag);
+                    }
+                    if (all) break;
+                    if (pbprb_poll_fail(a, spins)) {
+                        ok = false;
+                        break;
+                    }
+                }
+                if (!ok) *sh_ok = 0;
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int idx = tid + u * kPbPrbThreads;
+                    if (idx < total2) sh_cr[idx] = __longlong_as_double((long long)(t[u] & ~3ull));
                 }
             }
         }
@@ -808,25 +918,150 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         // the scalar cache recurrence in step order (every workgroup redundantly; every
         // workgroup also writes the new block norms -- one step late -- so that its own later
         // reads are consistent)
-        if (wave == 0) {
-            if (chained) {
-                // the previous step's new block norms go to memory now: every workgroup has
-                // finished that step's chain (it published this step's partial sums since), so
-                // none can still need the old values
-                if (cjp >= 0) rs.norms[cjp] = l2n_prev;
-                double l2n_new = 0.0;
-                pbprb_chain_step<M>(wlane, ncols, cj0, cn0, d, reg, rs, top_ncache, sh_scal,
-                                    sh_cache, &l2n_new);
-                cjp = cj0;
-                l2n_prev = l2n_new;
-            } else if (wlane < ncols) {
-                double f = 1.0;
-                if (reg == REG_L21) {  // l21.py:33-38
-                    const double l2 = sh_scal[4 * wlane], st0 = sh_scal[4 * wlane + 1];
-                    f = (l2 > st0) ? (1.0 - st0 / l2) : 0.0;
+        double l2n_step = 0.0;
+        const double* vfin = sh_pt;  // the blocks' p' of the step (CR: the last round's buffer)
+        // the previous step's new block norms go to memory now: every workgroup has finished
+        // that step's chain (it published this step's partial sums since), so none can still
+        // need the old values
+        if (wave == 0 && chained && cjp >= 0) rs.norms[cjp] = l2n_prev;
+        auto chain_phase = [&]() __attribute__((always_inline)) {
+            if (wave == 0) {
+                if (chained) {
+                    double l2n_new = 0.0;
+                    pbprb_chain_step<M>(wlane, ncols, cj0, cn0, d, reg, rs, top_ncache, sh_scal,
+                                        sh_cache, &l2n_new);
+                    l2n_step = l2n_new;
+                } else if (wlane < ncols) {
+                    double f = 1.0;
+                    if (reg == REG_L21) {  // l21.py:33-38
+                        const double l2 = sh_scal[4 * wlane], st0 = sh_scal[4 * wlane + 1];
+                        f = (l2 > st0) ? (1.0 - st0 / l2) : 0.0;
+                    }
+                    sh_scal[4 * wlane + 2] = f;
                 }
-                sh_scal[4 * wlane + 2] = f;
             }
+        };
+        if constexpr (!CR) {
+            chain_phase();
+        } else {
+            // ---- relaxed runs: replay the run (see the header).  My slots' old blocks -> LDS,
+            // Deltas start at zero, the regularizer state is saved for the rounds
+#pragma unroll
+            for (int t = 0; t < QM; ++t) {
+                const int q = slot_of(qs0, t);
+                if (q < ncols) {
+                    sh_po[q * L + lane] = po[t];
+                    sh_dl[q * L + lane] = 0.0;
+                }
+            }
+            if (wave == 0 && wlane < 2 * (kMaxDegree + 2)) sh_csave[wlane] = sh_cache[wlane];
+            if (tid == 0) *sh_chg = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // the earlier column's term of my conflict rows: from the published record
+            for (int c = grp; c < nconf; c += NG) {
+                const int2 cq = sh_cq[c];
+                const double2 cx = sh_cx[c];
+                const double av = kl ? sh_cr[c * L + lane] : 0.0;
+                const double pa = sh_po[cq.x * L + lane];
+                const double dAa = kl ? cx.x * (av - pa * cx.x) : 0.0;
+                const double dl0 = dloss_dev(loss, sh_cr[c * L + L - 2], sh_cr[c * L + L - 1]);
+                const double hs = pb_group_allsum<L>(dAa * dAa);
+                sh_ta[c * L + lane] = (lane == L - 2) ? hs : dl0 * dAa;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            double base[QM];
+#pragma unroll
+            for (int t = 0; t < QM; ++t) {
+                const int q = slot_of(qs0, t);
+                double b0 = 0.0;
+                if (q < ncols) {
+                    b0 = sh_pt[q * L + lane];
+                    for (int e = 0; e < 8; ++e) {
+                        const int ce = sh_cl[q * 8 + e];
+                        if (ce >= 0 && (ce >> 8) == 0) b0 += sh_ta[(ce & 0xff) * L + lane];
+                    }
+                }
+                base[t] = b0;
+            }
+            // Rounds.  Delta of a column = its old block - p' * f: the terms read (p', f) of the
+            // previous round straight from LDS (first round: Delta = 0; p' double-buffered by
+            // round parity), so a round is [terms + steps] barrier [chain] barrier, and it was
+            // the last one when no p' and no f changed a bit (then no Delta did).
+            double* vbuf[2] = {sh_pt, sh_tb};
+            for (int round = 0;; ++round) {
+                const double* vprev = vbuf[(round + 1) & 1];
+                double* vcur = vbuf[round & 1];
+                bool changed = false;
+#pragma unroll
+                for (int t = 0; t < QM; ++t) {
+                    const int q = slot_of(qs0, t);
+                    if (q < ncols) {  // (group-uniform)
+                        // my column's sums = totals + conflict terms; the later column's term of
+                        // a conflict row = the record after the earlier column's update for its
+                        // current Delta (pbcd.py:135-144), rounded to T as the scatter rounds
+                        double tot = base[t];
+                        for (int e = 0; e < 8; ++e) {
+                            const int ce = sh_cl[q * 8 + e];
+                            if (ce < 0 || (ce >> 8) == 0) continue;
+                            const int c = ce & 0xff;
+                            const int2 cq = sh_cq[c];
+                            const double2 cx = sh_cx[c];
+                            const double av = kl ? sh_cr[c * L + lane] : 0.0;
+                            const double pa = sh_po[cq.x * L + lane];
+                            const double Da = (round == 0 || !kl)
+                                                  ? 0.0
+                                                  : pa - vprev[cq.x * L + lane] * sh_scal[4 * cq.x + 2];
+                            const double dAa = kl ? cx.x * (av - pa * cx.x) : 0.0;
+                            const double a1 = kl ? (double)(T)(av - Da * cx.x) : 0.0;
+                            const double dec = pb_group_allsum<L>(kl ? (lam * Da) * dAa : 0.0);
+                            const double y1 = (double)(T)(sh_cr[c * L + L - 2] - dec);
+                            const double dAb = kl ? cx.y * (a1 - po[t] * cx.y) : 0.0;
+                            const double dl1 = dloss_dev(loss, y1, sh_cr[c * L + L - 1]);
+                            const double hs = pb_group_allsum<L>(dAb * dAb);
+                            tot += (lane == L - 2) ? hs : dl1 * dAb;
+                        }
+                        double l2, st0;
+                        const double v = pb_block_step<L>(tot, po[t], lam, kl, grp, reg, mu, beta,
+                                                          gamma, eta, l2, st0);
+                        changed = changed || round == 0 ||
+                                  __double_as_longlong(v) != __double_as_longlong(vprev[q * L + lane]);
+                        vcur[q * L + lane] = v;
+                        if (lane == 0) {
+                            sh_scal[4 * q + 3] = sh_scal[4 * q + 2];  // f of the previous round
+                            sh_scal[4 * q + 0] = l2;
+                            sh_scal[4 * q + 1] = st0;
+                        }
+                    }
+                }
+                if (__ballot(changed) != 0ull && wlane == 0) *sh_chg = round + 1;
+                if (wave == 0 && wlane < 2 * (kMaxDegree + 2)) sh_cache[wlane] = sh_csave[wlane];
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                chain_phase();
+                if (wave == 0 && wlane < ncols && round > 0 &&
+                    __double_as_longlong(sh_scal[4 * wlane + 2]) !=
+                        __double_as_longlong(sh_scal[4 * wlane + 3]))
+                    *sh_chg = round + 1;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (*sh_chg != round + 1 || round > ncols + 1) {
+                    if (tid == 0 && g == a.G - 1) {
+                        atomicAdd(&g_branch_count[BR_RELAX_STEPS], 1u);
+                        atomicAdd(&g_branch_count[BR_RELAX_ROUNDS], (unsigned)(round + 1));
+                    }
+                    vfin = vcur;
+                    break;
+                }
+            }
+            // the columns' Deltas for the conflict rows' final records
+#pragma unroll
+            for (int t = 0; t < QM; ++t) {
+                const int q = slot_of(qs0, t);
+                if (q < ncols)
+                    sh_dl[q * L + lane] = kl ? po[t] - vfin[q * L + lane] * sh_scal[4 * q + 2] : 0.0;
+            }
+        }
+        if (wave == 0 && chained) {
+            cjp = cj0;
+            l2n_prev = l2n_step;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // factors in LDS
         PB_STAMP(6)
@@ -841,7 +1076,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 const int q = min(qq, 63);
                 const bool vq = qq < ncols;
                 const double f = sh_scal[4 * q + 2];
-                const double pt = sh_pt[q * L + lane];
+                const double pt = vfin[q * L + lane];
                 pn[t] = (vq && kl) ? pt * f : 0.0;
                 up[t] = (vq && kl) ? po[t] - pn[t] : 0.0;
                 lu[t] = lam * up[t];
@@ -947,6 +1182,32 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 if (lane == 0) ri[L - 2] = (T)(y0 - accv);
             }
         }
+        if constexpr (CR) {
+            // the conflict rows' final records, by their owner: both updates in order
+            // (pbcd.py:135-144 twice), each rounded to T as the scatter rounds
+            const PrbConf<T>* cfa = reinterpret_cast<const PrbConf<T>*>(a.cf);
+            const int cp0 = a.cf_ptr[b];
+            for (int c = grp; c < nconf; c += NG) {
+                const int row = cfa[cp0 + c].row;
+                if (row / a.rows_per != g) continue;
+                const int2 cq = sh_cq[c];
+                const double2 cx = sh_cx[c];
+                const double av = kl ? sh_cr[c * L + lane] : 0.0;
+                const double pa = sh_po[cq.x * L + lane], pbv = sh_po[cq.y * L + lane];
+                const double Da = sh_dl[cq.x * L + lane], Db = sh_dl[cq.y * L + lane];
+                const double dAa = kl ? cx.x * (av - pa * cx.x) : 0.0;
+                const double a1 = kl ? (double)(T)(av - Da * cx.x) : 0.0;
+                const double dec_a = pb_group_allsum<L>(kl ? (lam * Da) * dAa : 0.0);
+                const double y1 = (double)(T)(sh_cr[c * L + L - 2] - dec_a);
+                const double dAb = kl ? cx.y * (a1 - pbv * cx.y) : 0.0;
+                const double a2 = kl ? a1 - Db * cx.y : 0.0;
+                const double dec_b = pb_group_allsum<L>(kl ? (lam * Db) * dAb : 0.0);
+                double outv = a2;
+                if (lane == L - 2) outv = y1 - dec_b;
+                if (lane == L - 1) outv = sh_cr[c * L + L - 1];
+                R[(size_t)row * rowlen + lane] = (T)outv;
+            }
+        }
         PB_STAMP(7)
         // ---- rotate the pipeline
         cur = nxt;
@@ -989,12 +1250,14 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
 }
 
 // dynamic LDS the kernel needs (bytes)
-template <typename T, int M, int L>
+template <typename T, int M, int L, bool CR = false>
 constexpr size_t pbcd_prb_lds_bytes() {
     constexpr int NG = kPbPrbThreads / L;
     constexpr int AS = Kind<M>::AS;
-    constexpr int ER = pbprb_er<T, M>();
-    return sizeof(double) * (2 * NG * L + 64 * L + 256 + 2 * NG * L + 2 * (kMaxDegree + 2)) +
+    constexpr int ER = (CR && pbprb_er<T, M>() > 4) ? 4 : pbprb_er<T, M>();
+    return (CR ? sizeof(double) * (5 * 64 * L + 2 * (kMaxDegree + 2) + 2 * 64) + sizeof(int) * (2 * 64 + 4) +
+                     sizeof(short) * 64 * 8 : 0) +
+           sizeof(double) * (2 * NG * L + 64 * L + 256 + 2 * NG * L + 2 * (kMaxDegree + 2)) +
            sizeof(int) * (4 * NG * L + 4) +
            sizeof(T) * (size_t)2 * (kPbPrbThreads / 64) * ER * AS * 64;
 }

@@ -622,9 +622,11 @@ void build_rowblock_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
 // group) -- 6.5 entries in the busiest group.  tab[(g*nb + b)*64 + grp*QM + t] = the step's slot
 // (column index inside the step) that group grp handles as its t-th, 0xFF = none; every slot
 // below `max(ncols(b), ncols(b+2))` is assigned (the kernel rewrites the unused ones with zeros).
+// `skip` (relaxed runs, schedule_relax): entries that are not part of the stream -- their rows
+// still count as touched by their step.
 void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
                      const std::vector<int32_t>& order, const std::vector<int32_t>& batch_ptr,
-                     int G, int NG, bool balance, std::vector<int32_t>& gsp,
+                     int G, int NG, bool balance, const uint8_t* skip, std::vector<int32_t>& gsp,
                      std::vector<int32_t>& src, std::vector<uint8_t>& meta,
                      std::vector<uint8_t>& tab) {
     const int nb = (int)batch_ptr.size() - 1;
@@ -660,7 +662,7 @@ void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
                 int64_t lo, hi;
                 sub_range(order[(size_t)batch_ptr[b] + q], rlo, rhi, lo, hi);
                 for (int64_t ii = lo; ii < hi; ++ii)
-                    cnt[(size_t)(cidx[ii] / rows_per - g0) * 64 + (size_t)q]++;
+                    if (!skip || !skip[ii]) cnt[(size_t)(cidx[ii] / rows_per - g0) * 64 + (size_t)q]++;
             }
             for (int g = g0; g < g1; ++g) {
                 const int32_t* c = &cnt[(size_t)(g - g0) * 64];
@@ -713,7 +715,8 @@ void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
             for (int q = 0; q < nc; ++q) {
                 sub_range(order[(size_t)batch_ptr[b] + q], rlo, rhi, lo_q[(size_t)q], hi_q[(size_t)q]);
                 for (int64_t ii = lo_q[(size_t)q]; ii < hi_q[(size_t)q]; ++ii)
-                    pos[(size_t)(cidx[ii] / rows_per - g0) * 64 + (size_t)q]++;  // counts first
+                    if (!skip || !skip[ii])
+                        pos[(size_t)(cidx[ii] / rows_per - g0) * 64 + (size_t)q]++;  // counts first
             }
             for (int g = g0; g < g1; ++g) {
                 int32_t* pc = &pos[(size_t)(g - g0) * 64];
@@ -735,6 +738,10 @@ void build_pb_stream(int64_t n, const int64_t* cptr, const int32_t* cidx,
             for (int q = 0; q < nc; ++q)
                 for (int64_t ii = lo_q[(size_t)q]; ii < hi_q[(size_t)q]; ++ii) {
                     const int64_t i = cidx[ii];
+                    if (skip && skip[ii]) {  // on a conflict row of a relaxed run: not in the
+                        last[(size_t)i] = b;  // stream, but the step does touch the row
+                        continue;
+                    }
                     const size_t gi = (size_t)(i / rows_per);
                     const size_t lq = (gi - (size_t)g0) * 64 + (size_t)q;
                     const size_t e = (size_t)pos[lq]++;

@@ -200,3 +200,104 @@ def test_relaxed_runs_degree3_explicit_lower_order(oracle, loss, precision, opti
         np.testing.assert_allclose(viol, ref, rtol=5e-5)
         np.testing.assert_allclose(P, fm.P_, rtol=0, atol=2e-4)
         np.testing.assert_allclose(w, fm.w_, rtol=0, atol=2e-4)
+
+
+# ---- round 4: relaxed runs for pbcd (pbcd_prb_kernel CR; degree 2, k <= 30, one GPU)
+def _run_pbcd(X, y, loss, reg, precision, options, order, k=5, epochs=2, gamma=1e-3):
+    from sparsepoly_amd.engine import HipEngine
+
+    d = X.shape[1]
+    eng = HipEngine(0, precision)
+    for key, val in options.items():
+        eng.set_option(key, val)
+    eng.set_data(X, y)
+    P0 = 0.05 * np.random.RandomState(1).randn(1, k, d)
+    lams = np.where(np.arange(k) % 2 == 0, 1.0, -1.0)
+    eng.set_params(P0, np.zeros(d), lams)
+    eng.configure("pbcd", loss, reg, 2)
+    eng.init_pred(2, True, False)
+    got = eng.set_schedule("exact", order)
+    np.testing.assert_array_equal(got, order)
+    viol = [eng.cd_linear_epoch(0.5) + eng.pbcd_epoch(0, 2, 1.0, gamma, 1.0) for _ in range(epochs)]
+    P, w = eng.get_params()
+    out = dict(viol=np.array(viol), P=P, w=w, y_pred=eng.get_y_pred(), strict=eng.n_batches,
+               relaxed=eng.get_option("relax_steps"), active=eng.get_option("pb_relax_active"),
+               pbprb=eng.get_option("pbprb_active"),
+               fallbacks=eng.get_option("persistent_fallbacks"), P0=P0, lams=lams)
+    eng.close()
+    return out
+
+
+def _oracle_pbcd(oracle, X, y, loss, reg, order, r, k=5, epochs=2, gamma=1e-3):
+    fm = oracle.OracleFM(degree=2, loss=loss, n_components=k, solver="pbcd", regularizer=reg,
+                         alpha=0.5, beta=1.0, gamma=gamma, tol=0, max_iter=epochs, fit_linear=True,
+                         feature_order=order)
+    fm.fit(X, y, P_init=r["P0"], lams_init=r["lams"])
+    return fm
+
+
+@pytest.mark.parametrize("precision,options", [("f64", {}), ("f32", {}),
+                                               ("f64", {"pbprb_groups": 5}),
+                                               ("f32", {"pbprb_groups": 64}),
+                                               ("f32", {"pbprb_groups": 256})])
+@pytest.mark.parametrize("loss,reg", [("squared", "omegacs"), ("logistic", "squaredl21"),
+                                      ("squared_hinge", "l21"), ("squared", "l1")])
+def test_relaxed_pbcd_runs_equal_the_sequential_sweep(oracle, loss, reg, precision, options):
+    """pbcd in the reference's own order (pbcd.py:99,110-146 with indices_feature = arange):
+    merged steps whose conflict rows every workgroup replays, against the oracle in that order."""
+    X, y = _problem(loss)
+    order = np.arange(X.shape[1], dtype=np.int32)
+    r = _run_pbcd(X, y, loss, reg, precision, options, order)
+    assert r["fallbacks"] == 0 and r["pbprb"] == 1 and r["active"] == 1
+    assert r["strict"] > 500 and 0 < r["relaxed"] < 0.4 * r["strict"], (r["strict"], r["relaxed"])
+    fm = _oracle_pbcd(oracle, X, y, loss, reg, order, r)
+    ref = [h[0] for h in fm.history]
+    assert 0.05 < (fm.P_ != 0).mean()
+    if precision == "f64":
+        np.testing.assert_allclose(r["viol"], ref, rtol=1e-9)
+        np.testing.assert_allclose(r["P"], fm.P_, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(r["w"], fm.w_, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(r["y_pred"], fm.y_pred_, rtol=0, atol=1e-8)
+    else:
+        np.testing.assert_allclose(r["viol"], ref, rtol=2e-5)
+        np.testing.assert_allclose(r["P"], fm.P_, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(r["w"], fm.w_, rtol=0, atol=1e-4)
+
+
+def test_relaxed_pbcd_runs_equal_the_strict_engine_and_can_be_switched_off():
+    X, y = _problem("squared")
+    order = np.arange(X.shape[1], dtype=np.int32)
+    a = _run_pbcd(X, y, "squared", "omegacs", "f64", {}, order, k=30)
+    b = _run_pbcd(X, y, "squared", "omegacs", "f64", {"relax": 0}, order, k=30)
+    assert a["relaxed"] > 0 and a["active"] == 1 and b["relaxed"] == 0 and b["active"] == 0
+    assert a["strict"] == b["strict"]
+    np.testing.assert_allclose(a["viol"], b["viol"], rtol=1e-11)
+    np.testing.assert_allclose(a["P"], b["P"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(a["y_pred"], b["y_pred"], rtol=0, atol=1e-10)
+    a = _run_pbcd(X, y, "squared", "omegacs", "f32", {}, order, k=30)
+    b = _run_pbcd(X, y, "squared", "omegacs", "f32", {"relax": 0}, order, k=30)
+    np.testing.assert_allclose(a["viol"], b["viol"], rtol=1e-6)
+    np.testing.assert_allclose(a["P"], b["P"], rtol=0, atol=2e-6)
+    # more than 30 components / degree 3: strict steps (the relaxed pass is built for the
+    # 32-lane groups and one cache value per row)
+    c = _run_pbcd(X, y, "squared", "omegacs", "f64", {}, order, k=33)
+    assert c["active"] == 0 and c["pbprb"] == 1
+
+
+def test_relaxed_pbcd_shuffled_order_and_frequent_features(oracle):
+    rng = np.random.RandomState(7)
+    X, y = _problem("squared", n=6000, d=900, per_row=9, seed=5)
+    X = sp.lil_matrix(X)
+    for j, dens in ((3, 0.5), (400, 0.2)):  # very frequent features
+        rows = np.flatnonzero(rng.rand(X.shape[0]) < dens)
+        X[rows, j] = rng.randn(rows.size)
+    X[:, 17] = 0  # an empty column
+    X = sp.csr_matrix(X)
+    X.eliminate_zeros()
+    order = rng.permutation(X.shape[1]).astype(np.int32)
+    r = _run_pbcd(X, y, "squared", "omegacs", "f64", {}, order)
+    assert r["fallbacks"] == 0
+    fm = _oracle_pbcd(oracle, X, y, "squared", "omegacs", order, r)
+    np.testing.assert_allclose(r["viol"], [h[0] for h in fm.history], rtol=1e-9)
+    np.testing.assert_allclose(r["P"], fm.P_, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(r["y_pred"], fm.y_pred_, rtol=0, atol=1e-8)

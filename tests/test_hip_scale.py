@@ -225,6 +225,44 @@ def test_fullsize_reference_order_merged_steps_vs_oracle(oracle, config2_matrix)
     np.testing.assert_allclose(a["yp"], ypo, rtol=0, atol=2e-4 * max(1.0, np.abs(ypo).max()))
 
 
+def test_fullsize_reference_order_pbcd_merged_steps_vs_oracle(oracle, config2_matrix):
+    """BASELINE configs[3] at full size in the REFERENCE's own column order (schedule='exact',
+    what SparseFactorizationMachineRegressor(solver='pbcd').fit() does by default:
+    sparse_factorization_machines.py:287-337, pbcd.py:99,110-146): the persistent pbcd pass runs
+    it as merged steps whose conflict rows every workgroup replays (38 284 strict steps -> ~5 500).
+    One cd_linear epoch + the whole pbcd epoch against the oracle in natural order, f32 storage."""
+    Xc, y = config2_matrix
+    n, d = Xc.shape
+    k = 30
+    eng, order, P0 = _engine(Xc, y, k, 2, "pbcd", "omegacs", "f32", "exact")
+    np.testing.assert_array_equal(order, np.arange(d))
+    y0 = eng.get_y_pred()
+    v_lin = eng.cd_linear_epoch(1.0)
+    v = eng.pbcd_epoch(0, 2, 1.0, 1e-3, 1.0)
+    assert eng.get_option("pb_relax_active") == 1 and eng.get_option("persistent_fallbacks") == 0
+    assert eng.n_batches > 30_000 and 3_000 < eng.get_option("relax_steps") < 0.25 * eng.n_batches
+    P, w = eng.get_params()
+    yp = eng.get_y_pred()
+    eng.close()
+    ds = oracle.CSC(Xc)
+    regc = oracle.Regularizer("omegacs")
+    wo = np.zeros(d)
+    ypo = np.ascontiguousarray(y0.copy())
+    cn = np.asarray(Xc.multiply(Xc).sum(axis=0)).ravel()
+    jf = np.arange(d, dtype=np.int32)
+    vo_lin = oracle.cd_linear_epoch(wo, ds, y, ypo, cn, 1.0, "squared", jf)
+    regc.init_cache_pbcd(2, d, k)
+    Pt = np.ascontiguousarray(P0[0].T.copy())
+    A = np.zeros((n, 3, k))
+    dA = np.zeros((n, 2, k))
+    vo = oracle.pbcd_epoch(Pt, ds, y, ypo, np.ones(k), 2, 1.0, 1e-3, 1.0, regc, "squared", A, dA, jf)
+    np.testing.assert_allclose(v_lin, vo_lin, rtol=1e-5)
+    np.testing.assert_allclose(v, vo, rtol=1e-5)
+    np.testing.assert_allclose(w, wo, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(P[0], Pt.T, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(yp, ypo, rtol=0, atol=2e-4 * max(1.0, np.abs(ypo).max()))
+
+
 @pytest.mark.parametrize("schedule", ["colored", "exact"])
 def test_fullsize_config3_vs_oracle(oracle, config2_matrix, schedule):
     """BASELINE configs[2] at full size (1M x 100k, degree 3, k = 16, omegati, pcd, the default

@@ -28,11 +28,18 @@ for G in [int(v) for v in (sys.argv[1:] or ["256", "128", "64", "32"])]:
     eng.init_pred(2, True, False)
     eng.set_schedule("exact", np.arange(d, dtype=np.int32))
     v = [eng.pbcd_epoch(0, 2, 1.0, 1e-3, 1.0)]
+    eng.debug_branch_counts(reset=True)
     t0 = time.perf_counter()
     for _ in range(2):
         v.append(eng.pbcd_epoch(0, 2, 1.0, 1e-3, 1.0))
     dt = (time.perf_counter() - t0) / 2
+    bc = eng.debug_branch_counts()
+    merged = eng.get_option("relax_steps")
     print(json.dumps(dict(G=G, ms_per_pbcd_epoch=round(dt * 1e3, 2), steps=eng.n_batches,
+                          merged_steps=merged, relaxed=eng.get_option("pb_relax_active"),
+                          us_per_merged_step=round(dt * 1e6 / merged, 3) if merged else None,
+                          steps_counted=bc["relax_steps"],
+                          rounds_per_such_step=round(bc["relax_rounds"] / max(bc["relax_steps"], 1), 2),
                           us_per_step=round(dt * 1e6 / eng.n_batches, 3),
                           active=eng.get_option("pbprb_active"),
                           viol=[round(float(x), 3) for x in v])), flush=True)

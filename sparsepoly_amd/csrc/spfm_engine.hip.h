@@ -603,6 +603,7 @@ struct spfm_engine {
         pers_failed = true;
         pers_fallbacks += 1;
         pers_reason = std::string(what) + ": its workgroups cannot all be resident on this device";
+        if (getenv("SPFM_VERBOSE")) fprintf(stderr, "spfm: fall-back: %s\n", pers_reason.c_str());
     }
 
     int cd_linear_epoch(double alpha, double* viol);

@@ -1009,6 +1009,7 @@ int spfm_engine::recover_from_abort(double* params, size_t count, const DevBuf& 
     pers_reason = std::string(what) +
                   " timed out waiting for its workgroups (not all resident, or a peer GPU "
                   "did not answer)";
+    if (getenv("SPFM_VERBOSE")) fprintf(stderr, "spfm: fall-back: %s\n", pers_reason.c_str());
     if (!have_pred_args)
         FAIL(SPFM_ERR_RUNTIME, pers_reason + "; the model is half-updated (no spfm_init_pred "
                                              "call to recompute y_pred from)");
@@ -1739,8 +1740,8 @@ int spfm_debug_prb_stamps(spfm_handle h, long long* out, int cap) {
             return SPFM_ERR_RUNTIME;
         return nv;
     }
-    if (h->pb_stamp_on && h->pb_stream_ready && out) {  // persistent pbcd pass's timers
-        const int nv = 16 * h->pb_stream_G;
+    if (h->pb_stamp_on && (h->pb_stream_ready || h->pbr_state == 1) && out) {  // persistent pbcd pass's timers
+        const int nv = 16 * (h->pbr_state == 1 ? h->pbr_G : h->pb_stream_G);
         if (cap < nv) return SPFM_ERR_INVALID;
         if (hipMemcpy(out, h->pb_stamps.p, sizeof(long long) * (size_t)nv,
                       hipMemcpyDeviceToHost) != hipSuccess)

@@ -201,7 +201,7 @@ int spfm_engine::pbcd_prb_l(int order_idx, double beta, double gamma, double eta
     int rc = SPFM_OK;
     constexpr bool can_cr = M == 2 && L == 32;
     if constexpr (can_cr) {
-        if (relax_on && !dist() && !pb_stamp_on && n_batches() > 0 &&
+        if (relax_on && !dist() && n_batches() > 0 &&
             (double)d / (double)n_batches() < 12.0) {
             rc = ensure_pb_relax<T>(kPbPrbThreads / L);
             if (rc) return rc;
@@ -306,17 +306,27 @@ int spfm_engine::pbcd_prb_l(int order_idx, double beta, double gamma, double eta
     bool fired = false;
     if constexpr (can_cr) {
         if (relaxed) {
-            auto* fn = pbcd_prb_kernel<T, M, L, false, true>;
-            const size_t lds = std::max(kPrbLds, pbcd_prb_lds_bytes<T, M, L, true>());
-            HIPC(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-            if (!resident_ok((const void*)fn, kPbPrbThreads, lds, G)) {
-                rc = kNotResident;
-            } else {
+            auto fire_cr = [&](auto* fn) -> int {
+                const size_t lds = std::max(kPrbLds, pbcd_prb_lds_bytes<T, M, L, true>());
+                HIPC(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+                if (!resident_ok((const void*)fn, kPbPrbThreads, lds, G)) return kNotResident;
                 hipLaunchKernelGGL(fn, dim3(launch_groups(G)), dim3(kPbPrbThreads), lds, stream, a,
                                    pbr_eval.as<T>(), pb_rec.as<T>(), Po, k, d, lams.as<double>(), loss,
                                    reg, rs, ncache, mu, beta, gamma, eta, prb_viol.as<double>());
+                return SPFM_OK;
+            };
+            bool stamped = false;
+            if constexpr (can_stamp) {
+                if (pb_stamp_on) {
+                    HIPC(pb_stamps.alloc(sizeof(long long) * 16 * (size_t)G));
+                    HIPC(hipMemsetAsync(pb_stamps.p, 0, pb_stamps.bytes, stream));
+                    a.stamps = pb_stamps.as<long long>();
+                    rc = fire_cr(&pbcd_prb_kernel<T, M, L, true, true>);
+                    stamped = true;
+                }
             }
+            if (!stamped) rc = fire_cr(&pbcd_prb_kernel<T, M, L, false, true>);
             fired = true;
         }
     }

@@ -111,10 +111,18 @@ constexpr int pbprb_er() {
     return ER0 >= 8 ? (ER0 / 8) * 8 : (ER0 >= 4 ? 4 : (ER0 >= 2 ? 2 : 1));
 }
 
-__device__ __forceinline__ bool pbprb_poll_fail(const PbPrbArgs& a, unsigned& spins) {
+// `site` / `step`: which wait gave up first, and where in the sweep (diagnostic: option
+// "pbprb_dbg" bit 3 zeroes the counters, spfm_debug_prb_stamps returns them)
+__device__ __forceinline__ bool pbprb_poll_fail(const PbPrbArgs& a, unsigned& spins, int site = 0,
+                                                int step = 0) {
     if ((++spins & 63u) == 0) {
         if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
             spins > a.spin_max) {
+            if ((a.dbg & 8) && spins > a.spin_max) {
+                atomicAdd(&a.dbg_out[4 + site], 1u);
+                atomicMin(&a.dbg_out[3], (unsigned)step);
+                atomicMax(&a.dbg_out[8 + site], (unsigned)blockIdx.x + 1u);
+            }
             __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return true;
         }
@@ -434,7 +442,8 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     double2* sh_cx = reinterpret_cast<double2*>(sh_csave + 2 * (kMaxDegree + 2));  // [64] (xa, xb)
     int2* sh_cq = reinterpret_cast<int2*>(sh_cx + 64);                             // [64] (qa, qb)
     short* sh_cl = reinterpret_cast<short*>(sh_cq + 64);                           // [64][8]
-    int* sh_chg = reinterpret_cast<int*>(sh_cl + 64 * 8);
+    int* sh_crow = reinterpret_cast<int*>(sh_cl + 64 * 8);                         // [64] row ids
+    int* sh_chg = sh_crow + 64;
     const int g = (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid % L, grp = tid / L;
     const int wlane = tid & 63, wave = tid >> 6;
@@ -592,6 +601,14 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
     double cn0 = (cj0 >= 0 && chained) ? rs.norms[cj0] : 0.0, cn1 = 0.0;
     int cjp = -1;           // chain: column of the previous step held by this lane ...
     double l2n_prev = 0.0;  // ... and its new block norm, stored one step late
+    // CR: conflict-row boundaries of steps b .. b+3 and the tables of step 0
+    int cfp0 = 0, cfp1 = 0, cfp2 = 0, cfp3 = 0;
+    if constexpr (CR) {
+        cfp0 = a.cf_ptr[0];
+        cfp1 = a.cf_ptr[min(1, a.nb)];
+        cfp2 = a.cf_ptr[min(2, a.nb)];
+        cfp3 = a.cf_ptr[min(3, a.nb)];
+    }
     __syncthreads();
 
     for (int b = 0; b < a.nb; ++b) {
@@ -606,6 +623,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         double* slabB = a.slabB + (size_t)par * 64 * L;
         const int2* srm = sh_rm + par * NG * L + gb;  // (row, meta) of the group's entries
         const int nfast = min(cur.cnt, ER);
+        const int nconf = CR ? cfp1 - cfp0 : 0;  // this step's conflict rows
 
         // ---- phase 0: rows this step shares with the previous one (after its barrier)
         fetch_rows(cur, par, 1);
@@ -688,29 +706,25 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
             }
         }
         PB_STAMP(1)
-        int nconf = 0;
         if constexpr (CR) {
-            // ---- relaxed runs: this step's conflict rows.  Tables -> LDS; the rows this workgroup
-            // owns -> slabR (their records as the previous step left them: its end barrier drained
-            // the scatter's stores).  Slots unused now but read at the buffer's next use are
-            // rewritten with zeros by workgroup 0 (stale-tag rule).
+            // ---- relaxed runs: this step's conflict rows.  Tables -> LDS; the records of the
+            // rows this workgroup owns -> slabR (as the previous step left them: its end barrier
+            // drained the scatter's stores).  Slots unused now but read at the buffer's next use
+            // are rewritten with zeros by workgroup 0 (stale-tag rule).
             const PrbConf<T>* cfa = reinterpret_cast<const PrbConf<T>*>(a.cf);
-            const int cp0 = a.cf_ptr[b], cp1 = a.cf_ptr[b + 1];
-            const int cp2 = a.cf_ptr[min(b + 2, a.nb)], cp3 = a.cf_ptr[min(b + 3, a.nb)];
-            nconf = cp1 - cp0;
             double* slabR = a.slabR + (size_t)par * 64 * L;
             if (tid < nconf) {
-                const PrbConf<T> cf = cfa[cp0 + tid];
+                const PrbConf<T> cf = cfa[cfp0 + tid];
                 sh_cq[tid] = make_int2(cf.qq & 0xff, cf.qq >> 8);
                 sh_cx[tid] = make_double2((double)cf.xa, (double)cf.xb);
+                sh_crow[tid] = cf.row;
             }
             if (tid < ncols)
-                reinterpret_cast<uint4*>(sh_cl)[tid] =
-                    reinterpret_cast<const uint4*>(a.clist)[c0 + tid];
-            const int ncw = max(nconf, cp3 - cp2);
+                reinterpret_cast<uint4*>(sh_cl)[tid] = reinterpret_cast<const uint4*>(a.clist)[c0 + tid];
+            const int ncw = max(nconf, cfp3 - cfp2);
             for (int c = grp; c < ncw; c += NG) {
                 if (c < nconf) {
-                    const int row = cfa[cp0 + c].row;
+                    const int row = cfa[cfp0 + c].row;
                     if (row / a.rows_per == g)
                         prb_store_granule(slabR + (size_t)c * L + lane,
                                           (double)R[(size_t)row * rowlen + lane], tag);
@@ -745,7 +759,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                             all = all && ((t[u] & 3ull) == tag);
                         }
                         if (all) break;
-                        if (pbprb_poll_fail(a, spins)) {
+                        if (pbprb_poll_fail(a, spins, 1, b)) {
                             ok = false;
                             break;
                         }
@@ -791,7 +805,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                         for (;;) {
                             t = prb_load_granule_sys(mine + off + (size_t)rr * L + lane);
                             if ((t & 3ull) == tag) break;
-                            if (pbprb_poll_fail(a, spins)) {
+                            if (pbprb_poll_fail(a, spins, 2, b)) {
                                 ok = false;
                                 break;
                             }
@@ -847,6 +861,8 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         opon = (oj1 >= 0 && grp == 0 && kl) ? P[(size_t)oj1 * k + lane] : 0.0;
         const int cj2 = (wave == 0) ? col_id(c2, c3 - c2, wlane) : -1;
         cn1 = (cj1 >= 0 && chained) ? rs.norms[cj1] : 0.0;
+        int cfp4 = 0;
+        if constexpr (CR) cfp4 = a.cf_ptr[min(b + 4, a.nb)];
         PB_STAMP(4)
         // ---- phase 3: every workgroup collects the published vectors of all slots
         {
@@ -864,7 +880,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                     all = all && ((t[u] & 3ull) == tag);
                 }
                 if (all) break;
-                if (pbprb_poll_fail(a, spins)) {
+                if (pbprb_poll_fail(a, spins, 3, b)) {
                     ok = false;
                     break;
                 }
@@ -896,7 +912,7 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                         all = all && ((t[u] & 3ull) == tag);
                     }
                     if (all) break;
-                    if (pbprb_poll_fail(a, spins)) {
+                    if (pbprb_poll_fail(a, spins, 4, b)) {
                         ok = false;
                         break;
                     }
@@ -969,63 +985,63 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                 sh_ta[c * L + lane] = (lane == L - 2) ? hs : dl0 * dAa;
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            double base[QM];
+            // my columns' sums without the later-column terms: totals + earlier-column terms.
+            // Parked in LDS for the rounds (sh_dl: free until the rounds are over)
 #pragma unroll
             for (int t = 0; t < QM; ++t) {
                 const int q = slot_of(qs0, t);
-                double b0 = 0.0;
                 if (q < ncols) {
-                    b0 = sh_pt[q * L + lane];
+                    double b0 = sh_pt[q * L + lane];
                     for (int e = 0; e < 8; ++e) {
                         const int ce = sh_cl[q * 8 + e];
                         if (ce >= 0 && (ce >> 8) == 0) b0 += sh_ta[(ce & 0xff) * L + lane];
                     }
+                    sh_dl[q * L + lane] = b0;
                 }
-                base[t] = b0;
             }
-            // Rounds.  Delta of a column = its old block - p' * f: the terms read (p', f) of the
-            // previous round straight from LDS (first round: Delta = 0; p' double-buffered by
-            // round parity), so a round is [terms + steps] barrier [chain] barrier, and it was
-            // the last one when no p' and no f changed a bit (then no Delta did).
-            double* vbuf[2] = {sh_pt, sh_tb};
+            PB_STAMP(10)
+            // Rounds.  Delta of a column = its old block - p' * f, read straight from LDS (first
+            // round: Delta = 0).  A round: [the conflict rows' later-column terms, spread evenly
+            // over the groups] barrier [my columns' sums and steps] barrier [chain] barrier; it
+            // was the last one when no p' and no f changed a bit (then no Delta did).
             for (int round = 0;; ++round) {
-                const double* vprev = vbuf[(round + 1) & 1];
-                double* vcur = vbuf[round & 1];
+                // the later column's term of my conflict rows: the record after the earlier
+                // column's update for its current Delta (pbcd.py:135-144), rounded to T as the
+                // scatter rounds
+                for (int c = grp; c < nconf; c += NG) {
+                    const int2 cq = sh_cq[c];
+                    const double2 cx = sh_cx[c];
+                    const double av = kl ? sh_cr[c * L + lane] : 0.0;
+                    const double pa = sh_po[cq.x * L + lane], pbv = sh_po[cq.y * L + lane];
+                    const double Da = (round == 0 || !kl)
+                                          ? 0.0
+                                          : pa - sh_pt[cq.x * L + lane] * sh_scal[4 * cq.x + 2];
+                    const double dAa = kl ? cx.x * (av - pa * cx.x) : 0.0;
+                    const double a1 = kl ? (double)(T)(av - Da * cx.x) : 0.0;
+                    const double dec = pb_group_allsum<L>(kl ? (lam * Da) * dAa : 0.0);
+                    const double y1 = (double)(T)(sh_cr[c * L + L - 2] - dec);
+                    const double dAb = kl ? cx.y * (a1 - pbv * cx.y) : 0.0;
+                    const double dl1 = dloss_dev(loss, y1, sh_cr[c * L + L - 1]);
+                    const double hs = pb_group_allsum<L>(dAb * dAb);
+                    sh_tb[c * L + lane] = (lane == L - 2) ? hs : dl1 * dAb;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 bool changed = false;
 #pragma unroll
                 for (int t = 0; t < QM; ++t) {
                     const int q = slot_of(qs0, t);
-                    if (q < ncols) {  // (group-uniform)
-                        // my column's sums = totals + conflict terms; the later column's term of
-                        // a conflict row = the record after the earlier column's update for its
-                        // current Delta (pbcd.py:135-144), rounded to T as the scatter rounds
-                        double tot = base[t];
+                    if (q < ncols) {  // (group-uniform): sums = totals + conflict terms; the step
+                        double tot = sh_dl[q * L + lane];
                         for (int e = 0; e < 8; ++e) {
                             const int ce = sh_cl[q * 8 + e];
-                            if (ce < 0 || (ce >> 8) == 0) continue;
-                            const int c = ce & 0xff;
-                            const int2 cq = sh_cq[c];
-                            const double2 cx = sh_cx[c];
-                            const double av = kl ? sh_cr[c * L + lane] : 0.0;
-                            const double pa = sh_po[cq.x * L + lane];
-                            const double Da = (round == 0 || !kl)
-                                                  ? 0.0
-                                                  : pa - vprev[cq.x * L + lane] * sh_scal[4 * cq.x + 2];
-                            const double dAa = kl ? cx.x * (av - pa * cx.x) : 0.0;
-                            const double a1 = kl ? (double)(T)(av - Da * cx.x) : 0.0;
-                            const double dec = pb_group_allsum<L>(kl ? (lam * Da) * dAa : 0.0);
-                            const double y1 = (double)(T)(sh_cr[c * L + L - 2] - dec);
-                            const double dAb = kl ? cx.y * (a1 - po[t] * cx.y) : 0.0;
-                            const double dl1 = dloss_dev(loss, y1, sh_cr[c * L + L - 1]);
-                            const double hs = pb_group_allsum<L>(dAb * dAb);
-                            tot += (lane == L - 2) ? hs : dl1 * dAb;
+                            if (ce >= 0 && (ce >> 8) != 0) tot += sh_tb[(ce & 0xff) * L + lane];
                         }
                         double l2, st0;
                         const double v = pb_block_step<L>(tot, po[t], lam, kl, grp, reg, mu, beta,
                                                           gamma, eta, l2, st0);
                         changed = changed || round == 0 ||
-                                  __double_as_longlong(v) != __double_as_longlong(vprev[q * L + lane]);
-                        vcur[q * L + lane] = v;
+                                  __double_as_longlong(v) != __double_as_longlong(sh_pt[q * L + lane]);
+                        sh_pt[q * L + lane] = v;
                         if (lane == 0) {
                             sh_scal[4 * q + 3] = sh_scal[4 * q + 2];  // f of the previous round
                             sh_scal[4 * q + 0] = l2;
@@ -1047,10 +1063,10 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
                         atomicAdd(&g_branch_count[BR_RELAX_STEPS], 1u);
                         atomicAdd(&g_branch_count[BR_RELAX_ROUNDS], (unsigned)(round + 1));
                     }
-                    vfin = vcur;
                     break;
                 }
             }
+            PB_STAMP(11)
             // the columns' Deltas for the conflict rows' final records
 #pragma unroll
             for (int t = 0; t < QM; ++t) {
@@ -1185,10 +1201,8 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         if constexpr (CR) {
             // the conflict rows' final records, by their owner: both updates in order
             // (pbcd.py:135-144 twice), each rounded to T as the scatter rounds
-            const PrbConf<T>* cfa = reinterpret_cast<const PrbConf<T>*>(a.cf);
-            const int cp0 = a.cf_ptr[b];
             for (int c = grp; c < nconf; c += NG) {
-                const int row = cfa[cp0 + c].row;
+                const int row = sh_crow[c];
                 if (row / a.rows_per != g) continue;
                 const int2 cq = sh_cq[c];
                 const double2 cx = sh_cx[c];
@@ -1218,6 +1232,12 @@ __global__ __launch_bounds__(kPbPrbThreads) void pbcd_prb_kernel(
         qs0 = qs1;
         qs1 = qs2;
         qs2 = qs3;
+        if constexpr (CR) {
+            cfp0 = cfp1;
+            cfp1 = cfp2;
+            cfp2 = cfp3;
+            cfp3 = cfp4;
+        }
 #pragma unroll
         for (int t = 0; t < QM; ++t) {
             j0[t] = j1[t];
@@ -1255,7 +1275,7 @@ constexpr size_t pbcd_prb_lds_bytes() {
     constexpr int NG = kPbPrbThreads / L;
     constexpr int AS = Kind<M>::AS;
     constexpr int ER = (CR && pbprb_er<T, M>() > 4) ? 4 : pbprb_er<T, M>();
-    return (CR ? sizeof(double) * (5 * 64 * L + 2 * (kMaxDegree + 2) + 2 * 64) + sizeof(int) * (2 * 64 + 4) +
+    return (CR ? sizeof(double) * (5 * 64 * L + 2 * (kMaxDegree + 2) + 2 * 64) + sizeof(int) * (3 * 64 + 4) +
                      sizeof(short) * 64 * 8 : 0) +
            sizeof(double) * (2 * NG * L + 64 * L + 256 + 2 * NG * L + 2 * (kMaxDegree + 2)) +
            sizeof(int) * (4 * NG * L + 4) +

@@ -23,7 +23,7 @@ Xc.sort_indices()
 k = 30
 PHASES = ["p0 shared rows+wait", "p1 late sums+publish", "p2 owner poll", "p2 barrier+step+publish",
           "prefetch issue", "p3 collect poll", "p4 chain+barrier", "p5 scatter", "rotate+end barrier",
-          "p3 barrier", "early phase (next step's unshared rows)"]
+          "p3 barrier", "CR: replay set-up + earlier-column terms", "CR: rounds"]
 for G in groups:
     for stamps in (0, 1):
         eng = HipEngine(0, "f32")
@@ -35,7 +35,7 @@ for G in groups:
         eng.set_params(0.01 * np.random.RandomState(0).randn(1, k, d), np.zeros(d), np.ones(k))
         eng.configure("pbcd", "squared", reg, 2)
         eng.init_pred(2, True, False)
-        eng.set_schedule("colored", np.arange(d, dtype=np.int32))
+        eng.set_schedule(os.environ.get("PB_SCHED", "colored"), np.arange(d, dtype=np.int32))
         v = [eng.pbcd_epoch(0, 2, 1.0, 1e-3, 1.0)]
         t0 = time.perf_counter()
         reps = 3
@@ -49,8 +49,8 @@ for G in groups:
         if int(os.environ.get("PB_DBG", 0)) & 8:
             out["dbg"] = [int(x) for x in eng.debug_prb_stamps().ravel()[:16]]
         elif stamps:
-            st = eng.debug_prb_stamps()[:, :11].astype(np.float64) / eng.n_batches
-            scale = (dt * 1e9 / eng.n_batches) / st[0].sum()  # cycles -> ns via the wall time
+            st = eng.debug_prb_stamps()[:, :12].astype(np.float64) / (eng.get_option("relax_steps") or eng.n_batches)
+            scale = (dt * 1e9 / (eng.get_option("relax_steps") or eng.n_batches)) / st[0].sum()  # cycles -> ns via the wall time
             out["cycles_per_step_wg0"] = round(float(st[0].sum()))
             out["phase_ns_wg0"] = dict(zip(PHASES, [round(float(x * scale)) for x in st[0]]))
             out["phase_ns_wg1"] = dict(zip(PHASES, [round(float(x * scale)) for x in st[min(1, len(st) - 1)]]))

@@ -260,6 +260,7 @@ struct spfm_engine {
     int pa_degree = 0, pa_lin = 0, pa_lower = 0;
     DevBuf snapP, snapW, snapC;
     std::map<const void*, int> resident_cache;  // kernel -> workgroups that can be resident
+    std::map<std::string, bool> resident_agreed;  // several ranks: the verdict all of them took
 
     // persistent row-block pass (single GPU, pcd): one launch per component pass
     bool persistent = true;

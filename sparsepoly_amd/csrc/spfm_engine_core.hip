@@ -962,7 +962,26 @@ bool spfm_engine::resident_ok(const void* fn, int threads, size_t lds, int G) {
     // host-shm communicator: ranks on one GPU; co_tenants: handles of this process whose
     // persistent passes run side by side (concurrent fits, one stream each)
     const int64_t sharers = (int64_t)(shm.hdr ? n_ranks : 1) * co_tenants;
-    return (int64_t)per_cu * ncu >= (int64_t)G * sharers;
+    const bool mine = (int64_t)per_cu * ncu >= (int64_t)G * sharers;
+    if (!dist()) return mine;
+    // Several ranks: the verdict must be the same on all of them -- a rank that alone switched to
+    // the multi-kernel engine would issue a per-step collective while its peers sit in the
+    // in-kernel exchange.  Agreed once per (kernel, grid, sharers): the sum of the ranks' "no".
+    char key[96];
+    snprintf(key, sizeof key, "%p|%d|%lld|%zu", fn, G, (long long)sharers, lds);
+    auto ag = resident_agreed.find(key);
+    if (ag != resident_agreed.end()) return ag->second;
+    double no = mine ? 0.0 : 1.0;
+    bool agreed = mine;
+    if (scalar.p && hipMemcpyAsync(scalar.as<double>() + 7, &no, sizeof(double), hipMemcpyHostToDevice,
+                                   stream) == hipSuccess &&
+        hipStreamSynchronize(stream) == hipSuccess && allreduce(scalar.as<double>() + 7, 1) == SPFM_OK &&
+        hipMemcpyAsync(&no, scalar.as<double>() + 7, sizeof(double), hipMemcpyDeviceToHost, stream) ==
+            hipSuccess &&
+        hipStreamSynchronize(stream) == hipSuccess)
+        agreed = no == 0.0;
+    resident_agreed[key] = agreed;
+    return agreed;
 }
 
 int spfm_engine::snapshot_state(const double* params, size_t count, DevBuf& dst) {
@@ -1335,6 +1354,7 @@ int spfm_comm_init(spfm_handle h, const char* id128, int n_ranks, int rank) {
     h->n_ranks = n_ranks;
     h->rank = rank;
     h->col_norm_reduced = false;
+    h->resident_agreed.clear();
     h->clear_graphs();
     return SPFM_OK;
 }
@@ -1371,6 +1391,7 @@ int spfm_comm_init_shm(spfm_handle h, const char* shm_name, int n_ranks, int ran
     h->shm.local_sense = 0;
     h->n_ranks = n_ranks;
     h->rank = rank;
+    h->resident_agreed.clear();
     h->col_norm_reduced = false;
     h->clear_graphs();
     return SPFM_OK;

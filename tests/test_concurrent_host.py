@@ -190,3 +190,55 @@ def test_shared_schedule_leader_failure_lets_the_followers_compute():
         a.join()
         b.join()
     assert sorted(res) == ["error", "order"]
+
+
+def test_fan_out_over_devices_binds_every_worker_to_its_device():
+    """fit_concurrently(devices=[...]): per device `max_concurrent` worker threads, each bound to
+    its device and to the call's shared caches; every estimator is fitted exactly once; an
+    estimator's own `device` is not consulted.  Stand-in estimators: no GPU needed."""
+    import threading
+
+    from sparsepoly_amd import engine as E
+    from sparsepoly_amd.concurrent import fit_concurrently
+
+    seen = []
+    lock = threading.Lock()
+    gate = threading.Barrier(6)  # all six workers are alive at once
+
+    class Stub(object):
+        distributed = False
+        warm_start = False
+        solver = "pcd"
+        device = 7  # must be ignored
+
+        def __init__(self, i):
+            self.i = i
+
+        def fit(self, X, y):
+            ten = E.current_tenancy()
+            try:
+                gate.wait(10)
+            except threading.BrokenBarrierError:
+                pass
+            with lock:
+                seen.append((self.i, ten.device, ten.n, ten.schedules is not None,
+                             ten.images is not None, threading.current_thread().name))
+            return self
+
+    ests = [Stub(i) for i in range(12)]
+    out = fit_concurrently(ests, "X", "y", max_concurrent=2, devices=[0, 3, 5])
+    assert out == ests
+    assert sorted(s[0] for s in seen) == list(range(12))
+    assert {s[1] for s in seen} == {0, 3, 5}
+    assert all(s[2] == 2 and s[3] and s[4] for s in seen)
+    # two workers per device
+    per_dev = {}
+    for s in seen:
+        per_dev.setdefault(s[1], set()).add(s[5])
+    assert all(len(v) == 2 for v in per_dev.values())
+    assert E.current_tenancy() is None
+    # without `devices` the workers carry no device: the estimator's own is used
+    seen.clear()
+    gate = threading.Barrier(2)
+    fit_concurrently([Stub(0), Stub(1)], "X", "y", max_concurrent=2)
+    assert {s[1] for s in seen} == {None}

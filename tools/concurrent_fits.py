@@ -7,6 +7,10 @@ aggregate iterations per second, and whether every fit equals its solo run bitwi
 
     [CONFIG=3] [ITERS=3] [NO_CHECK=1] python tools/concurrent_fits.py [F ...]      (default 1 2 3 4)
 
+SHARE=1 (default): the tenants attach to ONE device image of the matrix and share the entry stream
+(spfm_share_data); SHARE=0: every tenant uploads and transposes its own copy (round 3).  The line
+carries the device memory in use while the F fits run (hipMemGetInfo through ctypes).
+
 Diagnostics: WITH_TORCH=1 (a torch kernel on the null stream first), PRE=n PRE_SCHED=exact
 (handles created, run and closed beforehand), GPU_MAX_HW_QUEUES=4 (the runtime's own default).
 """
@@ -33,12 +37,28 @@ GAMMAS = [G0 * f for f in (1.0, 2.0, 0.5, 10.0, 3.0, 0.7, 20.0, 4.0)]
 ITERS = int(os.environ.get("ITERS", "3"))
 
 
-def make_engine(X, y, P0, F, sched="colored"):
+SHARE = os.environ.get("SHARE", "1") == "1"
+
+
+def device_mem_used_gb():
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    if hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) != 0:
+        return None
+    return round((total.value - free.value) / 2 ** 30, 3)
+
+
+def make_engine(X, y, P0, F, sched="colored", owner=None):
     d = X.shape[1]
     eng = HipEngine(0, "f32")
     if F > 1:
-        eng.set_option("co_tenants", F)
-    eng.set_data(X, y)
+        eng.set_option("co_tenants", min(F, 4))
+    if owner is not None:
+        eng.share_data(owner, y)
+    else:
+        eng.set_data(X, y)
     eng.set_params(P0, np.zeros(d), np.ones(K))
     eng.configure(SOLVER, "squared", REG, DEGREE)
     eng.init_pred(DEGREE, True, DEGREE == 3)
@@ -85,10 +105,14 @@ def main():
             iterate(e, GAMMAS[0], 1, o, 0)
         e.close()
     for F in Fs:
-        engs = [make_engine(X, y, P0, F) for _ in range(F)]
+        mem0 = device_mem_used_gb()
+        engs = []
+        for f in range(F):
+            engs.append(make_engine(X, y, P0, F, owner=engs[0] if (SHARE and f > 0) else None))
         out = [None] * F
         for f, e in enumerate(engs):          # warm-up: builds the entry streams
             iterate(e, GAMMAS[f], 1, out, f)
+        mem1 = device_mem_used_gb()
         barrier = threading.Barrier(F)
         th = [threading.Thread(target=iterate, args=(engs[f], GAMMAS[f], ITERS, out, f, barrier))
               for f in range(F)]
@@ -130,7 +154,9 @@ def main():
             "config": CONFIG, "fits": F, "iterations": ITERS, "ms_per_iteration_wall": round(ms_iter, 1),
             "ms_per_iteration_per_fit": [round(1e3 * o[0] / ITERS, 1) for o in out],
             "aggregate_epochs_per_s": round(agg, 3),
-            "equals_solo_bitwise": same, "persistent_fallbacks": fallbacks}), flush=True)
+            "equals_solo_bitwise": same, "persistent_fallbacks": fallbacks, "shared_image": SHARE,
+            "device_mem_gb_before": mem0, "device_mem_gb_with_fits": mem1,
+            "device_mem_gb_of_the_fits": None if mem0 is None else round(mem1 - mem0, 3)}), flush=True)
 
 
 if __name__ == "__main__":

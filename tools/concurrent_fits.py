@@ -33,7 +33,10 @@ SOLVER, REG, DEGREE, K, BETA, G0 = {
     3: ("pcd", "omegati", 3, 16, 10.0, 1e-6),
     4: ("pbcd", "omegacs", 2, 30, 1.0, 1e-3)}[CONFIG]
 ALPHA = 1.0
-GAMMAS = [G0 * f for f in (1.0, 2.0, 0.5, 10.0, 3.0, 0.7, 20.0, 4.0)]
+GAMMAS = [G0 * f for f in (1.0, 2.0, 0.5, 10.0, 3.0, 0.7, 20.0, 4.0)] * 4
+# CO=n: co_tenants as given (default min(F, 4): more than four fits take turns on the CUs; CO=F makes
+# every fit keep to 1/F of the CUs -- smaller row-block counts, rows in global memory beyond four)
+CO = int(os.environ.get("CO", "0"))
 ITERS = int(os.environ.get("ITERS", "3"))
 
 
@@ -54,7 +57,7 @@ def make_engine(X, y, P0, F, sched="colored", owner=None):
     d = X.shape[1]
     eng = HipEngine(0, "f32")
     if F > 1:
-        eng.set_option("co_tenants", min(F, 4))
+        eng.set_option("co_tenants", CO if CO > 0 else min(F, 4))
     if owner is not None:
         eng.share_data(owner, y)
     else:
@@ -127,6 +130,7 @@ def main():
             P, w = e.get_params()
             res.append((P, w, e.get_y_pred()))
         fallbacks = [e.get_option("persistent_fallbacks") for e in engs]
+        groups = engs[0].get_option("prb_groups" if SOLVER == "pcd" else "pbprb_groups")
         for e in engs:
             e.close()
         same = None
@@ -154,6 +158,7 @@ def main():
             "config": CONFIG, "fits": F, "iterations": ITERS, "ms_per_iteration_wall": round(ms_iter, 1),
             "ms_per_iteration_per_fit": [round(1e3 * o[0] / ITERS, 1) for o in out],
             "aggregate_epochs_per_s": round(agg, 3),
+            "co_tenants": CO if CO > 0 else min(F, 4), "prb_groups": groups,
             "equals_solo_bitwise": same, "persistent_fallbacks": fallbacks, "shared_image": SHARE,
             "device_mem_gb_before": mem0, "device_mem_gb_with_fits": mem1,
             "device_mem_gb_of_the_fits": None if mem0 is None else round(mem1 - mem0, 3)}), flush=True)

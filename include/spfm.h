@@ -222,11 +222,26 @@ int spfm_host_epoch_end(spfm_handle h, double* viol);
  *   sum_loss       out: sum over samples of loss(y_pred_i, y_i) at visiting time
  * Requires spfm_configure(h, SPFM_SOLVER_PSGD, loss, reg, degree) with reg in {l1, l21,
  * squaredl12, squaredl21}; no schedule is needed.  The training-time y_pred vector
- * (spfm_get_y_pred / spfm_loss_sum) is not maintained by this solver.  Single GPU. */
+ * (spfm_get_y_pred / spfm_loss_sum) is not maintained by this solver.  One rank; several ranks:
+ * spfm_psgd_epoch_sharded. */
 int spfm_psgd_epoch(spfm_handle h, int degree, double alpha, double beta, double gamma,
                     double eta0, int learning_rate, double power_t, int64_t batch_size,
                     const int32_t* indices_samples, int64_t n_samples, int fit_linear,
                     int64_t* it, double* sum_loss);
+/* The same epoch with the rows sharded over the ranks of the handle's communicator (data-parallel
+ * minibatch SGD; the reference has no distributed code -- this is what its loop implies:
+ * _update_grads (psgd.py:60-91) sums over the samples of a minibatch, _update_params
+ * (psgd.py:94-122) is a function of those sums alone).  The handle holds the rows
+ * [row_lo, row_lo + n_local) of a problem of n_global rows; indices_samples is the GLOBAL visiting
+ * order (a permutation of 0..n_global-1, identical on every rank).  Every rank forms the gradient
+ * of its own samples of a minibatch, the gradients are all-reduced (sum, f64: one collective of
+ * n_orders*k*d + d doubles per minibatch), and every rank applies the identical update with the
+ * GLOBAL batch size in eta/B -- parameters stay replicated.  sum_loss is the global sum.  Without
+ * a communicator (one rank) it is spfm_psgd_epoch. */
+int spfm_psgd_epoch_sharded(spfm_handle h, int degree, double alpha, double beta, double gamma,
+                            double eta0, int learning_rate, double power_t, int64_t batch_size,
+                            const int32_t* indices_samples, int64_t n_global, int64_t row_lo,
+                            int fit_linear, int64_t* it, double* sum_loss);
 
 /* -- multi-GPU (one process per GPU, RCCL over xGMI) ---------------------------
  * Rows are sharded; the column partial sums of every step are all-reduced

@@ -87,7 +87,8 @@ SYMBOLS = [
     "spfm_loss_sum", "spfm_predict_csr", "spfm_set_schedule", "spfm_set_schedule_raw",
     "spfm_get_schedule", "spfm_schedule_build",
     "spfm_cd_linear_epoch",
-    "spfm_pcd_epoch", "spfm_pbcd_epoch", "spfm_psgd_epoch", "spfm_host_epoch_begin",
+    "spfm_pcd_epoch", "spfm_pbcd_epoch", "spfm_psgd_epoch", "spfm_psgd_epoch_sharded",
+    "spfm_host_epoch_begin",
     "spfm_host_pass_begin", "spfm_host_step_sums", "spfm_host_step_apply", "spfm_host_epoch_end", "spfm_comm_unique_id", "spfm_comm_init", "spfm_comm_init_shm", "spfm_peer_alloc", "spfm_peer_connect",
     "spfm_profile_enable", "spfm_profile_get", "spfm_profile_reset", "spfm_set_use_graph",
     "spfm_set_option", "spfm_get_option", "spfm_debug_prb_stamps", "spfm_debug_hop_latency", "spfm_debug_exchange_cost",
@@ -144,6 +145,9 @@ def load():
     L.spfm_psgd_epoch.argtypes = [_h, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                   C.c_int, C.c_double, C.c_int64, _ip, C.c_int64, C.c_int, _lp,
                                   _dp]
+    L.spfm_psgd_epoch_sharded.argtypes = [_h, C.c_int, C.c_double, C.c_double, C.c_double,
+                                          C.c_double, C.c_int, C.c_double, C.c_int64, _ip,
+                                          C.c_int64, C.c_int64, C.c_int, _lp, _dp]
     L.spfm_host_epoch_begin.argtypes = [_h, C.c_int, C.c_int]
     L.spfm_host_pass_begin.argtypes = [_h, C.c_int]
     L.spfm_host_step_sums.argtypes = [_h, C.c_int, _dp]

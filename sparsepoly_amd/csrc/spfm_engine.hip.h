@@ -803,9 +803,14 @@ struct spfm_engine {
     int psgd_epoch_tl(int degree, double alpha, double beta, double gamma, double eta0, int lr,
                       double power_t, int64_t batch_size, int fit_linear, int64_t* it);
 
+    // row_lo / n_global: several ranks (spfm_psgd_epoch_sharded); one rank: 0 / n
     int psgd_epoch(int degree, double alpha, double beta, double gamma, double eta0, int lr,
                    double power_t, int64_t batch_size, const int32_t* indices_samples,
-                   int64_t n_samples, int fit_linear, int64_t* it, double* sum_loss);
+                   int64_t n_samples, int64_t row_lo, int fit_linear, int64_t* it, double* sum_loss);
+    // several ranks: per minibatch of the GLOBAL order this rank's samples (first position in
+    // its local sample list, count) and the global batch size
+    std::vector<int64_t> sg_lpos;
+    std::vector<int32_t> sg_lB, sg_gB;
 
     // diagnostics that need kernels of one translation unit
     int debug_stream_probe(int64_t* bytes_out);  // spfm_engine_pcd.hip

@@ -1301,8 +1301,21 @@ int spfm_psgd_epoch(spfm_handle h, int degree, double alpha, double beta, double
                     const int32_t* indices_samples, int64_t n_samples, int fit_linear,
                     int64_t* it, double* sum_loss) {
     GUARD(h);
+    if (h->dist()) {
+        h->err = "psgd: several ranks share this handle's communicator -- use spfm_psgd_epoch_sharded";
+        return SPFM_ERR_INVALID;
+    }
     return h->psgd_epoch(degree, alpha, beta, gamma, eta0, learning_rate, power_t, batch_size,
-                         indices_samples, n_samples, fit_linear, it, sum_loss);
+                         indices_samples, n_samples, 0, fit_linear, it, sum_loss);
+}
+
+int spfm_psgd_epoch_sharded(spfm_handle h, int degree, double alpha, double beta, double gamma,
+                            double eta0, int learning_rate, double power_t, int64_t batch_size,
+                            const int32_t* indices_samples, int64_t n_global, int64_t row_lo,
+                            int fit_linear, int64_t* it, double* sum_loss) {
+    GUARD(h);
+    return h->psgd_epoch(degree, alpha, beta, gamma, eta0, learning_rate, power_t, batch_size,
+                         indices_samples, n_global, row_lo, fit_linear, it, sum_loss);
 }
 
 int spfm_comm_unique_id(char* id128) {

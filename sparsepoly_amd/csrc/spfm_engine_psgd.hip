@@ -66,7 +66,8 @@ int spfm_engine::psgd_epoch_tl(int degree, double alpha, double beta, double gam
     // table, so every (gradient, update) pair has identical arguments
     // (squared-norm prox: the first epoch after configure() starts the support search cold --
     // 6-13 sweeps -- and runs eagerly; afterwards minibatches warm-start each other)
-    if (use_graph && !prof_on && !psgd_force_eager && (!mich || psgd_warm)) {
+    // (several ranks: every minibatch carries a collective -- eager launches)
+    if (use_graph && !prof_on && !psgd_force_eager && !dist() && (!mich || psgd_warm)) {
         constexpr int kPsgdRun = 32;
         const int kMichSweeps = psgd_graph_sweeps;  // recorded sweeps per minibatch (2 suffice
                                                     // with the warm start; a failed check
@@ -170,17 +171,32 @@ int spfm_engine::psgd_epoch_tl(int degree, double alpha, double beta, double gam
         HIPC(hipMemsetAsync(sg_gradw.p, 0, sizeof(double) * (size_t)d, stream));
         psgd_redone += 1;
     }
-    for (int64_t pos = 0; pos < n; pos += batch_size) {
-        const int B = (int)std::min<int64_t>(batch_size, n - pos);
+    // one rank: the batches of its n samples; several ranks: the batches of the global order,
+    // of which this rank holds samples [lpos, lpos + lB) of its local list (psgd_epoch)
+    const bool sharded = dist();
+    const int64_t nbat_e = sharded ? (int64_t)sg_gB.size() : cdiv(n, batch_size);
+    for (int64_t bi = 0; bi < nbat_e; ++bi) {
+        const int64_t pos = sharded ? sg_lpos[(size_t)bi] : bi * batch_size;
+        const int lB = sharded ? sg_lB[(size_t)bi] : (int)std::min<int64_t>(batch_size, n - pos);
+        const int B = sharded ? sg_gB[(size_t)bi] : lB;  // eta / B: the whole minibatch
         prof_begin(0, 0);
-        hipLaunchKernelGGL((psgd_grad_kernel<T, L>), dim3(cdiv(B, gpb)), dim3(kBlock), 0, stream,
-                           sg_samples.as<int32_t>() + pos, B, rptr.as<int64_t>(),
-                           ridx.as<int32_t>(), rval.as<T>(), yy.as<T>(), Pt.as<double>(),
-                           w.as<double>(), lams.as<double>(), n_orders, k, d, degree, loss,
-                           fit_linear, sg_gradP.as<double>(), sg_gradw.as<double>(),
-                           pred_tmp.as<double>() + pos, (const PsgdBatch*)nullptr,
-                           (int*)nullptr);
+        if (lB > 0)
+            hipLaunchKernelGGL((psgd_grad_kernel<T, L>), dim3(cdiv(lB, gpb)), dim3(kBlock), 0,
+                               stream, sg_samples.as<int32_t>() + pos, lB, rptr.as<int64_t>(),
+                               ridx.as<int32_t>(), rval.as<T>(), yy.as<T>(), Pt.as<double>(),
+                               w.as<double>(), lams.as<double>(), n_orders, k, d, degree, loss,
+                               fit_linear, sg_gradP.as<double>(), sg_gradw.as<double>(),
+                               pred_tmp.as<double>() + pos, (const PsgdBatch*)nullptr,
+                               (int*)nullptr);
         prof_end(0);
+        if (sharded) {  // sum of the ranks' gradients: identical bits on every rank
+            int arc = allreduce(sg_gradP.as<double>(), (size_t)n_orders * k * d);
+            if (arc) return arc;
+            if (fit_linear) {
+                arc = allreduce(sg_gradw.as<double>(), (size_t)d);
+                if (arc) return arc;
+            }
+        }
         double eta_P, eta_w;
         psgd_eta(lr, eta0, alpha, beta, power_t, *it, &eta_P, &eta_w);
         const double strength = gamma * eta_P / (1 + eta_P * beta);
@@ -229,36 +245,63 @@ int spfm_engine::psgd_epoch_tl(int degree, double alpha, double beta, double gam
 // optimizer/psgd.py:125-199: one pass over indices_samples
 int spfm_engine::psgd_epoch(int degree, double alpha, double beta, double gamma, double eta0, int lr,
                double power_t, int64_t batch_size, const int32_t* indices_samples,
-               int64_t n_samples, int fit_linear, int64_t* it, double* sum_loss) {
+               int64_t n_samples, int64_t row_lo, int fit_linear, int64_t* it, double* sum_loss) {
     if (!have_data || !have_params || !configured)
         FAIL(SPFM_ERR_INVALID, "epoch: data, parameters and configuration are required");
     if (solver != SPFM_SOLVER_PSGD) FAIL(SPFM_ERR_INVALID, "engine is not configured for psgd");
-    if (dist()) FAIL(SPFM_ERR_UNSUPPORTED, "psgd: multi-GPU is not supported");
     if (degree != top_degree) FAIL(SPFM_ERR_INVALID, "psgd: degree differs from configure()");
-    if (!indices_samples || !it || n_samples != n)
+    const bool sharded = dist();
+    if (!indices_samples || !it || (!sharded && (n_samples != n || row_lo != 0)))
         FAIL(SPFM_ERR_INVALID, "psgd: indices_samples must list every sample once");
+    if (sharded && (row_lo < 0 || row_lo + n > n_samples || n_samples > INT32_MAX))
+        FAIL(SPFM_ERR_INVALID, "psgd: the handle's rows [row_lo, row_lo + n) lie outside the "
+                               "global sample range");
     if (batch_size < 1) FAIL(SPFM_ERR_INVALID, "psgd: batch_size must be >= 1");
     if (lr < 0 || lr > 3) FAIL(SPFM_ERR_INVALID, "psgd: learning_rate is not supported.");
     if (*it < 1) FAIL(SPFM_ERR_INVALID, "psgd: it must be >= 1");
     {
-        std::vector<char> seen((size_t)n, 0);
-        for (int64_t q = 0; q < n; ++q) {
+        std::vector<char> seen((size_t)n_samples, 0);
+        for (int64_t q = 0; q < n_samples; ++q) {
             const int i = indices_samples[q];
-            if (i < 0 || i >= n || seen[(size_t)i])
+            if (i < 0 || i >= n_samples || seen[(size_t)i])
                 FAIL(SPFM_ERR_INVALID, "psgd: indices_samples is not a permutation");
             seen[(size_t)i] = 1;
         }
     }
-    if (n == 0) {
+    if (n_samples == 0) {
         if (sum_loss) *sum_loss = 0.0;
         return SPFM_OK;
     }
     int rc = ensure_pt();
     if (rc) return rc;
     p_valid = false;
-    HIPC(hipMemcpyAsync(sg_samples.p, indices_samples, sizeof(int32_t) * (size_t)n,
-                        hipMemcpyHostToDevice, stream));
-    HIPC(hipStreamSynchronize(stream));  // caller may reuse indices_samples
+    std::vector<int32_t> local;  // several ranks: this rank's samples in visiting order
+    if (sharded) {
+        const int64_t nbat = cdiv(n_samples, batch_size);
+        sg_lpos.assign((size_t)nbat, 0);
+        sg_lB.assign((size_t)nbat, 0);
+        sg_gB.assign((size_t)nbat, 0);
+        local.reserve((size_t)n);
+        for (int64_t bi = 0; bi < nbat; ++bi) {
+            const int64_t pos = bi * batch_size;
+            const int64_t B = std::min<int64_t>(batch_size, n_samples - pos);
+            sg_lpos[(size_t)bi] = (int64_t)local.size();
+            for (int64_t q = pos; q < pos + B; ++q) {
+                const int64_t i = (int64_t)indices_samples[q] - row_lo;
+                if (i >= 0 && i < n) local.push_back((int32_t)i);
+            }
+            sg_lB[(size_t)bi] = (int32_t)((int64_t)local.size() - sg_lpos[(size_t)bi]);
+            sg_gB[(size_t)bi] = (int32_t)B;
+        }
+        if ((int64_t)local.size() != n)
+            FAIL(SPFM_ERR_INVALID, "psgd: the global order does not hold this rank's rows once");
+        indices_samples = local.data();
+    }
+    if (n > 0) {
+        HIPC(hipMemcpyAsync(sg_samples.p, indices_samples, sizeof(int32_t) * (size_t)n,
+                            hipMemcpyHostToDevice, stream));
+        HIPC(hipStreamSynchronize(stream));  // caller may reuse indices_samples
+    }
 #define SPFM_PSGD_GO(T, L)                                                                    \
 rc = psgd_epoch_tl<T, L>(degree, alpha, beta, gamma, eta0, lr, power_t, batch_size,        \
                          fit_linear, it)
@@ -278,6 +321,10 @@ rc = psgd_epoch_tl<T, L>(degree, alpha, beta, gamma, eta0, lr, power_t, batch_si
     hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(kBlock), 0, stream,
                        partial.as<double>(), 256, scalar.as<double>());
     HIPC(hipGetLastError());
+    if (sharded) {
+        rc = allreduce(scalar.as<double>(), 1);
+        if (rc) return rc;
+    }
     HIPC(hipMemcpyAsync(h_scalar, scalar.p, sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPC(hipStreamSynchronize(stream));
     prof_collect();

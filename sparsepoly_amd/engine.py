@@ -535,13 +535,22 @@ class HipEngine(object):
         return viol
 
     def psgd_epoch(self, degree, alpha, beta, gamma, eta0, learning_rate, power_t, batch_size,
-                   indices_samples, fit_linear, it):
-        """``psgd.psgd_epoch`` (optimizer/psgd.py:125-199).  Returns (sum_loss, it)."""
+                   indices_samples, fit_linear, it, row_lo=None):
+        """``psgd.psgd_epoch`` (optimizer/psgd.py:125-199).  Returns (sum_loss, it).
+        ``row_lo`` (several ranks, ``spfm_psgd_epoch_sharded``): the handle holds the rows from
+        ``row_lo`` on of the problem whose GLOBAL visiting order ``indices_samples`` is; the
+        minibatch gradients are all-reduced, ``sum_loss`` is the global sum."""
         idx = np.ascontiguousarray(indices_samples, dtype=np.int32)
         itc = C.c_int64(int(it))
         sl = C.c_double()
         lr = (_capi.LEARNING_RATE[learning_rate] if isinstance(learning_rate, str)
               else int(learning_rate))
+        if row_lo is not None:
+            self._check(self._lib.spfm_psgd_epoch_sharded(
+                self._h, int(degree), float(alpha), float(beta), float(gamma), float(eta0), lr,
+                float(power_t), int(batch_size), idx.ctypes.data_as(_capi._ip), idx.size,
+                int(row_lo), int(bool(fit_linear)), C.byref(itc), C.byref(sl)))
+            return sl.value, itc.value
         self._check(self._lib.spfm_psgd_epoch(
             self._h, int(degree), float(alpha), float(beta), float(gamma), float(eta0), lr,
             float(power_t), int(batch_size), idx.ctypes.data_as(_capi._ip), idx.size,

@@ -345,9 +345,12 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
         for epoch in range(self.max_iter):
             if self.shuffle:
                 rng.shuffle(indices_samples)
+            # (distributed: the global order on every rank; each forms the gradient of its own
+            # rows of a minibatch, the sums are all-reduced -- spfm_psgd_epoch_sharded)
             sum_loss, self.it_ = engine.psgd_epoch(
                 self.degree, self.alpha, self.beta, self.gamma, self.eta0, self.learning_rate,
-                self.power_t, batch_size, indices_samples, self.fit_linear, self.it_)
+                self.power_t, batch_size, indices_samples, self.fit_linear, self.it_,
+                row_lo=self._row_lo if self.distributed else None)
             if (self.callback is not None) and epoch % self.n_calls == 0:
                 self._sync_params(engine, with_P=False)
                 if self.callback(self) is not None:
@@ -418,8 +421,6 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
             msg = f"Solver {self.solver} is not supported."
             raise ValueError(msg)
         if self.solver == "psgd":
-            if self.distributed:
-                raise ValueError("solver='psgd' runs on one GPU (distributed=False).")
             if not (self.warm_start and hasattr(self, "it_")):
                 self.it_ = 1  # :411-412
         if not isinstance(self.schedule, Schedule) and self.schedule not in ("exact", "colored"):
@@ -460,10 +461,12 @@ class _BaseSparseFactorizationMachine(BaseSparsePoly, metaclass=ABCMeta):
                 from . import distributed as _dist
 
                 lo, hi = _dist.row_block(n_samples)
+                self._row_lo = lo
                 conflict_csc = Xc
                 Xl = canonical_csc(Xc.tocsr()[lo:hi])
                 _dist.init_engine_comm(engine)
-                _dist.connect_peers(engine)  # in-kernel exchange for the persistent passes
+                if self.solver != "psgd":  # (psgd: one collective per minibatch, no persistent pass)
+                    _dist.connect_peers(engine)  # in-kernel exchange for the persistent passes
                 engine.set_data(Xl, y[lo:hi])
             else:
                 # (concurrent fits on one data set attach to ONE device image of it)

@@ -243,8 +243,6 @@ def test_validation_errors_raised_before_any_device_work():
         SparseFactorizationMachineRegressor(solver="nope").fit(X, y)
     with pytest.raises(TypeError, match="Only binary targets supported"):
         SparseFactorizationMachineClassifier().fit(X, y)
-    with pytest.raises(ValueError, match="distributed=False"):
-        SparseFactorizationMachineRegressor(solver="psgd", distributed=True).fit(X, y)
 
 
 def test_row_block_partition():

@@ -235,3 +235,161 @@ def test_estimator_distributed_flag_two_ranks_one_gpu():
     np.testing.assert_allclose(got[0]["P"], one.P_, rtol=0, atol=1e-10)
     np.testing.assert_allclose(got[0]["w"], one.w_, rtol=0, atol=1e-10)
     assert got[0]["n_iter"] == one.n_iter_
+
+
+# ------------------------------------------------------------------ psgd, rows sharded
+PSGD_CASES = {
+    # tag: regularizer, degree, k, loss, batch_size, fit_lower (explicit: two orders of P)
+    "l1_d2": ("l1", 2, 6, "squared", 64, None),
+    "sql12_d3": ("squaredl12", 3, 4, "logistic", 100, "explicit"),
+    "l21_ragged": ("l21", 2, 5, "squared", 4999, None),   # a short last minibatch (1001 rows)
+    "sql21_tiny": ("squaredl21", 2, 4, "squared", 3, None),  # minibatches with no row of a rank
+}
+
+
+def _run_psgd(case, world, rank, shm_name):
+    """One rank of a sharded psgd run (spfm_psgd_epoch_sharded): every rank gets the global
+    visiting order, forms the gradient of its own rows of each minibatch; the gradients are
+    all-reduced through the host communicator.  world == 1: spfm_psgd_epoch."""
+    sys.path.insert(0, ROOT)
+    from sparsepoly_amd.engine import HipEngine, canonical_csc
+
+    reg, degree, k, loss, bs, fit_lower = PSGD_CASES[case]
+    X, y = _problem(loss)
+    n, d = X.shape
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    eng = HipEngine(0, "f64")
+    if world > 1:
+        eng.comm_init_shm(shm_name, world, rank)
+    eng.set_data(canonical_csc(X[lo:hi]), y[lo:hi])
+    n_orders = degree - 1 if fit_lower == "explicit" else 1
+    P0 = 0.01 * np.random.RandomState(0).randn(n_orders, k, d)
+    eng.set_params(P0, np.zeros(d), np.ones(k))
+    eng.configure("psgd", loss, reg, degree)
+    rng = np.random.RandomState(5)
+    order = np.arange(n, dtype=np.int32)
+    it, losses = 1, []
+    for _ in range(3):
+        rng.shuffle(order)
+        sl, it = eng.psgd_epoch(degree, 1e-3, 1e-2, 1e-3, 0.05, "optimal", 1.0, bs, order, True, it,
+                                row_lo=lo if world > 1 else None)
+        losses.append(sl)
+    P, w = eng.get_params()
+    eng.close()
+    return dict(P=P, w=w, loss=np.array(losses), it=it)
+
+
+def _psgd_worker(case, world, rank, shm_name, q):
+    try:
+        q.put((rank, _run_psgd(case, world, rank, shm_name)))
+    except Exception as e:
+        q.put((rank, repr(e)))
+
+
+@pytest.mark.parametrize("case", sorted(PSGD_CASES))
+def test_psgd_two_row_shards_on_one_gpu(case):
+    """Data-parallel psgd (the reference's minibatch loop, psgd.py:125-199, with the minibatch
+    gradient summed over the ranks): replicated parameters bit-identical on both ranks, equal to
+    the one-rank run up to the order of the gradient sums, and to the oracle."""
+    reg, degree, k, loss, bs, fit_lower = PSGD_CASES[case]
+    shm_name = "/spfm_test_%d_psgd_%s" % (os.getpid(), case)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_psgd_worker, args=(case, 2, r, shm_name, q)) for r in (0, 1)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in procs:
+            rank, res = q.get(timeout=240)
+            got[rank] = res
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+        try:
+            os.unlink("/dev/shm" + shm_name)
+        except OSError:
+            pass
+    for r in (0, 1):
+        assert isinstance(got[r], dict), got[r]
+    a, b = got[0], got[1]
+    assert np.array_equal(a["P"], b["P"]) and np.array_equal(a["w"], b["w"])
+    assert np.array_equal(a["loss"], b["loss"]) and a["it"] == b["it"]
+    one = _run_psgd(case, 1, 0, None)
+    assert a["it"] == one["it"]
+    np.testing.assert_allclose(a["P"], one["P"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(a["w"], one["w"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(a["loss"], one["loss"], rtol=1e-10)
+    assert np.abs(a["P"]).max() > 0
+
+
+def _psgd_est_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import warnings
+
+        import torch.distributed as dist
+
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPFM_COMM="shm")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from sparsepoly_amd import SparseFactorizationMachineRegressor
+
+        X, y = _problem("squared")
+        est = SparseFactorizationMachineRegressor(
+            degree=2, n_components=5, solver="psgd", regularizer="squaredl12", alpha=1e-3,
+            beta=1e-2, gamma=1e-3, max_iter=3, tol=-1, n_iter_no_change=100, batch_size=128,
+            eta0=0.05, shuffle=True, random_state=0, precision="f64", device=0, distributed=True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            est.fit(X, y)
+        q.put((rank, dict(P=est.P_, w=est.w_, it=est.it_, n_iter=est.n_iter_)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, repr(e)))
+
+
+def test_psgd_estimator_distributed_two_ranks_one_gpu():
+    """solver='psgd' with distributed=True through the estimator (two gloo ranks, host
+    communicator): same model on both ranks, equal to the one-GPU fit."""
+    import socket
+    import warnings
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_psgd_est_worker, args=(r, 2, port, q)) for r in (0, 1)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in procs:
+            rank, res = q.get(timeout=240)
+            got[rank] = res
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for r in (0, 1):
+        assert isinstance(got[r], dict), got[r]
+    assert np.array_equal(got[0]["P"], got[1]["P"]) and np.array_equal(got[0]["w"], got[1]["w"])
+    sys.path.insert(0, ROOT)
+    from sparsepoly_amd import SparseFactorizationMachineRegressor
+
+    X, y = _problem("squared")
+    one = SparseFactorizationMachineRegressor(
+        degree=2, n_components=5, solver="psgd", regularizer="squaredl12", alpha=1e-3,
+        beta=1e-2, gamma=1e-3, max_iter=3, tol=-1, n_iter_no_change=100, batch_size=128,
+        eta0=0.05, shuffle=True, random_state=0, precision="f64", device=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        one.fit(X, y)
+    np.testing.assert_allclose(got[0]["P"], one.P_, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(got[0]["w"], one.w_, rtol=0, atol=1e-10)
+    assert (got[0]["it"], got[0]["n_iter"]) == (one.it_, one.n_iter_)

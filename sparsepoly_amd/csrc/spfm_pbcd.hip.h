@@ -351,12 +351,9 @@ __device__ __forceinline__ bool pbcd_chain_fast2_chunk(int lane, int cnt, bool v
     const double dc2 = cb - njl;  // dcache[2] (omegacs) / dcache (squaredl21)
     // cache[2] += dcache[2] * l2n - dcache[2] * n_j per column (omegacs.py:71-73)
     double c2term = (valid && reg == REG_OMEGACS) ? (dc2 * l2n - dc2 * njl) : 0.0;
-    double c2pre = c2term;  // inclusive prefix sum
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const double v = __shfl_up(c2pre, o, kWave);
-        if (lane >= o) c2pre += v;
-    }
+    // inclusive prefix sum (DPP moves: __shfl_up is an LDS-crossbar round trip per step, and this
+    // chain runs in every workgroup on every step's critical path)
+    const double c2pre = dpp_prefix_sum_inclusive(c2term);
     const double c_after = al * c0 + be;  // cache after this column
     const bool trouble = valid && ((dc2 < 0) || (c_after < 0) ||
                                    (reg == REG_OMEGACS && c2acc + c2pre < 0));

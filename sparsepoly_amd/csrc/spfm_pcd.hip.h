@@ -318,6 +318,21 @@ __device__ __forceinline__ void affine_scan_inclusive(double& al, double& be, in
     affine_scan_step<0x143, 0xc>(al, be);  // row_bcast:31 into rows 2 and 3
 }
 
+// inclusive prefix sum over the wave with the same DPP moves (a lane without a source adds 0)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void sum_scan_step(double& v) {
+    v += dpp_move_d<CTRL, ROW_MASK>(0.0, v);
+}
+__device__ __forceinline__ double dpp_prefix_sum_inclusive(double v) {
+    sum_scan_step<0x111, 0xf>(v);  // row_shr:1
+    sum_scan_step<0x112, 0xf>(v);  // row_shr:2
+    sum_scan_step<0x114, 0xf>(v);  // row_shr:4
+    sum_scan_step<0x118, 0xf>(v);  // row_shr:8
+    sum_scan_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    sum_scan_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // value of the cache in front of column `lane` given c0 and the inclusive scan
 __device__ __forceinline__ double affine_before(double al_inc, double be_inc, double c0, int /*lane*/) {
     const double pa = dpp_move_d<0x138, 0xf>(0.0, al_inc);  // wave_shr:1; lane 0: x -> c0

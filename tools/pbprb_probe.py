@@ -20,7 +20,7 @@ reg = os.environ.get("SPFM_REG", "omegacs")
 X, y = make_problem(n, d, 50, 0)
 Xc = X.tocsc()
 Xc.sort_indices()
-k = 30
+k = int(os.environ.get("PB_K", 30))
 PHASES = ["p0 shared rows+wait", "p1 late sums+publish", "p2 owner poll", "p2 barrier+step+publish",
           "prefetch issue", "p3 collect poll", "p4 chain+barrier", "p5 scatter", "rotate+end barrier",
           "p3 barrier", "CR: replay set-up + earlier-column terms", "CR: rounds"]
@@ -42,7 +42,7 @@ for G in groups:
         for _ in range(reps):
             v.append(eng.pbcd_epoch(0, 2, 1.0, 1e-3, 1.0))
         dt = (time.perf_counter() - t0) / reps
-        out = dict(G=G, stamps=stamps, reg=reg, balance=int(os.environ.get("PB_BALANCE", 1)),
+        out = dict(G=G, k=k, stamps=stamps, reg=reg, balance=int(os.environ.get("PB_BALANCE", 1)),
                    ms_per_pbcd_epoch=round(dt * 1e3, 2),
                    steps=eng.n_batches, us_per_step=round(dt * 1e6 / eng.n_batches, 3),
                    active=eng.get_option("pbprb_active"), viol=[round(float(x), 3) for x in v])

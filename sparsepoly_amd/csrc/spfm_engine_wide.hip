@@ -111,6 +111,7 @@ PcdwArgs spfm_engine::wide_args() {
     a.slabA = w_slabA.as<double>();
     a.slabB = w_slabB.as<double>();
     a.rows_per = (int)std::max<int64_t>((n + wide_G - 1) / wide_G, 1);
+    a.lds_rows = 0;
     a.n_rows = (int)n;
     a.abort_flag = prb_abort.as<unsigned>();
     a.spin_max = spin_max;
@@ -127,8 +128,22 @@ int spfm_engine::wide_launch(PcdwArgs& a, PcdwParams& pp, T* Aptr) {
     HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
     constexpr bool can_lr = std::is_same<T, float>::value;
     const size_t lds_lr = kPcdwLdsFixed + (size_t)a.rows_per * (KIND == 0 ? 8 : 4) + 16;
-    const bool use_lr = can_lr && prb_lds && loss == SPFM_LOSS_SQUARED && lds_lr <= (size_t)lds_max;
-    wide_lr_active = use_lr ? 1 : 0;
+    const bool lr_ok = can_lr && prb_lds && loss == SPFM_LOSS_SQUARED;
+    const bool use_lr = lr_ok && lds_lr <= (size_t)lds_max && wide_lds_cap < 0;
+    // the block does not fit: its first rows in LDS, the others in global memory (LR = 2) -- when
+    // at least an eighth of the block gets a place (option "wide_lds_rows": -1 as many as fit,
+    // 0 none, n > 0 at most n -- the test hook that makes small problems take this path)
+    int hyb_rows = 0;
+    if (lr_ok && !use_lr && wide_lds_cap != 0 && !wide_stamp_on) {
+        const size_t room = (size_t)lds_max > kPcdwLdsFixed + 64 ? (size_t)lds_max - kPcdwLdsFixed - 64 : 0;
+        hyb_rows = (int)std::min<size_t>(room / (KIND == 0 ? 8 : 4), (size_t)a.rows_per);
+        if (wide_lds_cap > 0) hyb_rows = std::min(hyb_rows, wide_lds_cap);
+        else if (hyb_rows * 8 < a.rows_per) hyb_rows = 0;
+    }
+    const bool use_hyb = hyb_rows > 0;
+    a.lds_rows = use_hyb ? hyb_rows : 0;
+    const size_t lds_hyb = kPcdwLdsFixed + (size_t)hyb_rows * (KIND == 0 ? 8 : 4) + 16;
+    wide_lr_active = use_lr ? 1 : (use_hyb ? 2 : 0);
     HIPC(hipMemsetAsync(w_slabA.p, 0, w_slabA.bytes, stream));
     HIPC(hipMemsetAsync(w_slabB.p, 0, w_slabB.bytes, stream));
     {
@@ -178,6 +193,11 @@ int spfm_engine::wide_launch(PcdwArgs& a, PcdwParams& pp, T* Aptr) {
     }
     if constexpr (can_lr) {
         if (use_lr) return fire(&pcdw_kernel<T, KIND, 1>, std::max(lds_lr, kPrbLds));
+        if (use_hyb) {
+            int hrc = fire(&pcdw_kernel<T, KIND, 2>, std::max(lds_hyb, kPrbLds));
+            if (hrc) return hrc;
+            return unpack();
+        }
     }
     int frc = fire(&pcdw_kernel<T, KIND, 0>, kPrbLds);
     if (frc) return frc;

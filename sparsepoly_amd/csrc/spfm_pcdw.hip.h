@@ -32,6 +32,10 @@ namespace spfm {
 // residual) (LR = 1, as in pcd_prb_kernel).  Pipeline for LR = 0: a thread's entries (row, x)
 // are loaded two steps ahead, the row state of the next step's entries one step ahead, except
 // rows the current step updates (host flag), which are read after the end-of-step barrier.
+// LR = 2 (round 4; a block too large for LDS, float storage, squared loss -- BASELINE configs[4]
+// on one GPU): the first `lds_rows` rows of the block live in LDS in the residual form, the rest
+// in global memory; the pipeline is LR = 0's, an entry's row state comes from wherever its row
+// lives (the pass is bound by the CU's outstanding misses: every row in LDS is a miss less).
 
 struct PcdwArgs {
     int G;                  // workgroups
@@ -45,6 +49,7 @@ struct PcdwArgs {
     double* slabA;          // [2][32][G][32] partial vectors
     double* slabB;          // [2][32][32]    totals
     int rows_per, n_rows;
+    int lds_rows;           // LR = 2: rows of a block kept in LDS (its first ones)
     unsigned* abort_flag;
     unsigned spin_max;     // polls of one wait before the pass gives up (default 2^21)
     int n_ranks, rank;
@@ -141,15 +146,17 @@ struct PcdwSet {  // a thread's entries of one step: [e0, e0 + cnt), the first k
 };
 
 // KIND 0: pcd component pass (degree 2), 1: cd_linear epoch.  LR 0: rows in global memory,
-// 1: (A[i], residual) in LDS (float storage, squared loss).
+// 1: (A[i], residual) in LDS (float storage, squared loss), 2: the first lds_rows rows of the
+// block in LDS like 1, the others in global memory like 0.
 template <typename T, int KIND, int LR, bool STAMP = false>
 __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwParams pp,
                                                             const T* __restrict__ eval,
                                                             T* __restrict__ A_all,
                                                             T* __restrict__ yy,
                                                             PcdwRec<T>* __restrict__ rec) {
-    // KIND 0, LR 0: the rows live in `rec` (packed records); every other variant ignores it
-    constexpr bool PACKED = (KIND == 0 && LR == 0);
+    // KIND 0, rows (also) in global memory: they live in `rec` (packed records)
+    constexpr bool PACKED = (KIND == 0 && LR != 1);
+    constexpr bool HYB = (LR == 2);
     static_assert(LR == 0 || sizeof(T) == 4, "LDS-resident rows: float storage");
     constexpr int NG = 16, L = 32, EPT = kPcdwEPT;
     using Set = PcdwSet<T>;
@@ -161,8 +168,9 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
     int* sh_bad = reinterpret_cast<int*>(sh_delta + 16);
     double* sh_pold = sh_delta + 512;        // [512]
     int* sh_ok = reinterpret_cast<int*>(sh_pold + 512);
-    T* lds_a = reinterpret_cast<T*>(sh_ok + 4);  // LR: [rows_per] A[i] (pcd)
-    T* lds_r = lds_a + (KIND == 0 ? a.rows_per : 0);  // LR: [rows_per] residual
+    const int lds_n = HYB ? a.lds_rows : a.rows_per;  // rows of the block that live in LDS
+    T* lds_a = reinterpret_cast<T*>(sh_ok + 4);  // LR: [lds_n] A[i] (pcd)
+    T* lds_r = lds_a + (KIND == 0 ? lds_n : 0);  // LR: [lds_n] residual
     const typename Vec2<T>::type* yy2 = reinterpret_cast<const typename Vec2<T>::type*>(yy);
     const int g = blockIdx.x, tid = threadIdx.x;
     const int lane = tid % L, grp = tid / L, wlane = tid & 63, wave = tid >> 6;
@@ -188,13 +196,23 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
         }                                   \
     }
     if constexpr (LR != 0) {  // row block -> LDS (residual form: dloss = yhat - y)
-        const int nr = min(a.rows_per, a.n_rows - row0);
+        const int nr = min(lds_n, a.n_rows - row0);
         for (int il = tid; il < nr; il += kPcdwThreads) {
-            const typename Vec2<T>::type yv = yy2[(size_t)(row0 + il)];
-            if constexpr (KIND == 0) lds_a[il] = A[(size_t)(row0 + il)];
-            lds_r[il] = (T)((double)yv.x - (double)yv.y);
+            if constexpr (HYB && KIND == 0) {  // (the pass's rows were packed into records)
+                const PcdwRec<T> r = rec[(size_t)(row0 + il)];
+                lds_a[il] = r.a;
+                lds_r[il] = (T)((double)r.yh - (double)r.y);
+            } else {
+                const typename Vec2<T>::type yv = yy2[(size_t)(row0 + il)];
+                if constexpr (KIND == 0) lds_a[il] = A[(size_t)(row0 + il)];
+                lds_r[il] = (T)((double)yv.x - (double)yv.y);
+            }
         }
     }
+    // LR = 2: does row i of this workgroup's block live in LDS?
+    auto in_lds = [&](int i) __attribute__((always_inline)) -> bool {
+        return (unsigned)(i - row0) < (unsigned)lds_n;
+    };
 
     auto bounds = [&](int b, int qq, int ncols_b, int& e0, int& e1) __attribute__((always_inline)) {
         e0 = 0;
@@ -222,6 +240,14 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
         for (int u = 0; u < EPT; ++u) {
             if (u < s.cnt && (int)((unsigned)s.row[u] >> 31) == hz) {
                 const size_t i = (size_t)(s.row[u] & 0x7fffffff);
+                if constexpr (HYB) {
+                    if (in_lds((int)i)) {  // (r, 0): dloss = r
+                        yh[u] = lds_r[(int)i - row0];
+                        yt[u] = (T)0;
+                        if constexpr (KIND == 0) av[u] = lds_a[(int)i - row0];
+                        continue;
+                    }
+                }
                 if constexpr (PACKED) {
                     const PcdwRec<T> r = rec[i];
                     yh[u] = r.yh;
@@ -252,7 +278,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
         load_entries(nxt, e0, e1);
         bounds(2, q, c3 - c2, b2e0, b2e1);
         nn = nxt;
-        if constexpr (LR == 0) load_rows(cur, av, yh, yt, 0);
+        if constexpr (LR != 1) load_rows(cur, av, yh, yt, 0);
     }
     double s0 = (q < c1 - c0) ? pp.sched0[c0 + q] : 0.0, s0n = 0.0;  // p_old / w of the slot
     double s1 = (KIND == 1 && q < c1 - c0) ? pp.sched1[c0 + q] : 0.0, s1n = 0.0;
@@ -271,8 +297,8 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
         // Everything loaded in the previous step has landed by now; a real S_WAITCNT tells the
         // compiler so (see pbcd_prb_kernel), else the prefetch block below stalls on its own loads
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        // ---- phase 0 (LR = 0): rows this step shares with the previous one
-        if constexpr (LR == 0) load_rows(cur, av, yh, yt, 1);
+        // ---- phase 0 (LR = 0 / 2): rows this step shares with the previous one
+        if constexpr (LR != 1) load_rows(cur, av, yh, yt, 1);
         PW_STAMP(0)  // hazard rows
         // ---- phase 1: the thread's column: partial sums over the block's rows (pcd.py:52-59,
         // cd_linear.py:15-18)
@@ -283,7 +309,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
             for (int u = 0; u < EPT; ++u) {
                 if (u < nfast) {
                     double y0, y1, a1 = 0.0;
-                    if constexpr (LR != 0) {
+                    if constexpr (LR == 1) {
                         const int il = (cur.row[u] & 0x7fffffff) - row0;
                         y0 = (double)lds_r[il];
                         y1 = 0.0;
@@ -308,7 +334,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
                 const int i = a.erow[cur.e0 + u] & 0x7fffffff;
                 const double x = (double)eval[cur.e0 + u];
                 double y0, y1, a1 = 0.0;
-                if constexpr (LR != 0) {
+                if (LR == 1 || (HYB && in_lds(i))) {
                     y0 = (double)lds_r[i - row0];
                     y1 = 0.0;
                     if constexpr (KIND == 0) a1 = (double)lds_a[i - row0];
@@ -429,7 +455,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
         // conservative about loads that are pending across the loop's back edge -- puts a full
         // vmcnt(0) in front of that use; issued behind this step's (cold, streaming) entry loads
         // it would wait for those too.  So: rows first, the entry stream last.
-        if constexpr (LR == 0) load_rows(nxt, avn, yhn, ytn, 0);
+        if constexpr (LR != 1) load_rows(nxt, avn, yhn, ytn, 0);
         s0n = (q < c2 - c1) ? pp.sched0[c1 + q] : 0.0;
         if constexpr (KIND == 1) s1n = (q < c2 - c1) ? pp.sched1[c1 + q] : 0.0;
         int jmine = 0;  // workgroup 0 writes the parameters
@@ -516,7 +542,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
                 if (u < nfast) {
                     const int i = cur.row[u] & 0x7fffffff;
                     const double x = (double)cur.x[u];
-                    if constexpr (LR != 0) {
+                    if constexpr (LR == 1) {
                         const int il = i - row0;
                         if constexpr (KIND == 0) {
                             const double a1 = (double)lds_a[il];
@@ -525,6 +551,16 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
                             lds_r[il] = (T)((double)lds_r[il] - lam * delta * dprev);
                         } else {
                             lds_r[il] = (T)((double)lds_r[il] - delta * x);
+                        }
+                    } else if (HYB && in_lds(i)) {  // the row's state is in registers (r, 0, A)
+                        const int il = i - row0;
+                        if constexpr (KIND == 0) {
+                            const double a1 = (double)av[u];
+                            const double dprev = x * (a1 - s0 * x);
+                            lds_a[il] = (T)(a1 - delta * x);
+                            lds_r[il] = (T)((double)yh[u] - lam * delta * dprev);
+                        } else {
+                            lds_r[il] = (T)((double)yh[u] - delta * x);
                         }
                     } else {
                         if constexpr (PACKED) {
@@ -550,7 +586,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
             for (int u = EPT; u < cur.cnt; ++u) {
                 const int i = a.erow[cur.e0 + u] & 0x7fffffff;
                 const double x = (double)eval[cur.e0 + u];
-                if constexpr (LR != 0) {
+                if (LR == 1 || (HYB && in_lds(i))) {
                     const int il = i - row0;
                     if constexpr (KIND == 0) {
                         const double a1 = (double)lds_a[il];
@@ -598,7 +634,7 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
         c1 = c2;
         c2 = c3;
         c3 = c4;
-        if constexpr (LR != 0)  // rows in LDS: only LDS traffic has to land
+        if constexpr (LR == 1)  // all rows in LDS: only LDS traffic has to land
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else
             __syncthreads();  // rows move between threads from step to step (stores drained)
@@ -611,11 +647,18 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdw_kernel(PcdwArgs a, PcdwPara
     }
     if constexpr (LR != 0) {  // write the row block back (yhat = r + y)
         __syncthreads();
-        const int nr = min(a.rows_per, a.n_rows - row0);
+        const int nr = min(lds_n, a.n_rows - row0);
         for (int il = tid; il < nr; il += kPcdwThreads) {
             const size_t i = (size_t)(row0 + il);
-            if constexpr (KIND == 0) A[i] = lds_a[il];
-            yy[2 * i] = (T)((double)lds_r[il] + (double)yy[2 * i + 1]);
+            if constexpr (HYB && KIND == 0) {  // into the records (unpacked behind the pass)
+                PcdwRec<T> r = rec[i];
+                r.yh = (T)((double)lds_r[il] + (double)r.y);
+                r.a = lds_a[il];
+                rec[i] = r;
+            } else {
+                if constexpr (KIND == 0) A[i] = lds_a[il];
+                yy[2 * i] = (T)((double)lds_r[il] + (double)yy[2 * i + 1]);
+            }
         }
     }
 }
@@ -635,7 +678,7 @@ __global__ void pcdw_gather_kernel(int64_t nnz, const int32_t* __restrict__ src,
     }
 }
 
-// dynamic LDS of the fixed part (bytes); LR adds rows_per * (KIND == 0 ? 8 : 4)
+// dynamic LDS of the fixed part (bytes); LR adds (rows in LDS) * (KIND == 0 ? 8 : 4)
 constexpr size_t kPcdwLdsFixed = sizeof(double) * (2 * 16 * 32 + 1024 + 512 + 512) + 16;
 
 }  // namespace spfm

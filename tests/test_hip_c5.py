@@ -5,7 +5,8 @@ class (~364 columns) as ONE dependent step run the same cd_linear epoch + 2 comp
 order (f32 storage tolerances):
 
 * the library's DEFAULT for this workload: the wide persistent pass (`pcdw_kernel`, steps of up to
-  512 columns, rows as packed records in global memory -- 10M rows do not fit LDS);
+  512 columns; 10M rows do not fit LDS: the first 45 % of every row block live there, the others
+  as packed records in global memory);
 * the multi-kernel engine (`persistent=0`: three launches per step).
 
 Also: steps per sweep = number of colours (~2 750), and the incrementally
@@ -39,9 +40,9 @@ def test_config5_full_size_single_gpu(oracle):
             "multi-kernel": bench_c5.run_engine(Xc, y, P0, 2, {"persistent": 0}, reps=0)}
     wide = runs["default (wide persistent pass)"]["info"]
     if full:
-        # the engine the library selects for this workload is the wide pass with its rows in
-        # global memory, and a colour class is one step
-        assert wide["wide_active"] == 1 and wide["wide_rows_in_lds"] == 0, wide
+        # the engine the library selects for this workload is the wide pass -- the blocks' first
+        # rows in LDS (all that fit), the others in global memory -- and a colour class is one step
+        assert wide["wide_active"] == 1 and wide["wide_rows_in_lds"] == 2, wide
         assert runs["multi-kernel"]["info"]["persistent"] == 0
     refs = []  # (order, oracle result): one oracle run per distinct order (normally one)
     for name, r in runs.items():

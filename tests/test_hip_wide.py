@@ -98,6 +98,41 @@ def test_wide_pass_f32_lds_rows_and_narrow_engine():
     assert n["wide"] == 0 and n["max_step"] <= 64 and n["steps"] > a["steps"]
 
 
+@pytest.mark.parametrize("lds_rows", [1, 7, 40])
+@pytest.mark.parametrize("groups", [None, 5])
+def test_wide_pass_first_rows_of_a_block_in_lds(oracle, lds_rows, groups):
+    """LR = 2 (a row block too large for LDS -- BASELINE configs[4] on one GPU): the first
+    `wide_lds_rows` rows of every block live in LDS (residual form), the others in global memory;
+    an entry's row state comes from wherever its row lives.  The option caps the LDS rows so that a
+    small problem takes the path.  With zero targets the residual IS the prediction, so the three
+    forms (mixed, all global, all LDS) run the same arithmetic on the same floats: bit-identical.
+    With real targets: equal to float rounding, and to the oracle."""
+    X, y = _problem("squared")
+    opts = {} if groups is None else {"pcdw_groups": groups}
+    for yy, exact in ((np.zeros_like(y), True), (y, False)):
+        hyb = _run(X, yy, "squared", "squaredl12", "f32", dict(opts, wide_lds_rows=lds_rows))
+        glob = _run(X, yy, "squared", "squaredl12", "f32", dict(opts, prb_lds=0))
+        lds = _run(X, yy, "squared", "squaredl12", "f32", opts)
+        assert (hyb["lds"], glob["lds"], lds["lds"]) == (2, 0, 1)
+        assert np.abs(hyb["P"] - hyb["P0"]).max() > 1e-4  # it trained
+        for r in (glob, lds):
+            np.testing.assert_array_equal(hyb["order"], r["order"])
+            if exact:
+                for key in ("P", "w", "viol", "y_pred"):
+                    np.testing.assert_array_equal(hyb[key], r[key], err_msg=key)
+            else:
+                np.testing.assert_allclose(hyb["viol"], r["viol"], rtol=2e-5)
+                np.testing.assert_allclose(hyb["P"], r["P"], rtol=0, atol=2e-5)
+                np.testing.assert_allclose(hyb["y_pred"], r["y_pred"], rtol=0, atol=2e-4)
+    k = 5
+    fm = oracle.OracleFM(degree=2, loss="squared", n_components=k, solver="pcd",
+                         regularizer="squaredl12", alpha=0.5, beta=10.0, gamma=1e-3, tol=0,
+                         max_iter=2, fit_linear=True, feature_order=hyb["order"])
+    fm.fit(X, y, P_init=hyb["P0"], lams_init=np.where(np.arange(k) % 2 == 0, 1.0, -1.0))
+    np.testing.assert_allclose(hyb["viol"], [h[0] for h in fm.history], rtol=2e-5)
+    np.testing.assert_allclose(hyb["P"], fm.P_, rtol=0, atol=1e-4)
+
+
 def test_moderately_wide_classes_run_as_64_column_steps(oracle):
     """Mean class width below the threshold (`wide_min_cols` = 110 columns when the 64-column pass
     keeps its rows in LDS, 0.72 x that otherwise -- double storage here): the engine colours again
@@ -121,21 +156,29 @@ def test_moderately_wide_classes_run_as_64_column_steps(oracle):
 
 
 
-@pytest.mark.parametrize("precision,groups", [("f64", 4), ("f32", 4), ("f32", 2), ("f64", 256)])
-def test_wide_pass_many_entries_per_thread_rows_in_global_memory(oracle, precision, groups):
+@pytest.mark.parametrize("precision,groups,lds_rows",
+                         [("f64", 4, -1), ("f32", 4, 0), ("f32", 2, 0), ("f64", 256, -1),
+                          ("f32", 4, -1), ("f32", 2, -1)])
+def test_wide_pass_many_entries_per_thread_rows_in_global_memory(oracle, precision, groups, lds_rows):
     """The memory path of the wide pass that BASELINE configs[4] takes at 10M rows, at a size the
     oracle replays in a second: 240k x 16k with 60-entry columns and few row blocks, so a thread
     (= one column slot of one row block) holds 15 (4 blocks) / 30 (2 blocks) entries per step --
     more than the `kPcdwEPT` = 8 it keeps in registers, the rest goes through the two dependent
     global loads in the gradient and again in the scatter -- and a workgroup gathers ~5 000 /
     ~10 000 rows per step (config 5: 430).  The row blocks (60k rows and more) do not fit LDS:
-    packed 16-byte row records in global memory (float) / `yy` + `A` (double).  Classes hold up
+    packed 16-byte row records in global memory (float; with the blocks' first rows in LDS when
+    the library chooses) / `yy` + `A` (double).  Classes hold up
     to 477 columns.  256 blocks: the register path on the same matrix.  Against the oracle in the
     reported order (pcd.py:97-135, cd_linear.py:8-33)."""
     X, y = _problem("squared", n=240_000, d=16_000, per_row=4, seed=5)
     k = 3
-    r = _run(X, y, "squared", "squaredl12", precision, {"pcdw_groups": groups}, k=k)
-    assert r["wide"] == 1 and r["lds"] == 0 and 256 < r["max_step"] <= 512, \
+    r = _run(X, y, "squared", "squaredl12", precision,
+             {"pcdw_groups": groups, "wide_lds_rows": lds_rows}, k=k)
+    # float storage, squared loss: the library's own choice (wide_lds_rows = -1) keeps the first
+    # ~17k rows of every block in LDS (mode 2) -- entries beyond the registers then take the
+    # mixed path too; 0 keeps every row in global memory
+    want = 2 if (precision == "f32" and lds_rows != 0) else 0
+    assert r["wide"] == 1 and r["lds"] == want and 256 < r["max_step"] <= 512, \
         (r["wide"], r["lds"], r["max_step"])
     col_len = np.diff(X.tocsc().indptr)
     if groups <= 4:

@@ -297,6 +297,8 @@ struct spfm_engine {
     int wide_G = 0, wide_tot = 0;
     int wide_lr_active = 0;  // what the last wide pass used: 0 global rows, 1 all rows in LDS, 2 the first rows of a block in LDS
     int wide_lds_cap = -1;   // option "wide_lds_rows" (see wide_launch)
+    bool wide_ep = true;     // option "wide_ep": rows (also) in global memory -> entry-parallel form
+    int wide_ep_active = 0;  // what the last wide pass used
     DevBuf w_wbase, w_wsp, w_erow, w_eval, w_slabA, w_slabB;
     // persistent pbcd pass (spfm_pbprb.hip.h): its own workgroup count, hence its own entry
     // stream when that differs from the pcd / cd_linear pass's

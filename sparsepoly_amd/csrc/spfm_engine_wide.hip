@@ -19,7 +19,7 @@ int spfm_engine::wide_groups(int ncu, size_t lds_max) const {
         g = (int)std::min<int64_t>(ncu, std::max<int64_t>(64, ((per_step / 160 + 15) / 16) * 16));
         auto fits = [&](int gg) {
             const size_t rows_per = ((size_t)n + (size_t)gg - 1) / (size_t)gg;
-            return kPcdwLdsFixed + rows_per * 8 + 16 <= lds_max;
+            return (wide_ep ? kPcdweLdsFixed : kPcdwLdsFixed) + rows_per * 8 + 16 <= lds_max;
         };
         if (!fits(g) && fits(ncu))
             while (g < ncu && !fits(g)) g = std::min(ncu, g + 16);
@@ -127,23 +127,27 @@ int spfm_engine::wide_launch(PcdwArgs& a, PcdwParams& pp, T* Aptr) {
     int lds_max = 0;
     HIPC(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
     constexpr bool can_lr = std::is_same<T, float>::value;
-    const size_t lds_lr = kPcdwLdsFixed + (size_t)a.rows_per * (KIND == 0 ? 8 : 4) + 16;
+    // the entry-parallel form (pcdwe_kernel; option "wide_ep" = 0: the thread-per-column form)
+    const bool use_ep = wide_ep;
+    const size_t fixed = use_ep ? kPcdweLdsFixed : kPcdwLdsFixed;
+    const size_t lds_lr = fixed + (size_t)a.rows_per * (KIND == 0 ? 8 : 4) + 16;
     const bool lr_ok = can_lr && prb_lds && loss == SPFM_LOSS_SQUARED;
     const bool use_lr = lr_ok && lds_lr <= (size_t)lds_max && wide_lds_cap < 0;
     // the block does not fit: its first rows in LDS, the others in global memory (LR = 2) -- when
     // at least an eighth of the block gets a place (option "wide_lds_rows": -1 as many as fit,
     // 0 none, n > 0 at most n -- the test hook that makes small problems take this path)
     int hyb_rows = 0;
-    if (lr_ok && !use_lr && wide_lds_cap != 0 && !wide_stamp_on) {
-        const size_t room = (size_t)lds_max > kPcdwLdsFixed + 64 ? (size_t)lds_max - kPcdwLdsFixed - 64 : 0;
+    if (lr_ok && !use_lr && wide_lds_cap != 0 && !(wide_stamp_on && !use_ep)) {
+        const size_t room = (size_t)lds_max > fixed + 64 ? (size_t)lds_max - fixed - 64 : 0;
         hyb_rows = (int)std::min<size_t>(room / (KIND == 0 ? 8 : 4), (size_t)a.rows_per);
         if (wide_lds_cap > 0) hyb_rows = std::min(hyb_rows, wide_lds_cap);
         else if (hyb_rows * 8 < a.rows_per) hyb_rows = 0;
     }
     const bool use_hyb = hyb_rows > 0;
     a.lds_rows = use_hyb ? hyb_rows : 0;
-    const size_t lds_hyb = kPcdwLdsFixed + (size_t)hyb_rows * (KIND == 0 ? 8 : 4) + 16;
+    const size_t lds_hyb = fixed + (size_t)hyb_rows * (KIND == 0 ? 8 : 4) + 16;
     wide_lr_active = use_lr ? 1 : (use_hyb ? 2 : 0);
+    wide_ep_active = use_ep ? 1 : 0;
     HIPC(hipMemsetAsync(w_slabA.p, 0, w_slabA.bytes, stream));
     HIPC(hipMemsetAsync(w_slabB.p, 0, w_slabB.bytes, stream));
     {
@@ -185,21 +189,28 @@ int spfm_engine::wide_launch(PcdwArgs& a, PcdwParams& pp, T* Aptr) {
             HIPC(hipMemsetAsync(wide_stamps.p, 0, wide_stamps.bytes, stream));
             a.stamps = wide_stamps.as<long long>();
             const size_t lds = use_lr ? std::max(lds_lr, kPrbLds) : kPrbLds;
-            int frc = use_lr ? fire(&pcdw_kernel<T, KIND, 1, true>, lds)
-                             : fire(&pcdw_kernel<T, KIND, 0, true>, lds);
+            int frc = use_lr ? (use_ep ? fire(&pcdwe_kernel<T, KIND, 1, true>, lds)
+                                       : fire(&pcdw_kernel<T, KIND, 1, true>, lds))
+                      : (use_ep ? (use_hyb ? fire(&pcdwe_kernel<T, KIND, 2, true>, std::max(lds_hyb, kPrbLds))
+                                           : fire(&pcdwe_kernel<T, KIND, 0, true>, std::max(fixed, kPrbLds)))
+                                : fire(&pcdw_kernel<T, KIND, 0, true>, lds));
             if (frc) return frc;
             return unpack();
         }
     }
     if constexpr (can_lr) {
-        if (use_lr) return fire(&pcdw_kernel<T, KIND, 1>, std::max(lds_lr, kPrbLds));
+        if (use_lr)
+            return use_ep ? fire(&pcdwe_kernel<T, KIND, 1>, std::max(lds_lr, kPrbLds))
+                          : fire(&pcdw_kernel<T, KIND, 1>, std::max(lds_lr, kPrbLds));
         if (use_hyb) {
-            int hrc = fire(&pcdw_kernel<T, KIND, 2>, std::max(lds_hyb, kPrbLds));
+            int hrc = use_ep ? fire(&pcdwe_kernel<T, KIND, 2>, std::max(lds_hyb, kPrbLds))
+                             : fire(&pcdw_kernel<T, KIND, 2>, std::max(lds_hyb, kPrbLds));
             if (hrc) return hrc;
             return unpack();
         }
     }
-    int frc = fire(&pcdw_kernel<T, KIND, 0>, kPrbLds);
+    int frc = use_ep ? fire(&pcdwe_kernel<T, KIND, 0>, std::max(fixed, kPrbLds))
+                     : fire(&pcdw_kernel<T, KIND, 0>, kPrbLds);
     if (frc) return frc;
     return unpack();
 }

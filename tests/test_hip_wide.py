@@ -69,7 +69,8 @@ def test_wide_pass_matches_oracle(oracle, loss, reg):
 
 
 @pytest.mark.parametrize("options", [{"pcdw_groups": 1}, {"pcdw_groups": 7}, {"pcdw_groups": 32},
-                                     {"pcdw_groups": 100}, {"prb_lds": 0}, {"persistent": 0}])
+                                     {"pcdw_groups": 100}, {"prb_lds": 0}, {"persistent": 0},
+                                     {"wide_ep": 0}, {"wide_ep": 0, "pcdw_groups": 7}])
 def test_wide_pass_engine_options(options):
     """Same schedule, other workgroup counts / row residency / the multi-kernel engine: results
     agree to reduction-order rounding.  float storage uses LDS rows for the squared loss."""
@@ -98,9 +99,10 @@ def test_wide_pass_f32_lds_rows_and_narrow_engine():
     assert n["wide"] == 0 and n["max_step"] <= 64 and n["steps"] > a["steps"]
 
 
+@pytest.mark.parametrize("ep", [1, 0])
 @pytest.mark.parametrize("lds_rows", [1, 7, 40])
 @pytest.mark.parametrize("groups", [None, 5])
-def test_wide_pass_first_rows_of_a_block_in_lds(oracle, lds_rows, groups):
+def test_wide_pass_first_rows_of_a_block_in_lds(oracle, lds_rows, groups, ep):
     """LR = 2 (a row block too large for LDS -- BASELINE configs[4] on one GPU): the first
     `wide_lds_rows` rows of every block live in LDS (residual form), the others in global memory;
     an entry's row state comes from wherever its row lives.  The option caps the LDS rows so that a
@@ -108,7 +110,7 @@ def test_wide_pass_first_rows_of_a_block_in_lds(oracle, lds_rows, groups):
     forms (mixed, all global, all LDS) run the same arithmetic on the same floats: bit-identical.
     With real targets: equal to float rounding, and to the oracle."""
     X, y = _problem("squared")
-    opts = {} if groups is None else {"pcdw_groups": groups}
+    opts = {"wide_ep": ep} if groups is None else {"pcdw_groups": groups, "wide_ep": ep}
     for yy, exact in ((np.zeros_like(y), True), (y, False)):
         hyb = _run(X, yy, "squared", "squaredl12", "f32", dict(opts, wide_lds_rows=lds_rows))
         glob = _run(X, yy, "squared", "squaredl12", "f32", dict(opts, prb_lds=0))
@@ -156,10 +158,12 @@ def test_moderately_wide_classes_run_as_64_column_steps(oracle):
 
 
 
+@pytest.mark.parametrize("ep", [1, 0])
 @pytest.mark.parametrize("precision,groups,lds_rows",
                          [("f64", 4, -1), ("f32", 4, 0), ("f32", 2, 0), ("f64", 256, -1),
                           ("f32", 4, -1), ("f32", 2, -1)])
-def test_wide_pass_many_entries_per_thread_rows_in_global_memory(oracle, precision, groups, lds_rows):
+def test_wide_pass_many_entries_per_thread_rows_in_global_memory(oracle, precision, groups, lds_rows,
+                                                                 ep):
     """The memory path of the wide pass that BASELINE configs[4] takes at 10M rows, at a size the
     oracle replays in a second: 240k x 16k with 60-entry columns and few row blocks, so a thread
     (= one column slot of one row block) holds 15 (4 blocks) / 30 (2 blocks) entries per step --
@@ -169,15 +173,19 @@ def test_wide_pass_many_entries_per_thread_rows_in_global_memory(oracle, precisi
     packed 16-byte row records in global memory (float; with the blocks' first rows in LDS when
     the library chooses) / `yy` + `A` (double).  Classes hold up
     to 477 columns.  256 blocks: the register path on the same matrix.  Against the oracle in the
-    reported order (pcd.py:97-135, cd_linear.py:8-33)."""
+    reported order (pcd.py:97-135, cd_linear.py:8-33).  ep = 1: the entry-parallel form
+    (pcdwe_kernel: 1 024 entries of a (workgroup, step) through its LDS table, the other thousands
+    walked by their slots' threads), ep = 0: the thread-per-column form (pcdw_kernel)."""
     X, y = _problem("squared", n=240_000, d=16_000, per_row=4, seed=5)
     k = 3
     r = _run(X, y, "squared", "squaredl12", precision,
-             {"pcdw_groups": groups, "wide_lds_rows": lds_rows}, k=k)
+             {"pcdw_groups": groups, "wide_lds_rows": lds_rows, "wide_ep": ep}, k=k)
     # float storage, squared loss: the library's own choice (wide_lds_rows = -1) keeps the first
     # ~17k rows of every block in LDS (mode 2) -- entries beyond the registers then take the
     # mixed path too; 0 keeps every row in global memory
     want = 2 if (precision == "f32" and lds_rows != 0) else 0
+    if want == 2 and groups == 2 and ep == 1:
+        want = 0  # (120k rows per block: less than an eighth of them would fit beside the tables)
     assert r["wide"] == 1 and r["lds"] == want and 256 < r["max_step"] <= 512, \
         (r["wide"], r["lds"], r["max_step"])
     col_len = np.diff(X.tocsc().indptr)
@@ -253,3 +261,38 @@ def test_forced_omegati_clip_inside_a_wide_step(oracle, pos_a, pos_b):
     np.testing.assert_allclose(P[0], Po, rtol=0, atol=1e-12)
     np.testing.assert_allclose(yp, ypo, rtol=0, atol=1e-12)
     assert P[0, 0, pos_a] == 0.0 and P[0, 0, pos_b] == 0.0
+
+
+def test_wide_pass_config5_block_shape_rows_partly_in_lds_is_deterministic():
+    """BASELINE configs[4]'s per-workgroup shape at an eighth of its size: 32 workgroups of 39 063
+    rows (312 KB as (A, residual): the blocks' first ~14k rows in LDS, the others in global
+    memory), wide classes, one cd_linear epoch
+    and three component passes.  The incrementally maintained prediction equals the recomputed
+    one on every row, two runs are bit-identical, and the entry-parallel form agrees with the
+    thread-per-column form to float rounding.  (Regression: the prologue read the LDS image of the
+    row block before all of it had been written -- a handful of rows per run, different ones each
+    time, only with blocks that fill the LDS.)"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "tools"))
+    import bench_c5
+
+    from sparsepoly_amd.synth import make_problem
+
+    X, y = make_problem(1_250_000, 250_000, 50, seed=0)  # 250-entry columns: classes of ~200
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    P0 = 0.01 * np.random.RandomState(0).randn(1, bench_c5.K, Xc.shape[1])
+    runs = [bench_c5.run_engine(Xc, y, P0, 3, dict(pcdw_groups=32, wide_min_cols=0, wide_ep=ep),
+                                reps=0) for ep in (1, 1, 0)]
+    for r in runs:
+        assert r["info"]["wide_active"] == 1 and r["info"]["wide_rows_in_lds"] == 2, r["info"]
+        scale = max(1.0, float(np.abs(r["y_recomputed"]).max()))
+        np.testing.assert_allclose(r["y_incremental"], r["y_recomputed"], rtol=0, atol=2e-4 * scale)
+    a, b, c = runs
+    for key in ("P", "w", "y_pred"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    np.testing.assert_allclose(a["v"], c["v"], rtol=1e-6)
+    np.testing.assert_allclose(a["P"], c["P"], rtol=0, atol=1e-5)

@@ -19,6 +19,9 @@ for stamps in (0, 1):
     eng = HipEngine(0, "f32")
     eng.set_option("pcdw_groups", G); eng.set_option("pcdw_stamps", stamps)
     eng.set_option("wide_min_cols", 0)  # the wide pass whatever the class width
+    for kv in os.environ.get("WIDE_OPTS", "").split(","):   # e.g. WIDE_OPTS=wide_lds_rows=0,wide_ep=0
+        if kv:
+            eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     eng.set_data(Xc, y)
     eng.set_params(0.01 * np.random.RandomState(0).randn(1, 30, d), np.zeros(d), np.ones(30))
     eng.configure("pcd", "squared", "squaredl12", 2); eng.init_pred(2, True, False)
@@ -33,10 +36,15 @@ for stamps in (0, 1):
         st = eng.debug_prb_stamps().astype(float)
         names = ["hazard rows", "sums+publish", "owner poll", "owner total+publish",
                  "prefetch issue", "collect poll", "barrier", "chain rounds", "scatter",
-                 "rotate+end barrier"]
+                 "rotate+end barrier", "(pf: row gathers)", "(pf: slot data, bounds)",
+                 "(pf: entry stream)"]
+        if st[:, 10:13].sum() == 0:
+            names = names[:10]
+        else:
+            names[4] = "(pf: slot table)"
         print("   cycles/step:           WG0      min     mean      max")
         for k in range(len(names)):
             print("   %-20s %8.0f %8.0f %8.0f %8.0f" % (names[k], st[0, k] / nb, st[:, k].min() / nb,
                                                       st[:, k].mean() / nb, st[:, k].max() / nb))
-        print("   total WG0 %.0f" % (st[0, :10].sum() / nb))
+        print("   total WG0 %.0f" % (st[0, :13].sum() / nb))
     eng.close()

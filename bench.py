@@ -479,7 +479,8 @@ class Bench(object):
                 # one launch = one component pass; per column entry: row 4 + value T + (yhat, y)
                 # read 2T + yhat write T + A[i,1..m-1] read and write 2T(m-1)
                 # (the wide pass -- steps of more than 64 columns, DESIGN 3d -- moves the same)
-                kname = "pcdw_kernel" if eng.get_option("wide_active") else "pcd_prb_kernel"
+                kname = (("pcdwe_kernel" if eng.get_option("wide_ep") else "pcdw_kernel")
+                         if eng.get_option("wide_active") else "pcd_prb_kernel")
                 bytes_per_nnz = 4 + 4 * tsz + 2 * tsz * (DEGREE - 1)
             else:
                 kname, bytes_per_nnz = "pcd_grad_kernel", 4 + 3 * tsz + tsz * (DEGREE - 1)
@@ -525,7 +526,9 @@ class Bench(object):
                 roof["us_per_dependent_step_in_kernel"] = round(avg_us / n_batches, 3)
                 if cfg["solver"] == "pcd":
                     # 0 = row state in global memory, 1 / 2 = row block in LDS
-                    roof["row_block_in_lds"] = int(eng.get_option("prb_lds_active"))
+                    # (wide pass: 2 = the blocks' first rows in LDS, the others in global memory)
+                    roof["row_block_in_lds"] = int(eng.get_option(
+                        "wide_lds_active" if eng.get_option("wide_active") else "prb_lds_active"))
         # what really ran: the ranks of the engine's communicator, the exchange it used, whether
         # a persistent pass had to be redone on the multi-kernel engine; per-rank set-up cost
         res = dict(

@@ -167,6 +167,49 @@ def test_two_row_shards_on_one_gpu(oracle, case, engine):
     np.testing.assert_allclose(a["viol"], [h[0] for h in fm.history], rtol=1e-9)
 
 
+def test_two_row_shards_wide_pass_float_rows_in_lds():
+    """The per-rank shape of BASELINE configs[4] on several GPUs: the wide pass in its
+    entry-parallel form with the shard's rows in LDS (float storage, squared loss) and the
+    cross-GPU stage of the vslot owners through the peer-mapped slabs.  Both ranks bit-identical;
+    equal to the one-rank float run up to the order of the partial sums and float rounding."""
+    case, engine = "pcd_wide", "persistent_peer"
+    shm_name = "/spfm_test_%d_wide_f32" % os.getpid()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    hq = [ctx.Queue(), ctx.Queue()]
+    procs = [ctx.Process(target=_worker, args=(case, 2, r, shm_name, "f32", q, engine, hq))
+             for r in (0, 1)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in procs:
+            rank, res = q.get(timeout=240)
+            got[rank] = res
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+        try:
+            os.unlink("/dev/shm" + shm_name)
+        except OSError:
+            pass
+    for r in (0, 1):
+        assert isinstance(got[r], dict), got[r]
+    a, b = got[0], got[1]
+    assert np.array_equal(a["P"], b["P"]) and np.array_equal(a["w"], b["w"])
+    assert np.array_equal(a["viol"], b["viol"]) and np.array_equal(a["order"], b["order"])
+    assert a["active"][0] == 1 and a["extra"][1] == 0, (a["active"], a["extra"])
+    one = _run(case, 1, 0, None, "f32", engine)
+    assert np.array_equal(one["order"], a["order"])
+    np.testing.assert_allclose(a["P"], one["P"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(a["w"], one["w"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(a["viol"], one["viol"], rtol=2e-5)
+    yp = np.concatenate([a["y_pred"], b["y_pred"]])
+    np.testing.assert_allclose(yp, one["y_pred"], rtol=0, atol=2e-4)
+
+
 def _est_worker(rank, world, port, q):
     try:
         sys.path.insert(0, ROOT)

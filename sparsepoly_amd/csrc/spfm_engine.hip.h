@@ -299,6 +299,7 @@ struct spfm_engine {
     int wide_lds_cap = -1;   // option "wide_lds_rows" (see wide_launch)
     bool wide_ep = true;     // option "wide_ep": rows (also) in global memory -> entry-parallel form
     int wide_ep_active = 0;  // what the last wide pass used
+    bool wide_rec8 = true;   // option "wide_rec8": squared loss, float: 8-byte (A, residual) row records
     DevBuf w_wbase, w_wsp, w_erow, w_eval, w_slabA, w_slabB;
     // persistent pbcd pass (spfm_pbprb.hip.h): its own workgroup count, hence its own entry
     // stream when that differs from the pcd / cd_linear pass's

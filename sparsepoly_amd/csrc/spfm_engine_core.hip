@@ -1690,6 +1690,8 @@ int spfm_set_option(spfm_handle h, const char* key, int value) {
         h->wide_lds_cap = value;
     } else if (k == "wide_ep") {  // wide pass, rows in global memory: entry-parallel form (default)
         h->wide_ep = value != 0;
+    } else if (k == "wide_rec8") {  // ... with 8-byte (A, residual) records where they apply
+        h->wide_rec8 = value != 0;
     } else if (k == "prb_groups") {
         if (value < 1) {
             h->err = "prb_groups must be >= 1";
@@ -1729,6 +1731,7 @@ int spfm_get_option(spfm_handle h, const char* key, int* value) {
     else if (k == "wide_lds_active") *value = h->wide_lr_active;
     else if (k == "wide_lds_rows") *value = h->wide_lds_cap;
     else if (k == "wide_ep") *value = h->wide_ep;
+    else if (k == "wide_rec8") *value = h->wide_rec8;
     else if (k == "wide_ep_active") *value = h->wide_ep_active;
     else if (k == "pbprb_groups") *value = h->pbprb_G;
     else if (k == "pcdw_groups") *value = h->wide_ready ? h->wide_G : h->pcdw_G;  // 0 = not chosen yet

@@ -158,17 +158,34 @@ int spfm_engine::wide_launch(PcdwArgs& a, PcdwParams& pp, T* Aptr) {
     // pcd with the rows in global memory: packed row records (see PcdwRec)
     PcdwRec<T>* rec = nullptr;
     const bool packed = KIND == 0 && !use_lr;
+    // squared loss, float, entry-parallel form: 8-byte (A, residual) records (option "wide_rec8")
+    const bool rec8 = packed && can_lr && use_ep && loss == SPFM_LOSS_SQUARED && wide_rec8 &&
+                      !wide_stamp_on;
     if (packed) {
         HIPC(w_rec.alloc(sizeof(PcdwRec<T>) * (size_t)n));
         rec = w_rec.as<PcdwRec<T>>();
-        hipLaunchKernelGGL((pcdw_pack_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
-                           pp.ctl, n, pp.a_stride, yy.as<T>(), Aptr, rec);
+        if constexpr (can_lr && KIND == 0) {
+            if (rec8)
+                hipLaunchKernelGGL(pcdw_pack8_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, pp.ctl,
+                                   n, pp.a_stride, yy.as<float>(), (const float*)Aptr,
+                                   reinterpret_cast<float2*>(rec));
+        }
+        if (!rec8)
+            hipLaunchKernelGGL((pcdw_pack_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                               pp.ctl, n, pp.a_stride, yy.as<T>(), Aptr, rec);
         HIPC(hipGetLastError());
     }
     auto unpack = [&]() -> int {
         if (packed) {
-            hipLaunchKernelGGL((pcdw_unpack_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0,
-                               stream, pp.ctl, n, pp.a_stride, rec, yy.as<T>(), Aptr);
+            if constexpr (can_lr && KIND == 0) {
+                if (rec8)
+                    hipLaunchKernelGGL(pcdw_unpack8_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                                       pp.ctl, n, pp.a_stride, reinterpret_cast<const float2*>(rec),
+                                       yy.as<float>(), (float*)Aptr);
+            }
+            if (!rec8)
+                hipLaunchKernelGGL((pcdw_unpack_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0,
+                                   stream, pp.ctl, n, pp.a_stride, rec, yy.as<T>(), Aptr);
             HIPC(hipGetLastError());
         }
         return SPFM_OK;
@@ -203,9 +220,23 @@ int spfm_engine::wide_launch(PcdwArgs& a, PcdwParams& pp, T* Aptr) {
             return use_ep ? fire(&pcdwe_kernel<T, KIND, 1>, std::max(lds_lr, kPrbLds))
                           : fire(&pcdw_kernel<T, KIND, 1>, std::max(lds_lr, kPrbLds));
         if (use_hyb) {
+            if constexpr (KIND == 0) {
+                if (rec8) {
+                    int hrc8 = fire(&pcdwe_kernel<T, KIND, 2, false, true>, std::max(lds_hyb, kPrbLds));
+                    if (hrc8) return hrc8;
+                    return unpack();
+                }
+            }
             int hrc = use_ep ? fire(&pcdwe_kernel<T, KIND, 2>, std::max(lds_hyb, kPrbLds))
                              : fire(&pcdw_kernel<T, KIND, 2>, std::max(lds_hyb, kPrbLds));
             if (hrc) return hrc;
+            return unpack();
+        }
+    }
+    if constexpr (can_lr && KIND == 0) {
+        if (rec8) {
+            int frc8 = fire(&pcdwe_kernel<T, KIND, 0, false, true>, std::max(fixed, kPrbLds));
+            if (frc8) return frc8;
             return unpack();
         }
     }

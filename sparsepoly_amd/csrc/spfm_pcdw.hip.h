@@ -141,6 +141,30 @@ __global__ void pcdw_unpack_kernel(const Ctl* __restrict__ ctl, int64_t n, size_
     }
 }
 
+// Squared loss, float storage: the record of a row in global memory can be the 8 bytes the LDS
+// rows are -- (A_s[i], r_i = yhat_i - y_i): dloss IS the residual -- half the bytes per random
+// access, twice the rows per cache line and per megabyte of L2 (round 4, pcdwe_kernel R8).
+static __global__ void pcdw_pack8_kernel(const Ctl* __restrict__ ctl, int64_t n, size_t a_stride,
+                                         const float* __restrict__ yy, const float* __restrict__ A_all,
+                                         float2* __restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float* A = A_all + (size_t)ctl->s * a_stride;
+        rec[i] = make_float2(A[i], (float)((double)yy[2 * i] - (double)yy[2 * i + 1]));
+    }
+}
+static __global__ void pcdw_unpack8_kernel(const Ctl* __restrict__ ctl, int64_t n, size_t a_stride,
+                                           const float2* __restrict__ rec, float* __restrict__ yy,
+                                           float* __restrict__ A_all) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float* A = A_all + (size_t)ctl->s * a_stride;
+        const float2 r = rec[i];
+        A[i] = r.x;
+        yy[2 * i] = (float)((double)r.y + (double)yy[2 * i + 1]);
+    }
+}
+
 template <typename T>
 struct PcdwSet {  // a thread's entries of one step: [e0, e0 + cnt), the first kPcdwEPT loaded
     int e0, cnt;
@@ -697,7 +721,7 @@ struct PcdweSet {  // a thread's share of a (workgroup, step)'s entries: E0 + ti
     T x[kPcdweEPR];
 };
 
-template <typename T, int KIND, int LR, bool STAMP = false>
+template <typename T, int KIND, int LR, bool STAMP = false, bool R8 = false>
 __global__ __launch_bounds__(kPcdwThreads) void pcdwe_kernel(PcdwArgs a, PcdwParams pp,
                                                              const T* __restrict__ eval,
                                                              T* __restrict__ A_all,
@@ -706,6 +730,8 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdwe_kernel(PcdwArgs a, PcdwPar
     static_assert(LR >= 0 && LR <= 2, "rows: 0 global memory, 1 LDS, 2 the block's first rows in LDS");
     static_assert(LR == 0 || sizeof(T) == 4, "LDS-resident rows: float storage");
     constexpr bool PACKED = (KIND == 0 && LR != 1);  // rows (also) in global memory: packed records
+    static_assert(!R8 || (PACKED && sizeof(T) == 4), "8-byte (A, residual) records: pcd, float");
+    float2* __restrict__ rec8 = reinterpret_cast<float2*>(rec);  // R8: (A, residual) per row
     constexpr bool HYB = (LR != 0);                  // rows may live in LDS
     constexpr bool ALL = (LR == 1);                  // ... all of them
     constexpr int NG = 16, L = 32, EPR = kPcdweEPR, CAP = kPcdweCap;
@@ -750,7 +776,11 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdwe_kernel(PcdwArgs a, PcdwPar
     if constexpr (HYB) {  // the block's (first) rows -> LDS (residual form: dloss = yhat - y)
         const int nr = min(lds_n, a.n_rows - row0);
         for (int il = tid; il < nr; il += kPcdwThreads) {
-            if constexpr (PACKED) {  // (the pass's rows were packed into records)
+            if constexpr (R8) {
+                const float2 r = rec8[(size_t)(row0 + il)];
+                lds_a[il] = r.x;
+                lds_r[il] = r.y;
+            } else if constexpr (PACKED) {  // (the pass's rows were packed into records)
                 const PcdwRec<T> r = rec[(size_t)(row0 + il)];
                 lds_a[il] = r.a;
                 lds_r[il] = (T)((double)r.yh - (double)r.y);
@@ -808,6 +838,11 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdwe_kernel(PcdwArgs a, PcdwPar
                     yh[r] = lds_r[i - row0];
                     yt[r] = (T)0;
                     if constexpr (KIND == 0) av[r] = lds_a[i - row0];
+                } else if constexpr (R8) {
+                    const float2 rr = rec8[(size_t)i];
+                    yh[r] = rr.y;
+                    yt[r] = (T)0;
+                    av[r] = rr.x;
                 } else if constexpr (PACKED) {
                     const PcdwRec<T> rr = rec[(size_t)i];
                     yh[r] = rr.yh;
@@ -923,6 +958,11 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdwe_kernel(PcdwArgs a, PcdwPar
                     y0 = (double)lds_r[i - row0];
                     y1 = 0.0;
                     if constexpr (KIND == 0) a1 = (double)lds_a[i - row0];
+                } else if constexpr (R8) {
+                    const float2 rr = rec8[i];
+                    y0 = (double)rr.y;
+                    y1 = 0.0;
+                    a1 = (double)rr.x;
                 } else if constexpr (PACKED) {
                     const PcdwRec<T> rr = rec[i];
                     y0 = (double)rr.yh;
@@ -1137,6 +1177,11 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdwe_kernel(PcdwArgs a, PcdwPar
                         } else {
                             lds_r[il] = (T)((double)yh[r] - dlt * x);
                         }
+                    } else if constexpr (R8) {
+                        const double a1 = (double)av[r];
+                        const double dprev = x * (a1 - pv[r] * x);
+                        rec8[(size_t)i] = make_float2((float)(a1 - dlt * x),
+                                                      (float)((double)yh[r] - lam * dlt * dprev));
                     } else if constexpr (PACKED) {
                         const double a1 = (double)av[r];
                         const double dprev = x * (a1 - pv[r] * x);
@@ -1166,6 +1211,12 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdwe_kernel(PcdwArgs a, PcdwPar
                     } else {
                         lds_r[il] = (T)((double)lds_r[il] - delta * x);
                     }
+                } else if constexpr (R8) {
+                    const float2 rr = rec8[(size_t)i];
+                    const double a1 = (double)rr.x;
+                    const double dprev = x * (a1 - s0 * x);
+                    rec8[(size_t)i] = make_float2((float)(a1 - delta * x),
+                                                  (float)((double)rr.y - lam * delta * dprev));
                 } else if constexpr (PACKED) {
                     PcdwRec<T> rr = rec[(size_t)i];
                     const double a1 = (double)rr.a;
@@ -1221,7 +1272,9 @@ __global__ __launch_bounds__(kPcdwThreads) void pcdwe_kernel(PcdwArgs a, PcdwPar
         const int nr = min(lds_n, a.n_rows - row0);
         for (int il = tid; il < nr; il += kPcdwThreads) {
             const size_t i = (size_t)(row0 + il);
-            if constexpr (PACKED) {  // into the records (unpacked behind the pass)
+            if constexpr (R8) {
+                rec8[i] = make_float2(lds_a[il], lds_r[il]);
+            } else if constexpr (PACKED) {  // into the records (unpacked behind the pass)
                 PcdwRec<T> r = rec[i];
                 r.yh = (T)((double)lds_r[il] + (double)r.y);
                 r.a = lds_a[il];
